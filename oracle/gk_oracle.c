@@ -1,0 +1,799 @@
+/*
+ * gk_oracle.c — CPU ORACLE (test infrastructure, NOT product code).  See gk_oracle.h.
+ *
+ * Literal single-threaded restatement of the reference algorithm; every function cites the
+ * reference lines it follows (S/ = /root/reference/src/main/scala/ru/ifmo/genome/).
+ * Java/Scala integer semantics are reproduced explicitly: 64-bit shifts use the count mod 64,
+ * `>>` is arithmetic, `>>>` logical, Int arithmetic wraps at 32 bits.
+ * PARITY STATUS: parity unpinned (no reference tests/fixtures exist; see header).
+ */
+#include "gk_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+/* ---------- Java-semantics helpers ---------- */
+static inline int64_t jshl(int64_t v, int n) { return (int64_t)((uint64_t)v << (n & 63)); }
+static inline int64_t jshr(int64_t v, int n) { return v >> (n & 63); }               /* >>  */
+static inline int64_t jushr(int64_t v, int n) { return (int64_t)((uint64_t)v >> (n & 63)); } /* >>> */
+
+int gko_k_supported(int k) { return (k >= 2 && k <= 31) || (k >= 34 && k <= 64); }
+
+/* S/dna/Base.scala:13-19 */
+int gko_base_complement(int b) {
+    static const int comp[4] = {3 /*A->T*/, 2 /*G->C*/, 1 /*C->G*/, 0 /*T->A*/};
+    return comp[b & 3];
+}
+int gko_base_from_char(char c) {
+    switch (c) { case 'A': return 0; case 'G': return 1; case 'C': return 2; case 'T': return 3; }
+    return -1;
+}
+char gko_base_to_char(int b) { return "AGCT"[b & 3]; }
+
+/* Long1DNASeq.apply :80-85 / Long2DNASeq.apply :178-184 */
+int gko_kmer_get(gko_kmer x, int i) {
+    uint64_t w = i < 32 ? x.lo : x.hi;
+    return (int)((w >> ((i % 32) * 2)) & 3);
+}
+
+/* DNASeq.newBuilder :237-281 (count <= 64 branch) */
+gko_kmer gko_kmer_from_bases(const uint8_t *bases, int len) {
+    gko_kmer r = {0, 0};
+    for (int c = 0; c < len; c++) {
+        if (c < 32) r.lo |= (uint64_t)(bases[c] & 3) << (c * 2);
+        else r.hi |= (uint64_t)(bases[c] & 3) << ((c % 32) * 2);
+    }
+    return r;
+}
+
+/* ArrayDNASeq.apply :46-51: base i = (data(i/4) >> (i%4*2)) & 3; then sliding(k) window via builder */
+gko_kmer gko_kmer_from_packed(const uint8_t *packed, int pos, int k) {
+    gko_kmer r = {0, 0};
+    for (int c = 0; c < k; c++) {
+        int i = pos + c;
+        uint64_t b = (uint64_t)((packed[i / 4] >> ((i % 4) * 2)) & 3);
+        if (c < 32) r.lo |= b << (c * 2);
+        else r.hi |= b << ((c % 32) * 2);
+    }
+    return r;
+}
+
+/* Long1DNASeq.complement :165-168 (note `length == 64` test, kept literally) */
+static int64_t long1_complement(int64_t v, int len) {
+    int64_t mask = (len == 64) ? -1LL : (int64_t)((uint64_t)jshl(1, 2 * len) - 1ULL);
+    return v ^ mask;
+}
+/* Long1DNASeq.reverse :155-163 */
+static int64_t long1_reverse(int64_t v, int len) {
+    int64_t i = v;
+    i = jshl(i & 0x3333333333333333LL, 2) | (jushr(i, 2) & 0x3333333333333333LL);
+    i = jshl(i & 0x0f0f0f0f0f0f0f0fLL, 4) | (jushr(i, 4) & 0x0f0f0f0f0f0f0f0fLL);
+    i = jshl(i & 0x00ff00ff00ff00ffLL, 8) | (jushr(i, 8) & 0x00ff00ff00ff00ffLL);
+    i = jshl(i, 48) | jshl(i & 0xffff0000LL, 16) | (jushr(i, 16) & 0xffff0000LL) | jushr(i, 48);
+    return jushr(i, 2 * (32 - len));
+}
+
+/* DNASeq.revComplement :28 = complement.reverse.  k<=32: Long1 bit tricks; k>32: the generic
+ * IndexedSeq map/reverse through the builder (Long2DNASeq has no specialisation, :172-215). */
+gko_kmer gko_revcomp(gko_kmer x, int k) {
+    gko_kmer r = {0, 0};
+    if (k <= 32) {
+        r.lo = (uint64_t)long1_reverse(long1_complement((int64_t)x.lo, k), k);
+        return r;
+    }
+    uint8_t b[64];
+    for (int i = 0; i < k; i++) b[i] = (uint8_t)gko_base_complement(gko_kmer_get(x, i));
+    uint8_t rv[64];
+    for (int i = 0; i < k; i++) rv[i] = b[k - 1 - i];
+    return gko_kmer_from_bases(rv, k);
+}
+
+/* scala-library 2.9.1 `Long.##` = BoxesRunTime.hashFromLong: iv = n.intValue; if (iv == n) iv else
+ * java.lang.Long.hashCode(n) = (int)(n ^ (n >>> 32)).  THIRD-PARTY, restated from the published
+ * 2.9.x definition; unpinned by any reference test. */
+static int32_t scala291_long_hash(int64_t lv) {
+    int32_t iv = (int32_t)lv;
+    if ((int64_t)iv == lv) return iv;
+    return (int32_t)(lv ^ jushr(lv, 32));
+}
+
+/* Long2DNASeq.multiHashCode :204-208, seed sign-extended to Long */
+static int32_t long2_multihash(int64_t l1, int64_t l2, int32_t seed) {
+    int64_t s = (int64_t)seed;
+    int64_t t = (int64_t)((uint64_t)(l1 ^ jshr(l1, 32)) * (uint64_t)s);
+    int64_t t1 = (int64_t)((uint64_t)(l2 ^ jshr(l2, 32) ^ t) * (uint64_t)s);
+    return (int32_t)(t1 ^ jshr(t1, 32));
+}
+
+/* hashCode: Long1DNASeq :103 (`long.##`); Long2DNASeq inherits MultiHash.hashCode =
+ * multiHashCode(42) (S/ds/BloomFilter.scala:12-15). */
+int32_t gko_hash(gko_kmer x, int k) {
+    if (k <= 32) return scala291_long_hash((int64_t)x.lo);
+    return long2_multihash((int64_t)x.lo, (int64_t)x.hi, 42);
+}
+
+/* FreqFilter.scala:31-32: y = if (x.hashCode < rcx.hashCode) x else rcx  (signed; tie -> rcx) */
+gko_kmer gko_canon(gko_kmer x, int k) {
+    gko_kmer rcx = gko_revcomp(x, k);
+    return gko_hash(x, k) < gko_hash(rcx, k) ? x : rcx;
+}
+
+/* ArrayDNAMap.improve :267-272 (32-bit wrapping, >>> logical) */
+int32_t gko_improve(int32_t hcode) {
+    uint32_t hc = (uint32_t)hcode;
+    uint32_t h = hc + ~(hc << 9);
+    h = h ^ (h >> 14);
+    h = h + (h << 4);
+    return (int32_t)(h ^ (h >> 10));
+}
+
+/* PartitionedDNAMap.partition :60-63: fix(hashCode % P), Java remainder (sign of dividend) */
+int gko_partition(gko_kmer x, int k, int P) {
+    int32_t i = gko_hash(x, k) % P;
+    return i < 0 ? i + P : i;
+}
+
+/* base +: x.take(k-1)  (Graph.scala:273; Long1 `+:` :135-143, generic otherwise) */
+gko_kmer gko_prepend(int b, gko_kmer x, int k) {
+    uint8_t s[64];
+    s[0] = (uint8_t)b;
+    for (int i = 0; i < k - 1; i++) s[i + 1] = (uint8_t)gko_kmer_get(x, i);
+    return gko_kmer_from_bases(s, k);
+}
+/* x.drop(1) :+ base  (Graph.scala:279; Long1 `:+` :145-153 for k<=32 since len k-1 < 32) */
+gko_kmer gko_append(gko_kmer x, int b, int k) {
+    uint8_t s[64];
+    for (int i = 1; i < k; i++) s[i - 1] = (uint8_t)gko_kmer_get(x, i);
+    s[k - 1] = (uint8_t)b;
+    return gko_kmer_from_bases(s, k);
+}
+
+int gko_kmer_cmp(gko_kmer a, gko_kmer b) {
+    if (a.hi != b.hi) return a.hi < b.hi ? -1 : 1;
+    if (a.lo != b.lo) return a.lo < b.lo ? -1 : 1;
+    return 0;
+}
+static int kmer_eq(gko_kmer a, gko_kmer b) { return a.lo == b.lo && a.hi == b.hi; }
+
+/* ================= ArrayDNAMap.Container (ArrayDNAMap.scala:74-179) ================= */
+typedef struct {
+    int bins, mask, size;
+    gko_kmer *keys;
+    int32_t *ar;
+    uint8_t *set, *del; /* one byte per bin: the two BitSets */
+} container;
+
+struct gko_map {
+    int k;
+    int rescales;
+    container *c;
+};
+
+static container *container_new(int bins) {
+    container *c = (container *)calloc(1, sizeof(container));
+    c->bins = bins;
+    c->mask = bins - 1;
+    c->keys = (gko_kmer *)calloc((size_t)bins, sizeof(gko_kmer));
+    c->ar = (int32_t *)calloc((size_t)bins, sizeof(int32_t));
+    c->set = (uint8_t *)calloc((size_t)bins, 1);
+    c->del = (uint8_t *)calloc((size_t)bins, 1);
+    return c;
+}
+static void container_free(container *c) {
+    if (!c) return;
+    free(c->keys); free(c->ar); free(c->set); free(c->del); free(c);
+}
+
+/* Container.putNew :152-162 */
+static void container_put_new(container *c, int k, gko_kmer key, int32_t v) {
+    int i = gko_improve(gko_hash(key, k)) & c->mask;
+    while (!c->del[i] && c->set[i]) i = (i + 1) & c->mask;
+    c->set[i] = 1;
+    c->del[i] = 0;
+    c->size += 1;
+    c->keys[i] = key;
+    c->ar[i] = v;
+}
+
+/* ArrayDNAMap.rescale :217-230; load factors :246-247; Int*Double compares */
+static void map_rescale(gko_map *m) {
+    container *c = m->c;
+    double bins = (double)c->bins;
+    if ((c->bins > 16 && (double)c->size < bins * 0.3) || bins * 0.7 < (double)c->size) {
+        int newBins = 16;
+        while ((double)newBins * 0.7 < (double)c->size) newBins *= 2;
+        container *n = container_new(newBins);
+        for (int i = 0; i < c->bins; i++)   /* container.iterator: slot order, live only */
+            if (c->set[i] && !c->del[i]) container_put_new(n, m->k, c->keys[i], c->ar[i]);
+        container_free(c);
+        m->c = n;
+        m->rescales++;
+    }
+}
+
+gko_map *gko_map_new(int k) {
+    gko_map *m = (gko_map *)calloc(1, sizeof(gko_map));
+    m->k = k;
+    m->c = container_new(16); /* :72 */
+    return m;
+}
+void gko_map_free(gko_map *m) {
+    if (!m) return;
+    container_free(m->c);
+    free(m);
+}
+int gko_map_size(const gko_map *m) { return m->c->size; }
+int gko_map_bins(const gko_map *m) { return m->c->bins; }
+int gko_map_rescales(const gko_map *m) { return m->rescales; }
+
+/* Container.update(key, v0, f) :129-150 with v0 = 1, f = _+1 (FreqFilter.scala:33); then rescale :201 */
+void gko_map_update_inc(gko_map *m, gko_kmer key) {
+    container *c = m->c;
+    int i = gko_improve(gko_hash(key, m->k)) & c->mask;
+    int firstPos = -1;
+    while (c->set[i] && (c->del[i] || !kmer_eq(c->keys[i], key))) {
+        if (c->del[i]) firstPos = i;
+        i = (i + 1) & c->mask;
+    }
+    if (!c->set[i]) {
+        if (firstPos != -1) {
+            i = firstPos;
+            c->del[i] = 0;
+        }
+        c->set[i] = 1;
+        c->keys[i] = key;
+        c->size += 1;
+        c->ar[i] = 1;
+    } else {
+        c->ar[i] = (int32_t)((uint32_t)c->ar[i] + 1u); /* Int wraps */
+    }
+    map_rescale(m);
+}
+
+/* Container.update(key, v) :115-127; then rescale :194 */
+void gko_map_update_set(gko_map *m, gko_kmer key, int32_t v) {
+    container *c = m->c;
+    int i = gko_improve(gko_hash(key, m->k)) & c->mask;
+    while (!c->del[i] && c->set[i] && !kmer_eq(c->keys[i], key)) i = (i + 1) & c->mask;
+    if (c->del[i] || !c->set[i]) {
+        c->set[i] = 1;
+        c->del[i] = 0;
+        c->keys[i] = key;
+        c->size += 1;
+    }
+    c->ar[i] = v;
+    map_rescale(m);
+}
+
+void gko_map_put_new(gko_map *m, gko_kmer key, int32_t v) {
+    container_put_new(m->c, m->k, key, v);
+    map_rescale(m);
+}
+
+/* Container.apply :90-101 */
+int gko_map_get(const gko_map *m, gko_kmer key, int32_t *v) {
+    const container *c = m->c;
+    int i = gko_improve(gko_hash(key, m->k)) & c->mask;
+    while (c->set[i]) {
+        if (!c->del[i] && kmer_eq(c->keys[i], key)) {
+            if (v) *v = c->ar[i];
+            return 1;
+        }
+        i = (i + 1) & c->mask;
+    }
+    return 0;
+}
+
+/* Container.getAll :103-113 (`ans ::= v` prepends: last probed first) */
+int gko_map_get_all(const gko_map *m, gko_kmer key, int32_t *out, int cap) {
+    const container *c = m->c;
+    int i = gko_improve(gko_hash(key, m->k)) & c->mask;
+    int n = 0;
+    while (c->set[i]) {
+        if (!c->del[i] && kmer_eq(c->keys[i], key)) {
+            if (n < cap) {
+                memmove(out + 1, out, (size_t)n * sizeof(int32_t));
+                out[0] = c->ar[i];
+            }
+            n++;
+        }
+        i = (i + 1) & c->mask;
+    }
+    return n;
+}
+
+/* Container.deleteAll :164-173 with p = (k,v) => v < rounds (FreqFilter.scala:55); rescale :214 */
+void gko_map_delete_lt(gko_map *m, int32_t rounds) {
+    container *c = m->c;
+    for (int i = 0; i < c->bins; i++) {
+        if (c->set[i] && !c->del[i] && c->ar[i] < rounds) {
+            c->del[i] = 1;
+            c->size -= 1;
+        }
+    }
+    map_rescale(m);
+}
+
+/* Container.iterator :175-178 */
+size_t gko_map_export(const gko_map *m, uint64_t *lo, uint64_t *hi, int32_t *val, size_t cap) {
+    const container *c = m->c;
+    size_t n = 0;
+    for (int i = 0; i < c->bins; i++) {
+        if (c->set[i] && !c->del[i]) {
+            if (n < cap) {
+                if (lo) lo[n] = c->keys[i].lo;
+                if (hi) hi[n] = c->keys[i].hi;
+                if (val) val[n] = c->ar[i];
+            }
+            n++;
+        }
+    }
+    return n;
+}
+
+/* ================= PartitionedDNAMap (PartitionedDNAMap.scala:15-64) ================= */
+struct gko_pmap {
+    int k, P;
+    gko_map **parts;
+};
+
+gko_pmap *gko_pmap_new(int k, int P) {
+    gko_pmap *pm = (gko_pmap *)calloc(1, sizeof(gko_pmap));
+    pm->k = k;
+    pm->P = P;
+    pm->parts = (gko_map **)calloc((size_t)P, sizeof(gko_map *));
+    for (int p = 0; p < P; p++) pm->parts[p] = gko_map_new(k);
+    return pm;
+}
+void gko_pmap_free(gko_pmap *pm) {
+    if (!pm) return;
+    for (int p = 0; p < pm->P; p++) gko_map_free(pm->parts[p]);
+    free(pm->parts);
+    free(pm);
+}
+int gko_pmap_k(const gko_pmap *pm) { return pm->k; }
+int gko_pmap_parts(const gko_pmap *pm) { return pm->P; }
+gko_map *gko_pmap_part(gko_pmap *pm, int p) { return pm->parts[p]; }
+long gko_pmap_size(const gko_pmap *pm) { /* :31 */
+    long s = 0;
+    for (int p = 0; p < pm->P; p++) s += gko_map_size(pm->parts[p]);
+    return s;
+}
+int gko_pmap_get(const gko_pmap *pm, gko_kmer key, int32_t *v) { /* :33 */
+    return gko_map_get(pm->parts[gko_partition(key, pm->k, pm->P)], key, v);
+}
+int gko_pmap_contains(const gko_pmap *pm, gko_kmer key) { return gko_pmap_get(pm, key, NULL); } /* :53 */
+void gko_pmap_update_inc(gko_pmap *pm, gko_kmer key) { /* :41-43 */
+    gko_map_update_inc(pm->parts[gko_partition(key, pm->k, pm->P)], key);
+}
+void gko_pmap_delete_lt(gko_pmap *pm, int32_t rounds) { /* :49-51 */
+    for (int p = 0; p < pm->P; p++) gko_map_delete_lt(pm->parts[p], rounds);
+}
+
+typedef struct { gko_kmer key; int32_t v; } kv;
+static int kv_cmp(const void *a, const void *b) { return gko_kmer_cmp(((const kv *)a)->key, ((const kv *)b)->key); }
+
+size_t gko_pmap_export_sorted(const gko_pmap *pm, uint64_t *lo, uint64_t *hi, int32_t *val, size_t cap) {
+    size_t n = (size_t)gko_pmap_size(pm);
+    if (n > cap) return n;
+    kv *tmp = (kv *)malloc((n ? n : 1) * sizeof(kv));
+    size_t w = 0;
+    for (int p = 0; p < pm->P; p++) {
+        const container *c = pm->parts[p]->c;
+        for (int i = 0; i < c->bins; i++)
+            if (c->set[i] && !c->del[i]) { tmp[w].key = c->keys[i]; tmp[w].v = c->ar[i]; w++; }
+    }
+    qsort(tmp, w, sizeof(kv), kv_cmp);
+    for (size_t i = 0; i < w; i++) {
+        if (lo) lo[i] = tmp[i].key.lo;
+        if (hi) hi[i] = tmp[i].key.hi;
+        if (val) val[i] = tmp[i].v;
+    }
+    free(tmp);
+    return w;
+}
+
+/* FreqFilter.add :28-36 over PairedEndData.getPairs records :20-36.  Reads shorter than k are
+ * skipped (:29); every window in order (`sliding(k)`, :30); canonical choice :31-32; update :33. */
+long gko_count_reads(gko_pmap *pm, const uint8_t *bin, size_t nbytes, uint64_t nreads) {
+    size_t pos = 0;
+    long occ = 0;
+    int k = pm->k;
+    for (uint64_t r = 0; r < nreads; r++) {
+        if (pos >= nbytes) return -1;
+        int len = bin[pos++];
+        int byteLen = (len + 3) / 4;
+        if (pos + (size_t)byteLen > nbytes) return -1;
+        const uint8_t *data = bin + pos;
+        pos += (size_t)byteLen;
+        if (len >= k) {
+            for (int p = 0; p + k <= len; p++) {
+                gko_kmer x = gko_kmer_from_packed(data, p, k);
+                gko_pmap_update_inc(pm, gko_canon(x, k));
+                occ++;
+            }
+        }
+    }
+    return occ;
+}
+
+/* ================= Graph (S/data/graph/Graph.scala, Node.scala, Edge.scala) ================= */
+typedef struct {
+    gko_kmer seq;
+    int alive;
+    int nin, incap;
+    int64_t *in;           /* inEdgeIds: Set[Long] */
+    int nout;
+    int out_base[4];       /* outEdgeIds: immutable Map1..Map4 keeps insertion order */
+    int64_t out_edge[4];
+} gnode;
+
+typedef struct {
+    int64_t start, end;    /* node ids (1-based) */
+    uint8_t *seq;          /* one base code per byte */
+    int64_t len;
+    int alive;
+} gedge;
+
+struct gko_graph {
+    int k;
+    int64_t nnodes, ncap;  /* nodes[1..nnodes] */
+    gnode *nodes;
+    int64_t nedges, ecap;  /* edges[1..nedges] */
+    gedge *edges;
+    /* k-mer -> node id index: ids are assigned in ascending k-mer order, so binary search */
+};
+
+static int64_t graph_find_node(const gko_graph *g, gko_kmer x) {
+    int64_t lo = 1, hi = g->nnodes;
+    while (lo <= hi) {
+        int64_t mid = (lo + hi) / 2;
+        int c = gko_kmer_cmp(g->nodes[mid].seq, x);
+        if (c == 0) return mid;
+        if (c < 0) lo = mid + 1; else hi = mid - 1;
+    }
+    return 0;
+}
+
+/* MapGraph.addEdge :178-184 */
+static int64_t graph_add_edge(gko_graph *g, int64_t start, int64_t end, const uint8_t *seq, int64_t len) {
+    if (g->nedges + 1 >= g->ecap) {
+        g->ecap = g->ecap ? g->ecap * 2 : 64;
+        g->edges = (gedge *)realloc(g->edges, (size_t)g->ecap * sizeof(gedge));
+    }
+    int64_t id = ++g->nedges;
+    gedge *e = &g->edges[id];
+    e->start = start; e->end = end; e->len = len; e->alive = 1;
+    e->seq = (uint8_t *)malloc((size_t)(len ? len : 1));
+    memcpy(e->seq, seq, (size_t)len);
+    gnode *s = &g->nodes[start];
+    int b = seq[0], found = 0;
+    for (int i = 0; i < s->nout; i++)          /* Map `+ (k -> v)`: replace in place if key exists */
+        if (s->out_base[i] == b) { s->out_edge[i] = id; found = 1; }
+    if (!found) { s->out_base[s->nout] = b; s->out_edge[s->nout] = id; s->nout++; }
+    gnode *t = &g->nodes[end];
+    int have = 0;
+    for (int i = 0; i < t->nin; i++) if (t->in[i] == id) have = 1;
+    if (!have) {
+        if (t->nin == t->incap) {
+            t->incap = t->incap ? t->incap * 2 : 4;
+            t->in = (int64_t *)realloc(t->in, (size_t)t->incap * sizeof(int64_t));
+        }
+        t->in[t->nin++] = id;
+    }
+    return id;
+}
+
+/* MapGraph.removeEdge :191-195: start drops its out entry BY BASE KEY, end drops the id */
+static void graph_remove_edge(gko_graph *g, int64_t id) {
+    gedge *e = &g->edges[id];
+    if (g->nodes[e->start].alive) {
+        gnode *s = &g->nodes[e->start];
+        for (int i = 0; i < s->nout; i++)
+            if (s->out_base[i] == e->seq[0]) {
+                for (int j = i; j + 1 < s->nout; j++) { s->out_base[j] = s->out_base[j + 1]; s->out_edge[j] = s->out_edge[j + 1]; }
+                s->nout--;
+                break;
+            }
+    }
+    if (g->nodes[e->end].alive) {
+        gnode *t = &g->nodes[e->end];
+        for (int i = 0; i < t->nin; i++)
+            if (t->in[i] == id) { t->in[i] = t->in[t->nin - 1]; t->nin--; break; }
+    }
+    e->alive = 0;
+}
+
+/* Graph.buildGraph `contains` :270 — either strand, each strand asked of its own partition */
+static int g_contains(const gko_pmap *pm, gko_kmer x) {
+    return gko_pmap_contains(pm, x) || gko_pmap_contains(pm, gko_revcomp(x, pm->k));
+}
+/* incoming :272-276 / outcoming :278-282; bases tried in Base.fromInt order A,G,C,T */
+static int g_incoming(const gko_pmap *pm, gko_kmer x, int *bases) {
+    int n = 0;
+    for (int b = 0; b < 4; b++) if (g_contains(pm, gko_prepend(b, x, pm->k))) bases[n++] = b;
+    return n;
+}
+static int g_outcoming(const gko_pmap *pm, gko_kmer x, int *bases) {
+    int n = 0;
+    for (int b = 0; b < 4; b++) if (g_contains(pm, gko_append(x, b, pm->k))) bases[n++] = b;
+    return n;
+}
+
+static int kmer_qcmp(const void *a, const void *b) { return gko_kmer_cmp(*(const gko_kmer *)a, *(const gko_kmer *)b); }
+
+gko_graph *gko_graph_build(const gko_pmap *pm) {
+    int k = pm->k;
+    gko_graph *g = (gko_graph *)calloc(1, sizeof(gko_graph));
+    g->k = k;
+    /* op1 (:320-329): terminal <=> (in,out) not (1,1) and not (0,0), over every live stored key */
+    size_t tcap = 1024, tn = 0;
+    gko_kmer *term = (gko_kmer *)malloc(tcap * sizeof(gko_kmer));
+    for (int p = 0; p < pm->P; p++) {
+        const container *c = pm->parts[p]->c;
+        for (int i = 0; i < c->bins; i++) {
+            if (!(c->set[i] && !c->del[i])) continue;
+            int tmp[4];
+            int in = g_incoming(pm, c->keys[i], tmp);
+            int out = g_outcoming(pm, c->keys[i], tmp);
+            if ((in != 1 || out != 1) && (in != 0 || out != 0)) {
+                if (tn + 2 > tcap) { tcap *= 2; term = (gko_kmer *)realloc(term, tcap * sizeof(gko_kmer)); }
+                term[tn++] = c->keys[i];
+                term[tn++] = gko_revcomp(c->keys[i], k);   /* termKmers = set ++ set.map(revComplement) :330-333 */
+            }
+        }
+    }
+    qsort(term, tn, sizeof(gko_kmer), kmer_qcmp);
+    size_t un = 0;
+    for (size_t i = 0; i < tn; i++) if (un == 0 || gko_kmer_cmp(term[un - 1], term[i]) != 0) term[un++] = term[i];
+    /* nodeMap (:343-347): one node per terminal k-mer, ids ascending in k-mer order */
+    g->nnodes = (int64_t)un;
+    g->nodes = (gnode *)calloc(un + 2, sizeof(gnode));
+    for (size_t i = 0; i < un; i++) { g->nodes[i + 1].seq = term[i]; g->nodes[i + 1].alive = 1; }
+    free(term);
+    /* buildEdges (:349-365) */
+    size_t bcap = 256;
+    uint8_t *builder = (uint8_t *)malloc(bcap);
+    for (int64_t id = 1; id <= g->nnodes; id++) {
+        gko_kmer read = g->nodes[id].seq;
+        int outs[4];
+        int no = g_outcoming(pm, read, outs);
+        for (int oi = 0; oi < no; oi++) {
+            size_t len = 0;
+            builder[len++] = (uint8_t)outs[oi];
+            gko_kmer seq = gko_append(read, outs[oi], k);
+            int64_t endId;
+            while ((endId = graph_find_node(g, seq)) == 0) {
+                int o2[4];
+                int n2 = g_outcoming(pm, seq, o2);
+                if (n2 != 1) { /* reference: assert(out.size == 1) :357 */
+                    abort();
+                }
+                if (len == bcap) { bcap *= 2; builder = (uint8_t *)realloc(builder, bcap); }
+                builder[len++] = (uint8_t)o2[0];
+                seq = gko_append(seq, o2[0], k);
+            }
+            graph_add_edge(g, id, endId, builder, (int64_t)len);
+        }
+    }
+    free(builder);
+    return g;
+}
+
+void gko_graph_free(gko_graph *g) {
+    if (!g) return;
+    for (int64_t i = 1; i <= g->nnodes; i++) free(g->nodes[i].in);
+    for (int64_t i = 1; i <= g->nedges; i++) free(g->edges[i].seq);
+    free(g->nodes); free(g->edges); free(g);
+}
+int gko_graph_k(const gko_graph *g) { return g->k; }
+long gko_graph_num_nodes(const gko_graph *g) {
+    long n = 0;
+    for (int64_t i = 1; i <= g->nnodes; i++) n += g->nodes[i].alive;
+    return n;
+}
+long gko_graph_num_edges(const gko_graph *g) {
+    long n = 0;
+    for (int64_t i = 1; i <= g->nedges; i++) n += g->edges[i].alive;
+    return n;
+}
+long gko_graph_total_edge_len(const gko_graph *g) {
+    long n = 0;
+    for (int64_t i = 1; i <= g->nedges; i++) if (g->edges[i].alive) n += g->edges[i].len;
+    return n;
+}
+
+/* MapGraph.simplifyGraph :211-230 */
+void gko_graph_simplify(gko_graph *g) {
+    for (int64_t id = 1; id <= g->nnodes; id++) {
+        gnode *n = &g->nodes[id];
+        if (!n->alive) continue;
+        if (n->nin == 0 && n->nout == 0) {
+            n->alive = 0;                                   /* removeNode */
+        } else if (n->nin == 1 && n->nout == 1) {
+            int64_t e1 = n->in[0], e2 = n->out_edge[0];
+            if (e1 == e2) {
+                graph_remove_edge(g, e1);
+            } else {
+                graph_remove_edge(g, e1);
+                graph_remove_edge(g, e2);
+                int64_t l1 = g->edges[e1].len, l2 = g->edges[e2].len;
+                uint8_t *s = (uint8_t *)malloc((size_t)(l1 + l2));
+                memcpy(s, g->edges[e1].seq, (size_t)l1);
+                memcpy(s + l1, g->edges[e2].seq, (size_t)l2);
+                int64_t st = g->edges[e1].start, en = g->edges[e2].end;
+                graph_add_edge(g, st, en, s, l1 + l2);     /* may realloc g->edges */
+                free(s);
+                n = &g->nodes[id];
+            }
+            n->alive = 0;                                   /* removeNode */
+        }
+    }
+}
+
+/* Graph.similar :121-123 */
+static int similar_len(int64_t a, int64_t b) {
+    int64_t d = a > b ? a - b : b - a;
+    int64_t mx = a > b ? a : b;
+    return d * 5 < mx;
+}
+
+/* Graph.removeBubbles :125-149 */
+void gko_graph_remove_bubbles(gko_graph *g) {
+    for (int64_t id = 1; id <= g->nnodes; id++) {
+        gnode *n = &g->nodes[id];
+        if (!n->alive) continue;
+        int cnt = n->nout;
+        int64_t out[4];
+        int removed[4] = {0, 0, 0, 0};
+        for (int i = 0; i < cnt; i++) out[i] = n->out_edge[i];
+        for (int i = 0; i < cnt; i++) {
+            if (removed[i]) continue;
+            for (int j = i + 1; j < cnt; j++)
+                if (g->edges[out[i]].end == g->edges[out[j]].end &&
+                    similar_len(g->edges[out[i]].len, g->edges[out[j]].len))
+                    removed[j] = 1;
+        }
+        for (int j = 0; j < cnt; j++) if (removed[j]) graph_remove_edge(g, out[j]);
+    }
+}
+
+int gko_graph_remove_edge(gko_graph *g, gko_kmer start, int base) {
+    int64_t id = graph_find_node(g, start);
+    if (!id || !g->nodes[id].alive) return 0;
+    gnode *n = &g->nodes[id];
+    for (int i = 0; i < n->nout; i++)
+        if (n->out_base[i] == base) { graph_remove_edge(g, n->out_edge[i]); return 1; }
+    return 0;
+}
+
+/* Graph.components :54-72 = connected components of the undirected node graph */
+static int64_t *graph_component_labels(const gko_graph *g, int64_t *ncomp_out) {
+    int64_t *label = (int64_t *)calloc((size_t)g->nnodes + 2, sizeof(int64_t));
+    int64_t *stack = (int64_t *)malloc(((size_t)g->nnodes + 2) * sizeof(int64_t));
+    /* undirected adjacency through live edges */
+    int64_t ncomp = 0;
+    /* build CSR of neighbours */
+    int64_t *deg = (int64_t *)calloc((size_t)g->nnodes + 2, sizeof(int64_t));
+    for (int64_t e = 1; e <= g->nedges; e++) if (g->edges[e].alive) { deg[g->edges[e].start]++; deg[g->edges[e].end]++; }
+    int64_t *off = (int64_t *)calloc((size_t)g->nnodes + 3, sizeof(int64_t));
+    for (int64_t i = 1; i <= g->nnodes; i++) off[i + 1] = off[i] + deg[i];
+    int64_t *adj = (int64_t *)malloc(((size_t)off[g->nnodes + 1] + 1) * sizeof(int64_t));
+    memset(deg, 0, ((size_t)g->nnodes + 2) * sizeof(int64_t));
+    for (int64_t e = 1; e <= g->nedges; e++) if (g->edges[e].alive) {
+        int64_t s = g->edges[e].start, t = g->edges[e].end;
+        adj[off[s] + deg[s]++] = t;
+        adj[off[t] + deg[t]++] = s;
+    }
+    for (int64_t i = 1; i <= g->nnodes; i++) {
+        if (!g->nodes[i].alive || label[i]) continue;
+        ncomp++;
+        int64_t sp = 0;
+        stack[sp++] = i;
+        label[i] = ncomp;
+        while (sp) {
+            int64_t u = stack[--sp];
+            for (int64_t a = off[u]; a < off[u + 1]; a++) {
+                int64_t v = adj[a];
+                if (g->nodes[v].alive && !label[v]) { label[v] = ncomp; stack[sp++] = v; }
+            }
+        }
+    }
+    free(stack); free(deg); free(off); free(adj);
+    *ncomp_out = ncomp;
+    return label;
+}
+
+long gko_graph_num_components(const gko_graph *g) {
+    int64_t nc;
+    int64_t *l = graph_component_labels(g, &nc);
+    free(l);
+    return (long)nc;
+}
+
+/* GraphBuilder.scala:52-54 maxBy(_.size) + MapGraph.retain :161-165 */
+long gko_graph_retain_largest(gko_graph *g) {
+    int64_t nc;
+    int64_t *label = graph_component_labels(g, &nc);
+    if (nc == 0) { free(label); return 0; }
+    int64_t *sz = (int64_t *)calloc((size_t)nc + 1, sizeof(int64_t));
+    for (int64_t i = 1; i <= g->nnodes; i++) if (g->nodes[i].alive) sz[label[i]]++;
+    /* labels were handed out in ascending node id = ascending k-mer, so the first maximum is
+     * the component holding the smallest k-mer among the largest ones */
+    int64_t best = 1;
+    for (int64_t c = 2; c <= nc; c++) if (sz[c] > sz[best]) best = c;
+    for (int64_t e = 1; e <= g->nedges; e++)
+        if (g->edges[e].alive && !(label[g->edges[e].start] == best && label[g->edges[e].end] == best))
+            g->edges[e].alive = 0;
+    for (int64_t i = 1; i <= g->nnodes; i++)
+        if (g->nodes[i].alive && label[i] != best) g->nodes[i].alive = 0;
+    long r = (long)sz[best];
+    free(sz); free(label);
+    return r;
+}
+
+size_t gko_graph_export_nodes(const gko_graph *g, uint64_t *lo, uint64_t *hi, size_t cap) {
+    size_t n = 0;
+    for (int64_t i = 1; i <= g->nnodes; i++) {
+        if (!g->nodes[i].alive) continue;
+        if (n < cap) { if (lo) lo[n] = g->nodes[i].seq.lo; if (hi) hi[n] = g->nodes[i].seq.hi; }
+        n++;
+    }
+    return n;
+}
+
+typedef struct { gko_kmer s; int b; int64_t id; } esort;
+static int esort_cmp(const void *a, const void *b) {
+    const esort *x = (const esort *)a, *y = (const esort *)b;
+    int c = gko_kmer_cmp(x->s, y->s);
+    if (c) return c;
+    if (x->b != y->b) return x->b < y->b ? -1 : 1;
+    return x->id < y->id ? -1 : (x->id > y->id);
+}
+
+size_t gko_graph_export_edges(const gko_graph *g, uint64_t *slo, uint64_t *shi, uint64_t *elo,
+                              uint64_t *ehi, int64_t *len, int64_t *off, size_t cap,
+                              uint8_t *bases_out, size_t bases_cap, size_t *nbases_out) {
+    size_t ne = (size_t)gko_graph_num_edges(g);
+    esort *es = (esort *)malloc((ne ? ne : 1) * sizeof(esort));
+    size_t w = 0;
+    for (int64_t e = 1; e <= g->nedges; e++) if (g->edges[e].alive) {
+        es[w].s = g->nodes[g->edges[e].start].seq;
+        es[w].b = g->edges[e].seq[0];
+        es[w].id = e;
+        w++;
+    }
+    qsort(es, w, sizeof(esort), esort_cmp);
+    size_t nb = 0;
+    for (size_t i = 0; i < w; i++) {
+        const gedge *e = &g->edges[es[i].id];
+        if (i < cap) {
+            if (slo) slo[i] = g->nodes[e->start].seq.lo;
+            if (shi) shi[i] = g->nodes[e->start].seq.hi;
+            if (elo) elo[i] = g->nodes[e->end].seq.lo;
+            if (ehi) ehi[i] = g->nodes[e->end].seq.hi;
+            if (len) len[i] = e->len;
+            if (off) off[i] = (int64_t)nb;
+            if (bases_out && nb + (size_t)e->len <= bases_cap) memcpy(bases_out + nb, e->seq, (size_t)e->len);
+        }
+        nb += (size_t)e->len;
+    }
+    free(es);
+    if (nbases_out) *nbases_out = nb;
+    return w;
+}
+
+int gko_graph_out_order(const gko_graph *g, gko_kmer node, int *bases4) {
+    int64_t id = graph_find_node(g, node);
+    if (!id || !g->nodes[id].alive) return -1;
+    for (int i = 0; i < g->nodes[id].nout; i++) bases4[i] = g->nodes[id].out_base[i];
+    return g->nodes[id].nout;
+}
+
+int gko_graph_degree(const gko_graph *g, gko_kmer node, int *in_deg, int *out_deg) {
+    int64_t id = graph_find_node(g, node);
+    if (!id || !g->nodes[id].alive) return -1;
+    if (in_deg) *in_deg = g->nodes[id].nin;
+    if (out_deg) *out_deg = g->nodes[id].nout;
+    return 0;
+}
