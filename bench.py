@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — distinct k-mers/s inserted (k=31, 150 bp synthetic reads) on N MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic reads that is already resident
+in HBM: clear the table, then FreqFilter.add for every read (extract -> canonicalise -> insert +
+count).  Workload = BASELINE.json configs[1] ("C2"): 1M x 150 bp reads per GPU, k=31.
+  N = 1 : single-partition DNAMap kernel (gk_map_count_reads_dev).
+  N > 1 : weak scaling, one rank per GPU: every rank owns 1M reads and one table partition; k-mers are
+          bucketed by strand-symmetric minimizer owner (gk_shard_reads_dev), exchanged with ONE RCCL
+          all-to-all (torch.distributed, backend nccl) and inserted by their owner
+          (gk_map_update_inc_dev).  value = distinct k-mers over all partitions / max-over-ranks time.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402  (first: its bundled HIP runtime must be the process's only one)
+import torch.distributed as dist  # noqa: E402
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_count_kernel(occ, distinct, L, k):
+    """per occurrence 2L/(8 n_k) B of packed read + one key slot read (W B) + one
+    int32 count read-modify-write (8 B); plus W B once per distinct key (first write)."""
+    W = 8 if k <= 32 else 16
+    nk = L - k + 1
+    return occ * (2.0 * L / (8.0 * nk) + W + 8.0) + distinct * W
+
+
+def algorithmic_bytes_insert_kernel(keys, distinct, k):
+    """Owner-side insert of routed keys: stream the key (W B) + slot read (W B) + count RMW (8 B)."""
+    W = 8 if k <= 32 else 16
+    return keys * (W + W + 8.0) + distinct * W
+
+
+def cpu_baseline(rec_host: np.ndarray, nreads_total: int, k: int, target_s: float = 12.0):
+    """The oracle (C restatement of the reference's single-partition ArrayDNAMap path) timed on
+    this host, one thread, on a bounded prefix of the same reads."""
+    from oracle import oracle as O
+    stride = rec_host.shape[1]
+    probe = min(2000, nreads_total)
+    pm = O.PMap(k, 1)
+    t0 = time.perf_counter()
+    pm.count_reads(rec_host[:probe].tobytes(), probe)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    pm.close()
+    sample = int(min(nreads_total, max(probe, probe * target_s / dt)))
+    pm = O.PMap(k, 1)
+    t0 = time.perf_counter()
+    occ = pm.count_reads(rec_host[:sample].tobytes(), sample)
+    dt = time.perf_counter() - t0
+    distinct = pm.size()
+    pm.close()
+    del stride
+    return {"value": distinct / dt, "unit": "distinct k-mers/s", "cores": 1, "kind": "port",
+            "occurrences_per_s": occ / dt,
+            "sample": f"first {sample} of the {nreads_total} reads ({occ} k-mer occurrences, {distinct} distinct), "
+                      f"{dt:.1f} s, C restatement of ArrayDNAMap+FreqFilter.add, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--mode", choices=["U", "G"], default="U", help="U: uniform reads (every k-mer distinct w.h.p.); "
+                    "G: 5 Mbp genome, 30x, 1%% error")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)", file=sys.stderr)
+        if world == 1 and args.gpus > 1:
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from genome_amd import synth
+    from genome_amd.dnamap import Context, HipDNAMap
+
+    n, L, k = args.reads, args.read_len, args.k
+    W = 1 if k <= 32 else 2
+    nk = L - k + 1
+    stride = synth.record_stride(L)
+    ctx = Context(local_rank)
+    rec = torch.empty(n * stride + 64, dtype=torch.uint8, device=dev)
+    G, err = 5_000_000 * world, 0.01
+    ctx.synth_reads(rec.data_ptr(), n, L, args.mode, 2, rank * n, G, err)     # config_id 2 = C2
+    occ_rank = n * nk
+    m = HipDNAMap(ctx, k, int(occ_rank * 1.05))
+    if world > 1:
+        send = torch.empty(occ_rank * W, dtype=torch.int64, device=dev)
+        recv = torch.empty(int(occ_rank * W * 1.5) + 1024, dtype=torch.int64, device=dev)
+
+    kernel_ms, kernel_units = [], []
+
+    def step():
+        m.clear()
+        if world == 1:
+            m.count_reads_dev(rec.data_ptr(), n, L)
+            ms, kocc = m.last_count_kernel()
+            kernel_ms.append(ms); kernel_units.append(kocc)
+            return
+        counts = ctx.shard_reads(k, rec.data_ptr(), n, L, world, send.data_ptr(), occ_rank)
+        sc = torch.as_tensor(counts.astype(np.int64), device=dev)
+        rc = torch.empty_like(sc)
+        dist.all_to_all_single(rc, sc)
+        rcn = rc.cpu().numpy()
+        nrecv = int(rcn.sum())
+        nonlocal recv
+        if nrecv * W > recv.numel():
+            recv = torch.empty(nrecv * W + 1024, dtype=torch.int64, device=dev)
+        dist.all_to_all_single(recv[:nrecv * W], send[:occ_rank * W],
+                               output_split_sizes=[int(c) * W for c in rcn], input_split_sizes=[int(c) * W for c in counts])
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        m.update_inc_dev(recv.data_ptr(), nrecv)
+        kernel_ms.append((time.perf_counter() - t0) * 1e3); kernel_units.append(nrecv)
+        del ev0, ev1
+
+    def fence():
+        torch.cuda.synchronize()
+        ctx_sync()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def ctx_sync():
+        from genome_amd import _lib
+        _lib.check(_lib.lib().gk_ctx_sync(ctx.h), ctx.h)
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms.clear(); kernel_units.clear()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+
+    distinct_rank = m.size()
+    tt = torch.tensor([dt, float(distinct_rank), float(occ_rank)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_max, distinct_total, occ_total = float(tmax[0]), float(tsum[1]), float(tsum[2])
+    else:
+        dt_max, distinct_total, occ_total = dt, float(distinct_rank), float(occ_rank)
+
+    if rank == 0:
+        ms_per_step = dt_max / args.steps * 1e3
+        avg_kernel_ms = float(np.mean(kernel_ms))
+        units = float(np.mean(kernel_units))
+        if world == 1:
+            abytes = algorithmic_bytes_count_kernel(units, distinct_rank, L, k)
+            kname = "k_count_reads<1>" if W == 1 else "k_count_reads<2>"
+            timing = "HIP events on the library stream (gk_map_last_count_kernel)"
+        else:
+            abytes = algorithmic_bytes_insert_kernel(units, distinct_rank, k)
+            kname = "k_add_keys<1>" if W == 1 else "k_add_keys<2>"
+            timing = "host wall around the synchronous gk_map_update_inc_dev call"
+        achieved = abytes / (avg_kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "distinct k-mers/s inserted (k=31, 150bp reads)",
+            "value": distinct_total / (dt_max / args.steps),
+            "unit": "distinct k-mers/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64" if W == 1 else "u128", "data": "synthetic",
+            "config": {"workload": f"C2: {n} x {L}bp synthetic reads per GPU (SplitMix64 mode {args.mode}), k={k}, "
+                                   + ("single-partition DNAMap kernel" if world == 1 else
+                                      f"minimizer-sharded PartitionedDNAMap, {world} partitions, RCCL all-to-all"),
+                       "reads_per_gpu": n, "read_len": L, "k": k, "mode": args.mode,
+                       "table_slots_per_gpu": m.slots(), "slot_bytes": 16 if W == 1 else 32},
+            "occurrences_per_s": occ_total / (dt_max / args.steps),
+            "distinct_per_step": distinct_total, "occurrences_per_step": occ_total,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
+                         "kernel_ms": avg_kernel_ms, "units_per_launch": units,
+                         "algorithmic_bytes_per_launch": abytes, "timing": timing},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            sample_reads = min(n, 400_000)
+            host = ctx.download(rec.data_ptr(), sample_reads * stride).reshape(sample_reads, stride)
+            out["cpu_baseline"] = cpu_baseline(host, sample_reads, k)
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    m.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,127 @@
+"""ctypes binding of the C-ABI library (include/genome_amd.h -> genome_amd/libgenome_amd.so).
+
+This is the Python twin of the JNI stub shown in INTEGRATION.md: plain pointers and sizes, no torch
+types.  There is no fallback: if the library is missing, or a call fails, an exception is raised.
+
+Import order note: when a process also uses torch (bench.py for torch.distributed), `import torch`
+must come BEFORE the first call into this module so that the HIP runtime torch bundles
+(libamdhip64.so, SONAME libamdhip64.so.7) is the single runtime in the process.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgenome_amd.so")
+
+GK_OK = 0
+GK_E_INVALID, GK_E_KLEN, GK_E_UNSUPPORTED_K, GK_E_CAPACITY = -1, -2, -3, -4
+GK_E_HIP, GK_E_NODEVICE, GK_E_FORMAT, GK_E_STATE = -5, -6, -7, -8
+_NAMES = {-1: "GK_E_INVALID", -2: "GK_E_KLEN", -3: "GK_E_UNSUPPORTED_K", -4: "GK_E_CAPACITY", -5: "GK_E_HIP",
+          -6: "GK_E_NODEVICE", -7: "GK_E_FORMAT", -8: "GK_E_STATE"}
+
+
+class GkError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class KeyLengthError(GkError, AssertionError):
+    """The reference raises AssertionError (`assert(key.length == k)`, ArrayDNAMap.scala:182)."""
+
+
+_lib = None
+
+u64p = C.POINTER(C.c_uint64)
+i64p = C.POINTER(C.c_int64)
+i32p = C.POINTER(C.c_int32)
+u8p = C.POINTER(C.c_uint8)
+vp = C.c_void_p
+
+# every symbol include/genome_amd.h declares: (restype, argtypes)
+SIGNATURES = {
+    "gk_device_count": (C.c_int, []),
+    "gk_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "gk_ctx_destroy": (None, [vp]),
+    "gk_last_error": (C.c_char_p, [vp]),
+    "gk_ctx_device": (C.c_int, [vp]),
+    "gk_ctx_sync": (C.c_int, [vp]),
+    "gk_dev_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+    "gk_dev_free": (C.c_int, [vp, vp]),
+    "gk_dev_upload": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "gk_dev_download": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "gk_map_create": (C.c_int, [vp, C.c_int, C.c_uint64, C.POINTER(vp)]),
+    "gk_map_destroy": (None, [vp]),
+    "gk_map_k": (C.c_int, [vp]),
+    "gk_map_clear": (C.c_int, [vp]),
+    "gk_map_size": (C.c_int, [vp, u64p]),
+    "gk_map_slots": (C.c_int, [vp, u64p]),
+    "gk_map_count_reads": (C.c_int, [vp, u8p, C.c_size_t, C.c_uint64, u64p]),
+    "gk_map_count_reads_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, u64p]),
+    "gk_map_update_inc": (C.c_int, [vp, u64p, u64p, C.c_uint64]),
+    "gk_map_update_inc_dev": (C.c_int, [vp, vp, C.c_uint64]),
+    "gk_map_add_counts": (C.c_int, [vp, u64p, u64p, i32p, C.c_uint64]),
+    "gk_map_filter_lt": (C.c_int, [vp, C.c_int32]),
+    "gk_map_get_batch": (C.c_int, [vp, u64p, u64p, C.c_uint64, i32p, u8p]),
+    "gk_map_export": (C.c_int, [vp, u64p, u64p, i32p, C.c_uint64, u64p]),
+    "gk_map_stats": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
+    "gk_map_last_count_kernel": (C.c_int, [vp, C.POINTER(C.c_float), u64p]),
+    "gk_shard_reads_dev": (C.c_int, [vp, C.c_int, vp, C.c_uint64, C.c_int, C.c_int, vp, C.c_uint64, u64p]),
+    "gk_owner_of": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_int]),
+    "gk_graph_build": (C.c_int, [vp, C.POINTER(vp)]),
+    "gk_graph_destroy": (None, [vp]),
+    "gk_graph_counts": (C.c_int, [vp, u64p, u64p, u64p]),
+    "gk_graph_simplify": (C.c_int, [vp]),
+    "gk_graph_remove_bubbles": (C.c_int, [vp]),
+    "gk_graph_remove_edges": (C.c_int, [vp, u64p, u64p, u8p, C.c_uint64, u64p]),
+    "gk_graph_retain_largest": (C.c_int, [vp, u64p, u64p]),
+    "gk_graph_export_nodes": (C.c_int, [vp, u64p, u64p, C.c_uint64, u64p]),
+    "gk_graph_export_edges": (C.c_int, [vp, u64p, u64p, u64p, u64p, i64p, i64p, C.c_uint64, u64p, u8p, C.c_uint64, u64p]),
+    "gk_graph_out_order": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gk_synth_reads_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]),
+}
+
+
+def lib():
+    """Load the HIP library; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(make -C genome_amd/csrc). genome_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def device_count() -> int:
+    return lib().gk_device_count()
+
+
+def check(rc: int, ctx=None):
+    if rc == GK_OK:
+        return
+    msg = lib().gk_last_error(ctx)
+    msg = msg.decode() if msg else ""
+    if rc == GK_E_KLEN:
+        raise KeyLengthError(rc, msg)
+    raise GkError(rc, msg)
+
+
+def ptr(a: np.ndarray | None, ctype):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def as_u64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint64)

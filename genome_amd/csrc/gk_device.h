@@ -1,0 +1,301 @@
+// gk_device.h — k-mer arithmetic and open-addressed table primitives shared by the HIP kernels
+// (and, for the pure-arithmetic part, by the host side of the C-ABI).
+//
+// Everything here is integer/bit work laid out for gfx950: one lane = one k-mer, 64-bit VALU ops,
+// no MFMA anywhere.  Reference semantics are cited per function
+// (S/ = /root/reference/src/main/scala/ru/ifmo/genome/).
+#pragma once
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GK_HD __host__ __device__ __forceinline__
+#define GK_D __device__ __forceinline__
+#else
+#define GK_HD inline
+#endif
+
+namespace gk {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t i32;
+typedef int64_t i64;
+
+// ------------------------------------------------------------------------------------------
+// K-mers.  W = number of 64-bit words: 1 for k<=31 (Long1DNASeq, DNASeq.scala:74-169),
+// 2 for 34<=k<=63 (Long2DNASeq, :172-215).  Base i sits at bits 2i, first base at the LSB,
+// codes A0 G1 C2 T3 (Base.scala:13-18); unused high bits are zero.
+// ------------------------------------------------------------------------------------------
+template <int W> struct Kmer;
+template <> struct Kmer<1> { u64 lo; };
+template <> struct Kmer<2> { u64 lo, hi; };
+
+GK_HD bool operator==(Kmer<1> a, Kmer<1> b) { return a.lo == b.lo; }
+GK_HD bool operator==(Kmer<2> a, Kmer<2> b) { return a.lo == b.lo && a.hi == b.hi; }
+GK_HD bool kmer_less(Kmer<1> a, Kmer<1> b) { return a.lo < b.lo; }
+GK_HD bool kmer_less(Kmer<2> a, Kmer<2> b) { return a.hi != b.hi ? a.hi < b.hi : a.lo < b.lo; }
+
+GK_HD u64 bitrev64(u64 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brevll(v);
+#else
+    v = ((v >> 1) & 0x5555555555555555ULL) | ((v & 0x5555555555555555ULL) << 1);
+    v = ((v >> 2) & 0x3333333333333333ULL) | ((v & 0x3333333333333333ULL) << 2);
+    v = ((v >> 4) & 0x0f0f0f0f0f0f0f0fULL) | ((v & 0x0f0f0f0f0f0f0f0fULL) << 4);
+    return __builtin_bswap64(v);
+#endif
+}
+// reverse the order of the 32 two-bit groups of a word
+GK_HD u64 rev_groups(u64 v) {
+    v = bitrev64(v);
+    return ((v >> 1) & 0x5555555555555555ULL) | ((v & 0x5555555555555555ULL) << 1);
+}
+
+// revComplement = complement.reverse (DNASeq.scala:28; complement is b^3, Base.scala:19).
+// ~x complements every base and turns the unused high groups into garbage that the final shift
+// discards.
+GK_HD Kmer<1> revcomp(Kmer<1> x, int k) {
+    Kmer<1> r;
+    r.lo = rev_groups(~x.lo) >> (64 - 2 * k);
+    return r;
+}
+GK_HD Kmer<2> revcomp(Kmer<2> x, int k) {   // 34 <= k <= 63  =>  shift s in [2, 60]
+    u64 nlo = rev_groups(~x.hi), nhi = rev_groups(~x.lo);
+    int s = 128 - 2 * k;
+    Kmer<2> r;
+    r.lo = (nlo >> s) | (nhi << (64 - s));
+    r.hi = nhi >> s;
+    return r;
+}
+
+// hashCode.  k<=31: scala-library 2.9.1 `Long.##` (DNASeq.scala:103) — for the non-negative
+// values a k<=31 k-mer takes this is (int)(v ^ (v >>> 32)) under either branch of
+// BoxesRunTime.hashFromLong.  k>32: MultiHash.hashCode = multiHashCode(42)
+// (BloomFilter.scala:12-15) with Long2DNASeq.multiHashCode (DNASeq.scala:204-208): arithmetic >>,
+// wrapping 64-bit multiply.
+GK_HD i32 ref_hash(Kmer<1> x) { return (i32)(u32)(x.lo ^ (x.lo >> 32)); }
+GK_HD i32 ref_hash(Kmer<2> x) {
+    i64 l1 = (i64)x.lo, l2 = (i64)x.hi;
+    i64 t = (i64)((u64)(l1 ^ (l1 >> 32)) * 42ULL);
+    i64 t1 = (i64)((u64)(l2 ^ (l2 >> 32) ^ t) * 42ULL);
+    return (i32)(u32)(u64)(t1 ^ (t1 >> 32));
+}
+
+// FreqFilter.scala:31-32: y = if (x.hashCode < rcx.hashCode) x else rcx  (signed, tie -> rcx)
+template <int W> GK_HD Kmer<W> canonical(Kmer<W> x, int k) {
+    Kmer<W> rc = revcomp(x, k);
+    return ref_hash(x) < ref_hash(rc) ? x : rc;
+}
+
+// x.drop(1) :+ b  (Graph.scala:279)
+GK_HD Kmer<1> append_base(Kmer<1> x, int b, int k) {
+    Kmer<1> r;
+    r.lo = (x.lo >> 2) | ((u64)b << (2 * (k - 1)));
+    return r;
+}
+GK_HD Kmer<2> append_base(Kmer<2> x, int b, int k) {
+    Kmer<2> r;
+    r.lo = (x.lo >> 2) | (x.hi << 62);
+    r.hi = (x.hi >> 2) | ((u64)b << (2 * (k - 33)));
+    return r;
+}
+// b +: x.take(k-1)  (Graph.scala:273)
+GK_HD Kmer<1> prepend_base(int b, Kmer<1> x, int k) {
+    Kmer<1> r;
+    r.lo = ((x.lo << 2) | (u64)b) & ((1ULL << (2 * k)) - 1);
+    return r;
+}
+GK_HD Kmer<2> prepend_base(int b, Kmer<2> x, int k) {
+    Kmer<2> r;
+    r.hi = ((x.hi << 2) | (x.lo >> 62)) & ((1ULL << (2 * (k - 32))) - 1);
+    r.lo = (x.lo << 2) | (u64)b;
+    return r;
+}
+GK_HD int first_base(Kmer<1> x) { return (int)(x.lo & 3); }
+GK_HD int first_base(Kmer<2> x) { return (int)(x.lo & 3); }
+
+// ------------------------------------------------------------------------------------------
+// Slot placement hash (free choice: slot order is unobservable — the reference's
+// improve(hashCode)&mask, ArrayDNAMap.scala:130,267-272, only fixes ITS slot order).
+// ------------------------------------------------------------------------------------------
+GK_HD u64 mix64(u64 x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+GK_HD u64 slot_hash(Kmer<1> x) { return mix64(x.lo); }
+GK_HD u64 slot_hash(Kmer<2> x) { return mix64(x.lo ^ (mix64(x.hi) + 0x9e3779b97f4a7c15ULL)); }
+
+// ------------------------------------------------------------------------------------------
+// Owner partition = strand-symmetric minimizer: the minimum, over all m-mers of
+// the k-mer, of a hash of the m-mer's own canonical form min(w, rc(w)).  The set of canonical
+// m-mers of x and rc(x) is the same, so x, rc(x) — hence both hash-rule candidates — share an
+// owner.  m = min(11, k).
+// ------------------------------------------------------------------------------------------
+GK_HD u32 hash32(u32 x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+GK_HD u64 window_bits(Kmer<1> x, int bit) { return x.lo >> bit; }
+GK_HD u64 window_bits(Kmer<2> x, int bit) {
+    if (bit >= 64) return x.hi >> (bit - 64);
+    if (bit == 0) return x.lo;
+    return (x.lo >> bit) | (x.hi << (64 - bit));
+}
+template <int W> GK_HD u32 minimizer_score(Kmer<W> x, int k) {
+    const int m = k < 11 ? k : 11;
+    const u32 mm = (u32)((1ULL << (2 * m)) - 1);
+    Kmer<W> rc = revcomp(x, k);
+    u32 best = 0xffffffffu;
+    for (int i = 0; i + m <= k; i++) {
+        u32 a = (u32)window_bits(x, 2 * i) & mm;
+        u32 b = (u32)window_bits(rc, 2 * (k - m - i)) & mm;   // rc of window i of x
+        u32 s = hash32(a < b ? a : b);
+        best = s < best ? s : best;
+    }
+    return best;
+}
+template <int W> GK_HD int owner_of(Kmer<W> x, int k, int P) {
+    // the minimum of many hashes is skewed towards 0: re-mix it (a bijection) before scaling to P
+    return (int)(((u64)hash32(minimizer_score(x, k) ^ 0x5bd1e995u) * (u64)P) >> 32);
+}
+
+#if defined(__HIPCC__)
+// ------------------------------------------------------------------------------------------
+// HBM-resident open-addressed table, array-of-slots so that one probe touches one 64-B sector:
+// key word(s), the int32 count and the graph-phase annotation word live side by side.
+// ------------------------------------------------------------------------------------------
+static constexpr u64 KEY_EMPTY = ~0ULL;       // never a valid key word (top bit clear in all valid words)
+static constexpr u64 KEY_TOMB = ~0ULL - 1;    // deleteAll tombstone (ArrayDNAMap.scala:168): probes run through it
+
+template <int W> struct Slot;
+template <> struct __attribute__((aligned(16))) Slot<1> { u64 w0; u32 count; u32 aux; };
+template <> struct __attribute__((aligned(32))) Slot<2> { u64 w0; u64 w1; u32 count; u32 aux; u64 pad; };
+
+// Stored form.  W=1: the key itself (k<=31 leaves the two top bits clear).  W=2: two 63-bit
+// halves, bits 0..62 and 63..125 of the 128-bit k-mer, so each word has a spare top bit and each
+// can be claimed by its own 64-bit CAS (there is no 128-bit CAS).
+template <int W> struct Stored;
+template <> struct Stored<1> { u64 w0; };
+template <> struct Stored<2> { u64 w0, w1; };
+GK_HD Stored<1> to_stored(Kmer<1> x) { return Stored<1>{x.lo}; }
+GK_HD Stored<2> to_stored(Kmer<2> x) { return Stored<2>{x.lo & 0x7fffffffffffffffULL, (x.lo >> 63) | (x.hi << 1)}; }
+GK_HD Kmer<1> from_stored(Stored<1> s) { return Kmer<1>{s.w0}; }
+GK_HD Kmer<2> from_stored(Stored<2> s) { return Kmer<2>{s.w0 | (s.w1 << 63), s.w1 >> 1}; }
+GK_D Stored<1> load_stored(const Slot<1> *s) { return Stored<1>{s->w0}; }
+GK_D Stored<2> load_stored(const Slot<2> *s) { return Stored<2>{s->w0, s->w1}; }
+
+template <int W> struct Table {
+    Slot<W> *slots;
+    u64 mask;          // capacity - 1 (capacity is a power of two)
+};
+
+struct Counters {      // device-resident, one per map
+    unsigned long long size;        // live keys
+    unsigned long long occurrences; // windows counted by the last count kernel
+    u32 error;                      // 1 = a probe ran the whole table (capacity exhausted)
+    u32 pad;
+};
+
+GK_D u64 cas64(u64 *p, u64 expect, u64 val) {
+    __hip_atomic_compare_exchange_strong(p, &expect, val, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return expect;   // old value
+}
+GK_D void add32_noret(u32 *p, u32 v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Container.update(key, v0, f) with v0 = add, f = _ + add (ArrayDNAMap.scala:129-150), lock-free:
+// plain loads are only hints (a stale line can only read EMPTY, never a wrong key, because key
+// words are write-once during an insert phase); the CAS decides.  Returns 1 if this call claimed
+// a new slot.  *err is set when the probe wraps the whole table.
+GK_D int table_add(const Table<1> &t, Kmer<1> key, u32 add, u32 *err) {
+    u64 i = slot_hash(key) & t.mask;
+    for (u64 n = 0; n <= t.mask; ++n) {
+        Slot<1> *s = &t.slots[i];
+        u64 cur = s->w0;
+        int claimed = 0;
+        if (cur == KEY_EMPTY) {
+            cur = cas64(&s->w0, KEY_EMPTY, key.lo);
+            if (cur == KEY_EMPTY) { cur = key.lo; claimed = 1; }
+        }
+        if (cur == key.lo) { add32_noret(&s->count, add); return claimed; }
+        i = (i + 1) & t.mask;
+    }
+    *err = 1;
+    return 0;
+}
+// 128-bit keys: claim w0 then w1, each write-once.  Two keys sharing w0 may race for w1; the
+// loser simply moves on to the next slot, and every later probe of that key makes the same
+// decision from the (now immutable) slot contents, so a key never lands in two slots.
+GK_D int table_add(const Table<2> &t, Kmer<2> key, u32 add, u32 *err) {
+    Stored<2> k = to_stored(key);
+    u64 i = slot_hash(key) & t.mask;
+    for (u64 n = 0; n <= t.mask; ++n) {
+        Slot<2> *s = &t.slots[i];
+        u64 c0 = s->w0;
+        int claimed = 0;
+        if (c0 == KEY_EMPTY) {
+            c0 = cas64(&s->w0, KEY_EMPTY, k.w0);
+            if (c0 == KEY_EMPTY) c0 = k.w0;
+        }
+        if (c0 == k.w0) {
+            u64 c1 = s->w1;
+            if (c1 == KEY_EMPTY) {
+                c1 = cas64(&s->w1, KEY_EMPTY, k.w1);
+                if (c1 == KEY_EMPTY) { c1 = k.w1; claimed = 1; }
+            }
+            if (c1 == k.w1) { add32_noret(&s->count, add); return claimed; }
+        }
+        i = (i + 1) & t.mask;
+    }
+    *err = 1;
+    return 0;
+}
+
+// Container.apply (ArrayDNAMap.scala:90-101) on a quiescent table: slot index or -1.
+GK_D i64 table_find(const Table<1> &t, Kmer<1> key) {
+    u64 i = slot_hash(key) & t.mask;
+    for (u64 n = 0; n <= t.mask; ++n) {
+        u64 cur = t.slots[i].w0;
+        if (cur == key.lo) return (i64)i;
+        if (cur == KEY_EMPTY) return -1;
+        i = (i + 1) & t.mask;
+    }
+    return -1;
+}
+GK_D i64 table_find(const Table<2> &t, Kmer<2> key) {
+    Stored<2> k = to_stored(key);
+    u64 i = slot_hash(key) & t.mask;
+    for (u64 n = 0; n <= t.mask; ++n) {
+        u64 c0 = t.slots[i].w0;
+        if (c0 == k.w0 && t.slots[i].w1 == k.w1) return (i64)i;
+        if (c0 == KEY_EMPTY) return -1;
+        i = (i + 1) & t.mask;
+    }
+    return -1;
+}
+template <int W> GK_D bool slot_live(const Slot<W> *s) { return s->w0 != KEY_EMPTY && s->w0 != KEY_TOMB; }
+
+// Graph.buildGraph `contains` (Graph.scala:270): either strand.  Only the hash-rule canonical
+// orientation can be a stored key, except in the tie h(x) == h(rc x) where occurrences seen as x
+// are filed under rc x and vice versa (FreqFilter.scala:31-32) — then both are probed, the
+// numerically smaller orientation first so that every caller resolves a tie pair to the same slot.
+// Returns the slot (or -1) and whether the stored key is x itself (fwd) or its reverse complement.
+template <int W> GK_D i64 table_find_either(const Table<W> &t, Kmer<W> x, int k, bool *fwd) {
+    Kmer<W> rc = revcomp(x, k);
+    i32 hx = ref_hash(x), hr = ref_hash(rc);
+    if (hx < hr) { *fwd = true; return table_find(t, x); }
+    if (hx > hr) { *fwd = false; return table_find(t, rc); }
+    bool x_first = !kmer_less(rc, x);
+    i64 s = table_find(t, x_first ? x : rc);
+    if (s >= 0) { *fwd = x_first; return s; }
+    *fwd = !x_first;
+    return table_find(t, x_first ? rc : x);
+}
+#endif  // __HIPCC__
+
+}  // namespace gk

@@ -1,0 +1,64 @@
+// gk_internal.h — host-side handle definitions shared by the C-ABI translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/genome_amd.h"
+#include "gk_device.h"
+
+struct gk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int cu_count = 256;
+    std::string err;
+};
+
+struct gk_map {
+    gk_ctx *ctx = nullptr;
+    int k = 0;
+    int W = 1;                   // 64-bit words per key
+    uint64_t capacity = 0;       // slots, power of two
+    void *slots = nullptr;       // Slot<W>[capacity]
+    gk::Counters *d_ctr = nullptr;
+    uint64_t size = 0;           // host mirror of d_ctr->size (valid after every public call)
+    uint64_t tombstones = 0;
+    uint64_t total_occurrences = 0;
+    uint64_t grows = 0;
+    float last_count_ms = 0.f;
+    uint64_t last_count_occ = 0;
+    // staging buffer reused by host-fed count_reads
+    void *d_stage = nullptr;
+    size_t stage_bytes = 0;
+    void *d_offsets = nullptr;
+    size_t offsets_bytes = 0;
+};
+
+namespace gk {
+
+void set_error(const gk_ctx *ctx, const std::string &msg);
+int fail(const gk_ctx *ctx, int code, const std::string &msg);
+int hip_fail(const gk_ctx *ctx, hipError_t e, const char *what);
+
+#define GK_HIP(ctx, call)                                                   \
+    do {                                                                    \
+        hipError_t e__ = (call);                                            \
+        if (e__ != hipSuccess) return gk::hip_fail((ctx), e__, #call);      \
+    } while (0)
+
+inline bool k_supported(int k) { return (k >= 2 && k <= 31) || (k >= 34 && k <= 63); }
+inline int words_for_k(int k) { return k <= 32 ? 1 : 2; }
+inline size_t slot_bytes(int W) { return W == 1 ? 16 : 32; }
+inline uint64_t pow2ceil(uint64_t v) {
+    uint64_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// table ops used across translation units
+int map_reserve(gk_map *m, uint64_t extra_keys);     // grow so that size+extra stays under the load limit
+int map_sync_counters(gk_map *m);                    // refresh m->size, detect device-side error flag
+
+}  // namespace gk

@@ -1,0 +1,48 @@
+// gk_tile.h — LDS staging of `.bin` read records and k-mer window extraction, shared by the
+// kernels that stream reads (k_count_reads, k_shard_*).
+#pragma once
+
+#include "gk_device.h"
+
+namespace gk {
+
+static constexpr int BLOCK = 256;          // 4 waves of 64
+static constexpr int TILE_READS = 64;      // reads staged per LDS tile
+static constexpr int TILE_WORDS = 1088;    // 64 reads x 65 B + alignment slack + extraction slack
+
+// Pull the k-mer starting at bit `bitpos` out of the LDS tile (2 bits per base, LSB first — the
+// reference's own packing, ArrayDNASeq.apply DNASeq.scala:46-51, so a window IS a bit range).
+__device__ __forceinline__ Kmer<1> tile_kmer(const u32 *tile, u32 bitpos, int k, Kmer<1> *) {
+    u32 wi = bitpos >> 5, sh = bitpos & 31;
+    u64 v0 = (u64)tile[wi] | ((u64)tile[wi + 1] << 32);
+    u64 v1 = tile[wi + 2];
+    u64 x = (v0 >> sh) | (sh ? (v1 << (64 - sh)) : 0ull);
+    return Kmer<1>{x & ((1ull << (2 * k)) - 1)};
+}
+__device__ __forceinline__ Kmer<2> tile_kmer(const u32 *tile, u32 bitpos, int k, Kmer<2> *) {
+    u32 wi = bitpos >> 5, sh = bitpos & 31;
+    u64 v0 = (u64)tile[wi] | ((u64)tile[wi + 1] << 32);
+    u64 v1 = (u64)tile[wi + 2] | ((u64)tile[wi + 3] << 32);
+    u64 v2 = tile[wi + 4];
+    u64 lo = (v0 >> sh) | (sh ? (v1 << (64 - sh)) : 0ull);
+    u64 hi = (v1 >> sh) | (sh ? (v2 << (64 - sh)) : 0ull);
+    return Kmer<2>{lo, hi & ((1ull << (2 * (k - 32))) - 1)};
+}
+
+// Stage the records of reads [r0, r0+nr) into LDS with 16-byte coalesced loads.  The byte range
+// is widened to 16-byte alignment on both sides; an aligned 16-byte block that holds at least one
+// valid byte never crosses a page, so the widening cannot fault.  Returns the global byte offset
+// that LDS byte 0 corresponds to.
+__device__ __forceinline__ u64 stage_tile(u32 *tile, const uint8_t *rec, u64 gb, u64 ge) {
+    u64 base = (u64)(uintptr_t)rec;
+    u64 a0 = ((base + gb) & ~15ull) - base;             // may be "negative" (wraps) by < 16: fine, same block
+    u64 a1 = ((base + ge + 15) & ~15ull) - base;
+    u32 nvec = (u32)((a1 - a0) >> 4);
+    const uint4 *src = reinterpret_cast<const uint4 *>(rec + (i64)a0);
+    uint4 *dst = reinterpret_cast<uint4 *>(tile);
+    for (u32 i = threadIdx.x; i < nvec; i += BLOCK) dst[i] = src[i];
+    return a0;
+}
+
+
+}  // namespace gk

@@ -1,0 +1,179 @@
+"""Host-side mirror of `trait DNAMap[T]` for T = Int (S/ds/ArrayDNAMap.scala:49-60) over the HIP
+library.  Method names and meanings follow the trait; the closure-taking forms exist only for the
+closures the hot path actually passes (`_ + 1`, `(k, v) => v < rounds`), everything
+else is expressed on exported arrays.  All compute happens on the GPU through the C-ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+
+import numpy as np
+
+from . import _lib as L
+from . import dna
+
+
+class Context:
+    """One device + stream (replaces ActorsHome.system, S/scripts/ActorsHome.scala:20-30)."""
+
+    def __init__(self, device: int = 0):
+        self.h = L.vp()
+        L.check(L.lib().gk_ctx_create(device, C.byref(self.h)))
+        self.device = device
+
+    def close(self):
+        if self.h:
+            L.lib().gk_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def alloc(self, nbytes: int) -> int:
+        p = L.vp()
+        L.check(L.lib().gk_dev_alloc(self.h, nbytes, C.byref(p)), self.h)
+        return p.value
+
+    def free(self, dptr: int):
+        L.check(L.lib().gk_dev_free(self.h, dptr), self.h)
+
+    def upload(self, dptr: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        L.check(L.lib().gk_dev_upload(self.h, dptr, arr.ctypes.data, arr.nbytes), self.h)
+
+    def download(self, dptr: int, nbytes: int) -> np.ndarray:
+        out = np.empty(nbytes, np.uint8)
+        L.check(L.lib().gk_dev_download(self.h, out.ctypes.data, dptr, nbytes), self.h)
+        return out
+
+    def synth_reads(self, dptr: int, nreads: int, read_len: int, mode: str = "U", config_id: int = 0,
+                    first_read: int = 0, genome_len: int = 0, err: float = 0.0):
+        L.check(L.lib().gk_synth_reads_dev(self.h, dptr, nreads, read_len, 0 if mode == "U" else 1, config_id,
+                                           first_read, genome_len, int(err * (1 << 24))), self.h)
+
+    def shard_reads(self, k: int, d_records: int, nreads: int, read_len: int, P: int, d_keys_out: int, keys_cap: int):
+        counts = np.zeros(P, np.uint64)
+        L.check(L.lib().gk_shard_reads_dev(self.h, k, d_records, nreads, read_len, P, d_keys_out, keys_cap,
+                                           L.ptr(counts, C.c_uint64)), self.h)
+        return counts
+
+
+def _keys(k: int, keys):
+    """Accept base strings, (lo, hi) pairs or a pair of uint64 arrays."""
+    if isinstance(keys, tuple) and len(keys) == 2 and isinstance(keys[0], np.ndarray):
+        return L.as_u64(keys[0]), L.as_u64(keys[1])
+    keys = list(keys)
+    if keys and isinstance(keys[0], str):
+        for s in keys:
+            if len(s) != k:        # assert(key.length == k)  ArrayDNAMap.scala:182
+                raise L.KeyLengthError(L.GK_E_KLEN, f"key length {len(s)} != k={k}")
+        return dna.pack_many(keys)
+    lo = np.array([a for a, _ in keys], np.uint64)
+    hi = np.array([b for _, b in keys], np.uint64)
+    return lo, hi
+
+
+class HipDNAMap:
+    """`ArrayDNAMap[Int]` resident in HBM (one partition)."""
+
+    def __init__(self, ctx: Context, k: int, capacity_hint: int = 0):
+        self.ctx, self.k = ctx, k
+        self.h = L.vp()
+        L.check(L.lib().gk_map_create(ctx.h, k, capacity_hint, C.byref(self.h)), ctx.h)
+
+    def close(self):
+        if self.h:
+            L.lib().gk_map_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- trait DNAMap[Int] -------------------------------------------------------------
+    def size(self) -> int:                                   # :50
+        n = C.c_uint64()
+        L.check(L.lib().gk_map_size(self.h, C.byref(n)), self.ctx.h)
+        return n.value
+
+    def apply_batch(self, keys) -> np.ndarray:               # :51 apply, batched; -1 = None
+        lo, hi = _keys(self.k, keys)
+        out = np.empty(len(lo), np.int32)
+        L.check(L.lib().gk_map_get_batch(self.h, L.ptr(lo, C.c_uint64), L.ptr(hi, C.c_uint64), len(lo),
+                                         L.ptr(out, C.c_int32), None), self.ctx.h)
+        return out
+
+    def apply(self, key):                                    # :51
+        v = int(self.apply_batch([key])[0])
+        return None if v < 0 else v
+
+    def contains(self, key) -> bool:                         # :57
+        return self.apply(key) is not None
+
+    def update_inc(self, keys):                              # :54 update(key, 1, _ + 1), batched
+        lo, hi = _keys(self.k, keys)
+        L.check(L.lib().gk_map_update_inc(self.h, L.ptr(lo, C.c_uint64), L.ptr(hi, C.c_uint64), len(lo)), self.ctx.h)
+
+    def add_counts(self, lo, hi, counts):                    # update(key, c, _ + c): partition merge
+        lo, hi = L.as_u64(lo), L.as_u64(hi)
+        counts = np.ascontiguousarray(counts, np.int32)
+        L.check(L.lib().gk_map_add_counts(self.h, L.ptr(lo, C.c_uint64), L.ptr(hi, C.c_uint64),
+                                          L.ptr(counts, C.c_int32), len(lo)), self.ctx.h)
+
+    def update_inc_dev(self, d_keys: int, n: int):
+        L.check(L.lib().gk_map_update_inc_dev(self.h, d_keys, n), self.ctx.h)
+
+    def deleteAll_lt(self, rounds: int):                     # :56 deleteAll((k, v) => v < rounds)
+        L.check(L.lib().gk_map_filter_lt(self.h, rounds), self.ctx.h)
+
+    def items(self):                                         # :58 mapReduce(identity) / Container.iterator
+        n = self.size()
+        lo = np.empty(n, np.uint64)
+        hi = np.zeros(n, np.uint64)
+        cnt = np.empty(n, np.int32)
+        got = C.c_uint64()
+        L.check(L.lib().gk_map_export(self.h, L.ptr(lo, C.c_uint64), L.ptr(hi, C.c_uint64), L.ptr(cnt, C.c_int32),
+                                      n, C.byref(got)), self.ctx.h)
+        return lo, hi, cnt
+
+    def sorted_items(self):
+        """Canonical table serialisation: sorted by (hi, lo) unsigned."""
+        lo, hi, cnt = self.items()
+        order = np.lexsort((lo, hi))
+        return lo[order], hi[order], cnt[order]
+
+    # ---- FreqFilter.add over a read stream ----------------------------------------------
+    def count_reads(self, bin_bytes, nreads: int) -> int:
+        buf = np.frombuffer(bin_bytes, np.uint8) if not isinstance(bin_bytes, np.ndarray) else np.ascontiguousarray(bin_bytes, np.uint8).reshape(-1)
+        occ = C.c_uint64()
+        L.check(L.lib().gk_map_count_reads(self.h, L.ptr(buf, C.c_uint8), buf.size, nreads, C.byref(occ)), self.ctx.h)
+        return occ.value
+
+    def count_reads_dev(self, d_records: int, nreads: int, read_len: int) -> int:
+        occ = C.c_uint64()
+        L.check(L.lib().gk_map_count_reads_dev(self.h, d_records, nreads, read_len, C.byref(occ)), self.ctx.h)
+        return occ.value
+
+    def clear(self):
+        L.check(L.lib().gk_map_clear(self.h), self.ctx.h)
+
+    def slots(self) -> int:
+        n = C.c_uint64()
+        L.check(L.lib().gk_map_slots(self.h, C.byref(n)), self.ctx.h)
+        return n.value
+
+    def stats(self) -> dict:
+        buf = C.create_string_buffer(1024)
+        L.check(L.lib().gk_map_stats(self.h, buf, 1024), self.ctx.h)
+        return json.loads(buf.value.decode())
+
+    def last_count_kernel(self):
+        ms, occ = C.c_float(), C.c_uint64()
+        L.check(L.lib().gk_map_last_count_kernel(self.h, C.byref(ms), C.byref(occ)), self.ctx.h)
+        return ms.value, occ.value

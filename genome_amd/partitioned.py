@@ -1,0 +1,141 @@
+"""PartitionedDNAMap[Int] (S/ds/PartitionedDNAMap.scala:15-64): P partitions, each a HipDNAMap.
+
+Two deployments of the same routing code:
+  * logical partitions on ONE device (this class) — the only form `gpurun`'s 1-GPU box can run;
+  * one partition per rank/GPU (`RankPartition` + `exchange_and_insert`), the all-to-all carried by
+    RCCL through torch.distributed (backend "nccl"), or by gloo on CPU tensors in the CPU tests.
+Owner = strand-symmetric minimizer hash mod P (gk_owner_of) instead of `hashCode mod P`
+(PartitionedDNAMap.scala:60-63): unobservable in results, keeps x and rc(x) together.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .dnamap import Context, HipDNAMap, _keys
+
+
+def owner_of(k: int, lo: int, hi: int, P: int) -> int:
+    return L.lib().gk_owner_of(k, int(lo), int(hi), P)
+
+
+def split_counts_to_offsets(counts: np.ndarray) -> np.ndarray:
+    off = np.zeros(len(counts) + 1, np.int64)
+    np.cumsum(counts.astype(np.int64), out=off[1:])
+    return off
+
+
+class PartitionedDNAMap:
+    """P logical partitions on one device."""
+
+    def __init__(self, ctx: Context, k: int, P: int, capacity_hint: int = 0):
+        self.ctx, self.k, self.P = ctx, k, P
+        self.W = 1 if k <= 32 else 2
+        self.parts = [HipDNAMap(ctx, k, max(1, capacity_hint // P)) for _ in range(P)]
+
+    def close(self):
+        for p in self.parts:
+            p.close()
+
+    def size(self) -> int:                                    # :31
+        return sum(p.size() for p in self.parts)
+
+    def _owner_batch(self, lo, hi):
+        return np.array([owner_of(self.k, a, b, self.P) for a, b in zip(lo, hi)], np.int64)
+
+    def apply_batch(self, keys) -> np.ndarray:                # :33, routed per key
+        lo, hi = _keys(self.k, keys)
+        own = self._owner_batch(lo, hi)
+        out = np.empty(len(lo), np.int32)
+        for p in range(self.P):
+            idx = np.nonzero(own == p)[0]
+            if len(idx):
+                out[idx] = self.parts[p].apply_batch((lo[idx], hi[idx]))
+        return out
+
+    def apply(self, key):
+        v = int(self.apply_batch([key])[0])
+        return None if v < 0 else v
+
+    def contains(self, key) -> bool:                          # :53
+        return self.apply(key) is not None
+
+    def deleteAll_lt(self, rounds: int):                      # :49-51
+        for p in self.parts:
+            p.deleteAll_lt(rounds)
+
+    def count_reads_dev(self, d_records: int, nreads: int, read_len: int) -> int:
+        """extract + canonicalise + bucket by owner on the device, then owner-side inserts."""
+        nk = max(0, read_len - self.k + 1)
+        total = nreads * nk
+        if total == 0:
+            return 0
+        d_keys = self.ctx.alloc(total * 8 * self.W)
+        try:
+            counts = self.ctx.shard_reads(self.k, d_records, nreads, read_len, self.P, d_keys, total)
+            off = split_counts_to_offsets(counts)
+            for p in range(self.P):
+                if counts[p]:
+                    self.parts[p].update_inc_dev(d_keys + int(off[p]) * 8 * self.W, int(counts[p]))
+        finally:
+            self.ctx.free(d_keys)
+        return int(counts.sum())
+
+    def count_reads(self, bin_bytes, nreads: int) -> int:
+        """Host `.bin` stream.  Fixed-length streams take the device sharding path; ragged streams
+        are grouped by length first (the record framing is one length byte per read)."""
+        buf = np.frombuffer(bin_bytes, np.uint8) if not isinstance(bin_bytes, np.ndarray) else np.ascontiguousarray(bin_bytes, np.uint8).reshape(-1)
+        by_len: dict[int, list[int]] = {}
+        pos = 0
+        for _ in range(nreads):
+            if pos >= buf.size:
+                raise L.GkError(L.GK_E_FORMAT, "truncated .bin stream")
+            ln = int(buf[pos])
+            rb = 1 + (ln + 3) // 4
+            if pos + rb > buf.size:
+                raise L.GkError(L.GK_E_FORMAT, "truncated .bin stream")
+            by_len.setdefault(ln, []).append(pos)
+            pos += rb
+        occ = 0
+        for ln, starts in by_len.items():
+            if ln < self.k:
+                continue
+            rb = 1 + (ln + 3) // 4
+            idx = (np.array(starts, np.int64)[:, None] + np.arange(rb)[None, :]).reshape(-1)
+            rec = np.ascontiguousarray(buf[idx])
+            d_rec = self.ctx.alloc(rec.size + 64)
+            try:
+                self.ctx.upload(d_rec, rec)
+                occ += self.count_reads_dev(d_rec, len(starts), ln)
+            finally:
+                self.ctx.free(d_rec)
+        return occ
+
+    def items(self):
+        parts = [p.items() for p in self.parts]
+        return tuple(np.concatenate([x[i] for x in parts]) for i in range(3))
+
+    def sorted_items(self):
+        lo, hi, cnt = self.items()
+        order = np.lexsort((lo, hi))
+        return lo[order], hi[order], cnt[order]
+
+    def merged(self) -> HipDNAMap:
+        """Gather every partition into one table (what Graph.buildGraph needs; SURVEY.md §8e
+        "all-gather the survivors")."""
+        lo, hi, cnt = self.items()
+        m = HipDNAMap(self.ctx, self.k, len(lo))
+        if len(lo):
+            m.add_counts(lo, hi, cnt)
+        return m
+
+
+def exchange_plan(send_counts: np.ndarray, dist, device=None):
+    """all-to-all of the per-owner counts: returns recv_counts (what each peer sends me)."""
+    import torch
+    sc = torch.as_tensor(send_counts.astype(np.int64), device=device)
+    rc = torch.empty_like(sc)
+    dist.all_to_all_single(rc, sc)
+    return rc.cpu().numpy().astype(np.int64)

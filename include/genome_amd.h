@@ -1,0 +1,164 @@
+/*
+ * genome_amd.h — C-ABI of the MI355X-native k-mer hashtable + de Bruijn graph-build core.
+ *
+ * This is the drop-in boundary for the data-parallel hot path of winger/genome
+ * (S/ = /root/reference/src/main/scala/ru/ifmo/genome/).  Plain pointers and sizes only; no torch
+ * types.  Each entry point names the reference interface it replaces.  The Scala-side binding a
+ * maintainer would add (JNI stub + `HipDNAMap extends DNAMap[Int]`) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - Every function returns a gk_status (0 = ok, <0 = error); the message of the last error of a
+ *     context is available through gk_last_error().  Nothing aborts.  (Reference: `assert` =>
+ *     AssertionError on wrong key length, S/ds/ArrayDNAMap.scala:182; failures surface via Future.)
+ *   - Handles are opaque, created/destroyed by the caller and EXTERNALLY SYNCHRONISED: one call at
+ *     a time per handle, from any thread (reference: an ArrayDNAMap is confined to its actor).
+ *   - Calls are synchronous on return.  Host input buffers are borrowed for the duration of the
+ *     call; export buffers are caller-allocated with a capacity and an out-count.
+ *   - `_dev` variants take DEVICE pointers (hipMalloc'ed by the caller, e.g. a torch tensor's
+ *     data_ptr()) valid on the context's device.
+ *   - k-mers cross the ABI as little-endian uint64 lo[,hi] in the reference bit layout: base i at
+ *     bits 2i of lo (i<32) / 2(i-32) of hi, codes A=0 G=1 C=2 T=3, unused high bits zero
+ *     (S/dna/DNASeq.scala:74-215, S/dna/Base.scala:13-19).  `hi` arrays may be NULL when k<=32.
+ *     Counts are int32 (the reference's DNAMap[Int]).
+ *   - Supported k: 2..31 and 34..63.  k=32/33 are broken in the reference itself
+ *     and k=64 / k>64 are not implemented here: GK_E_UNSUPPORTED_K.
+ *   - There is no CPU fallback: without a gfx950 device every compute call fails with
+ *     GK_E_NODEVICE / GK_E_HIP.
+ */
+#ifndef GENOME_AMD_H
+#define GENOME_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    GK_OK = 0,
+    GK_E_INVALID = -1,        /* bad argument (NULL handle, negative size, ...) */
+    GK_E_KLEN = -2,           /* key length != the map's k  (ArrayDNAMap.scala:182,187,192,199,206) */
+    GK_E_UNSUPPORTED_K = -3,  /* k outside 2..31, 34..63 */
+    GK_E_CAPACITY = -4,       /* table could not grow / export buffer too small */
+    GK_E_HIP = -5,            /* HIP runtime error (message has the hipError string) */
+    GK_E_NODEVICE = -6,       /* no usable gfx950 device */
+    GK_E_FORMAT = -7,         /* malformed `.bin` read stream */
+    GK_E_STATE = -8           /* operation not valid in the handle's current state */
+} gk_status;
+
+typedef struct gk_ctx gk_ctx;       /* one device + stream; replaces ActorsHome.system (S/scripts/ActorsHome.scala:20-30) */
+typedef struct gk_map gk_map;       /* one ArrayDNAMap[Int] partition, resident in HBM */
+typedef struct gk_graph gk_graph;   /* a MapGraph, resident in HBM */
+
+/* ---- context ---------------------------------------------------------------------------- */
+int gk_device_count(void);                       /* number of HIP devices, 0 if none / no runtime */
+int gk_ctx_create(int device, gk_ctx **out);
+void gk_ctx_destroy(gk_ctx *ctx);
+const char *gk_last_error(const gk_ctx *ctx);    /* ctx may be NULL: last error of the calling thread */
+int gk_ctx_device(const gk_ctx *ctx);
+int gk_ctx_sync(gk_ctx *ctx);                    /* hipStreamSynchronize on the context stream */
+/* raw device memory helpers for callers without their own allocator (tests, the C++ host side) */
+int gk_dev_alloc(gk_ctx *ctx, size_t nbytes, void **dev_ptr);
+int gk_dev_free(gk_ctx *ctx, void *dev_ptr);
+int gk_dev_upload(gk_ctx *ctx, void *dev_dst, const void *host_src, size_t nbytes);
+int gk_dev_download(gk_ctx *ctx, void *host_dst, const void *dev_src, size_t nbytes);
+
+/* ---- DNAMap[Int]: trait at S/ds/ArrayDNAMap.scala:49-60 ----------------------------------- */
+/* new ArrayDNAMap[Int](k)  (ArrayDNAMap.scala:62-72).  capacity_hint = expected number of distinct
+ * keys (0 = default); the table is pre-sized from it and grows by rehashing when a batch could
+ * push the load factor past 0.75 (the reference's 0.3/0.7 rescale, :217-230, is unobservable). */
+int gk_map_create(gk_ctx *ctx, int k, uint64_t capacity_hint, gk_map **out);
+void gk_map_destroy(gk_map *m);
+int gk_map_k(const gk_map *m);
+int gk_map_clear(gk_map *m);                               /* back to an empty table of the same capacity */
+int gk_map_size(gk_map *m, uint64_t *n);                   /* DNAMap.size :50 (live keys) */
+int gk_map_slots(gk_map *m, uint64_t *slots);              /* current table capacity in slots */
+
+/* FreqFilter.add over a stream of reads (S/data/FreqFilter.scala:28-36, 44-48):
+ * for every read with len >= k, every window in order -> reverse complement -> orientation with
+ * the smaller signed hashCode (tie: reverse complement) -> update(y, 1, _+1).
+ * `bin` is the reference `.bin` record stream [len:u8][ceil(len/4) bytes] x nreads
+ * (S/data/PairedEndData.scala:20-36); *occurrences (may be NULL) = number of windows counted. */
+int gk_map_count_reads(gk_map *m, const uint8_t *bin_host, size_t nbytes, uint64_t nreads, uint64_t *occurrences);
+/* same, records already in HBM and all of one length (fixed stride 1+ceil(read_len/4)) */
+int gk_map_count_reads_dev(gk_map *m, const void *dev_records, uint64_t nreads, int read_len, uint64_t *occurrences);
+
+/* DNAMap.update(key, 1, _+1) for a batch of keys taken verbatim (no canonicalisation):
+ * PartitionedDNAMap's owner-side insert (Messages.update1, ArrayDNAMap.scala:39).  Keys are
+ * W = 1 (k<=32) or 2 (k>32) uint64 each. */
+int gk_map_update_inc(gk_map *m, const uint64_t *lo, const uint64_t *hi, uint64_t n);
+/* device keys, interleaved W words per key ([lo] or [lo,hi]) as gk_shard_reads_dev emits them */
+int gk_map_update_inc_dev(gk_map *m, const void *dev_keys, uint64_t n);
+/* update(key, v0=c, f=_+c): adds counts of pre-aggregated keys (merging exported partitions) */
+int gk_map_add_counts(gk_map *m, const uint64_t *lo, const uint64_t *hi, const int32_t *counts, uint64_t n);
+
+/* DNAMap.deleteAll((k, v) => v < rounds)  (FreqFilter.scala:55; ArrayDNAMap.scala:164-173, 212-215) */
+int gk_map_filter_lt(gk_map *m, int32_t rounds);
+
+/* DNAMap.apply / contains for a batch (ArrayDNAMap.scala:90-101, 232): counts_out[i] = value or
+ * -1 when absent; found_out[i] = 0/1.  Either output may be NULL.  One strand only, as the trait. */
+int gk_map_get_batch(gk_map *m, const uint64_t *lo, const uint64_t *hi, uint64_t n, int32_t *counts_out, uint8_t *found_out);
+
+/* Container.iterator / mapReduce(identity) (ArrayDNAMap.scala:175-178, 234-241): every live
+ * (key, count) in slot order (unspecified; callers sort for comparison).  If cap < live count the
+ * call fails with GK_E_CAPACITY and *n holds the required size. */
+int gk_map_export(gk_map *m, uint64_t *lo, uint64_t *hi, int32_t *counts, uint64_t cap, uint64_t *n);
+
+/* JSON counters: capacity, size, occurrences, grows, last kernel time ... (SURVEY.md §5 metrics) */
+int gk_map_stats(gk_map *m, char *json, size_t cap);
+/* duration (ms, HIP events on the context stream) and occurrence count of the most recent
+ * insert+count kernel launched by gk_map_count_reads[_dev] — used by bench.py's roofline. */
+int gk_map_last_count_kernel(gk_map *m, float *ms, uint64_t *occurrences);
+
+/* ---- PartitionedDNAMap: owner routing (S/ds/PartitionedDNAMap.scala:60-63) ----------------- */
+/* Extract + canonicalise every k-mer of fixed-length device reads and bucket the canonical keys
+ * by owner partition.  The owner is a strand-symmetric minimizer hash mod P (not `hashCode mod P`:
+ * the partition function is unobservable in results), so both orientations of a
+ * k-mer — and both candidates of the hash-rule tie — land on the same partition.
+ * dev_keys_out receives the keys grouped by owner (W uint64 per key), capacity keys_cap keys;
+ * counts_host[p] = number of keys for owner p (sum = occurrences).  Exchange the groups
+ * (RCCL all-to-all) and feed what a rank receives to gk_map_update_inc_dev. */
+int gk_shard_reads_dev(gk_ctx *ctx, int k, const void *dev_records, uint64_t nreads, int read_len, int P,
+                       void *dev_keys_out, uint64_t keys_cap, uint64_t *counts_host);
+/* owner of one key under the same function (host-side, for tests and for routing point queries) */
+int gk_owner_of(int k, uint64_t lo, uint64_t hi, int P);
+
+/* ---- Graph: S/data/graph/Graph.scala ------------------------------------------------------- */
+/* Graph.buildGraph(k, kmersFreq) (:269-382): degree classification of every live key through
+ * `contains` on both strands, one node per terminal k-mer (both strands), one edge per
+ * (node, outgoing base) walked to the next terminal k-mer.  The map must hold the whole k-mer set
+ * (merge partitions with gk_map_export + gk_map_add_counts first). */
+int gk_graph_build(gk_map *m, gk_graph **out);
+void gk_graph_destroy(gk_graph *g);
+int gk_graph_counts(gk_graph *g, uint64_t *nodes, uint64_t *edges, uint64_t *total_edge_len); /* live */
+int gk_graph_simplify(gk_graph *g);          /* MapGraph.simplifyGraph :211-230 */
+int gk_graph_remove_bubbles(gk_graph *g);    /* Graph.removeBubbles :125-149 */
+/* MapGraph.removeEdge :191-195 for the edges leaving start[i] with first base base[i] */
+int gk_graph_remove_edges(gk_graph *g, const uint64_t *start_lo, const uint64_t *start_hi, const uint8_t *base,
+                          uint64_t n, uint64_t *removed);
+/* Graph.components + retain(maxBy size) (:54-72, :161-165; GraphBuilder.scala:52-54); ties between
+ * equal-size components go to the one holding the smallest k-mer. */
+int gk_graph_retain_largest(gk_graph *g, uint64_t *kept_nodes, uint64_t *components);
+/* live nodes, unspecified order */
+int gk_graph_export_nodes(gk_graph *g, uint64_t *lo, uint64_t *hi, uint64_t cap, uint64_t *n);
+/* live edges, unspecified order: start/end k-mer, length in bases, and the edge sequence as 2-bit
+ * codes packed LSB-first (4 per byte, each edge starting on a byte boundary at seq_off[i]). */
+int gk_graph_export_edges(gk_graph *g, uint64_t *start_lo, uint64_t *start_hi, uint64_t *end_lo, uint64_t *end_hi,
+                          int64_t *len, int64_t *seq_off, uint64_t cap, uint64_t *n,
+                          uint8_t *seq2bit, uint64_t seq_cap, uint64_t *seq_bytes);
+/* out-edge insertion order of one node (the reference's immutable Map1..Map4 order, used by
+ * removeBubbles); bases4 gets up to 4 base codes, *count their number (-1 = no such node) */
+int gk_graph_out_order(gk_graph *g, uint64_t lo, uint64_t hi, int *bases4, int *count);
+
+/* ---- synthetic reads (bench / tests) ---------------------------------------- */
+/* Fill dev_records with nreads fixed-length `.bin` records generated on device, bit-identical to
+ * genome_amd/synth.py.  mode 0 = U (uniform bases); mode 1 = G (genome of G bases, error rate
+ * err_thresh24 / 2^24).  first_read offsets the stream so chunks can be generated independently. */
+int gk_synth_reads_dev(gk_ctx *ctx, void *dev_records, uint64_t nreads, int read_len, int mode, uint64_t config_id,
+                       uint64_t first_read, uint64_t genome_len, uint32_t err_thresh24);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,236 @@
+"""GPU parity tests of the DNAMap / FreqFilter hot path: the HIP library, called through the C-ABI,
+against the CPU oracle on the same inputs — bit-exact on the canonical (sorted) table
+serialisation — plus size-independent properties at BASELINE.json's full C2 size.
+"""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from genome_amd import _lib as L
+from genome_amd import dna, synth
+from genome_amd.dnamap import Context, HipDNAMap
+from genome_amd.partitioned import PartitionedDNAMap, owner_of
+from oracle import oracle as O
+from oracle import pyref as R
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def assert_same_table(got, want):
+    for name, a, b in zip(("lo", "hi", "count"), got, want):
+        assert a.shape == b.shape, f"{name}: {a.shape} vs {b.shape}"
+        assert np.array_equal(a, b), name
+
+
+def test_device_is_gfx950(ctx):
+    assert L.device_count() >= 1
+
+
+@pytest.mark.parametrize("name", sorted(f[:-5] for f in os.listdir(GOLDEN) if f.endswith(".json")))
+def test_golden_tables(ctx, name):
+    fx = json.load(open(os.path.join(GOLDEN, name + ".json")))
+    k, P, rounds = fx["k"], fx["P"], fx["rounds"]
+    binb = bytes.fromhex(fx["bin_hex"])
+    for m in (HipDNAMap(ctx, k), PartitionedDNAMap(ctx, k, P) if P > 1 else HipDNAMap(ctx, k, 100000)):
+        assert m.count_reads(binb, fx["nreads"]) == fx["occurrences"]
+        lo, hi, cnt = m.sorted_items()
+        assert [[int(a), int(b), int(c)] for a, b, c in zip(lo, hi, cnt)] == fx["table"]
+        m.deleteAll_lt(rounds)
+        lo, hi, cnt = m.sorted_items()
+        assert [[int(a), int(b), int(c)] for a, b, c in zip(lo, hi, cnt)] == fx["table_filtered"]
+        assert m.size() == len(fx["table_filtered"])
+        m.close()
+
+
+def _random_reads(rnd, n, lmin, lmax, genome_len, err):
+    g = "".join(rnd.choice("AGCT") for _ in range(genome_len))
+    reads = []
+    for _ in range(n):
+        ln = rnd.randint(lmin, lmax)
+        st = rnd.randrange(0, genome_len - ln + 1)
+        r = g[st:st + ln]
+        if rnd.random() < 0.5:
+            r = R.rev_comp(r)
+        reads.append("".join(c if rnd.random() >= err else rnd.choice([x for x in "AGCT" if x != c]) for c in r))
+    return reads
+
+
+@pytest.mark.parametrize("k", [2, 5, 11, 21, 30, 31, 34, 35, 47, 55, 62, 63])
+def test_ragged_reads_vs_oracle(ctx, k):
+    """Ragged / empty / shorter-than-k records (FreqFilter.scala:29), every supported key width."""
+    rnd = random.Random(k)
+    reads = _random_reads(rnd, 300, max(1, k - 5), min(255, k + 120), 1200, 0.02)
+    reads += ["", "A", "AG", "AGCT"[:max(1, min(4, k - 1))]] + ["".join(rnd.choice("AGCT") for _ in range(255))] * 2
+    rnd.shuffle(reads)
+    binb = dna.reads_to_bin(reads)
+    m = HipDNAMap(ctx, k, 64)            # tiny hint: forces the rehash/grow path
+    ref = O.PMap(k, 1)
+    occ = ref.count_reads(binb, len(reads))
+    assert m.count_reads(binb, len(reads)) == occ
+    assert_same_table(m.sorted_items(), ref.export_sorted())
+    assert m.size() == ref.size()
+    assert m.stats()["grows"] >= 1
+    # a second pass over the same reads doubles every count (update(y, 1, _+1) is additive)
+    m.count_reads(binb, len(reads))
+    lo, hi, cnt = ref.export_sorted()
+    assert_same_table(m.sorted_items(), (lo, hi, cnt * 2))
+    for rounds in (3, 5):
+        m.deleteAll_lt(rounds)
+        ref2 = O.PMap(k, 1)
+        ref2.count_reads(binb, len(reads)); ref2.count_reads(binb, len(reads))
+        ref2.delete_lt(rounds)
+        assert_same_table(m.sorted_items(), ref2.export_sorted())
+    m.close()
+
+
+def test_truncated_stream_is_a_format_error(ctx):
+    m = HipDNAMap(ctx, 11)
+    binb = dna.reads_to_bin(["AGCTAGCTAGCTAGCT"] * 3)
+    with pytest.raises(L.GkError) as e:
+        m.count_reads(binb[:-2], 3)
+    assert e.value.code == L.GK_E_FORMAT
+    with pytest.raises(L.GkError):
+        m.count_reads(binb, 4)
+    assert m.size() <= 6
+    m.close()
+
+
+def test_key_length_and_k_errors(ctx):
+    """`assert(key.length == k)` (ArrayDNAMap.scala:182,199) -> GK_E_KLEN; k=32/33/64 unsupported."""
+    m = HipDNAMap(ctx, 11)
+    with pytest.raises(AssertionError):
+        m.apply("AGCT")
+    with pytest.raises(L.KeyLengthError):
+        m.update_inc([(1 << 22, 0)])          # bit above 2k
+    with pytest.raises(L.KeyLengthError):
+        m.apply_batch([(1, 1)])
+    m.close()
+    for k in (0, 1, 32, 33, 64, 65, 100):
+        with pytest.raises(L.GkError) as e:
+            HipDNAMap(ctx, k)
+        assert e.value.code == L.GK_E_UNSUPPORTED_K
+
+
+@pytest.mark.parametrize("k", [21, 55])
+def test_apply_contains_update(ctx, k):
+    rnd = random.Random(k)
+    keys = ["".join(rnd.choice("AGCT") for _ in range(k)) for _ in range(500)]
+    m = HipDNAMap(ctx, k)
+    assert m.size() == 0 and m.apply(keys[0]) is None and not m.contains(keys[0])
+    m.update_inc(keys[:300])
+    m.update_inc(keys[:100])
+    want = {}
+    for s in keys[:300] + keys[:100]:
+        want[s] = want.get(s, 0) + 1
+    assert m.size() == len(want)
+    got = m.apply_batch(keys)
+    for s, v in zip(keys, got):
+        assert int(v) == want.get(s, -1)
+    # verbatim keys: no canonicalisation happens in update (that is FreqFilter's job)
+    rc = R.rev_comp(keys[0])
+    if rc not in want:
+        assert not m.contains(rc)
+    m.clear()
+    assert m.size() == 0 and m.apply(keys[0]) is None
+    m.close()
+
+
+@pytest.mark.parametrize("k,L_,mode", [(21, 100, "G"), (31, 150, "U"), (31, 150, "G"), (55, 150, "G"), (63, 150, "U")])
+def test_device_resident_reads_and_device_synth(ctx, k, L_, mode):
+    """count_reads_dev on records generated on the device == oracle on the numpy generator's bytes."""
+    n, G, e, cid = 3000, 20000, 0.01, 7
+    rec = synth.reads_mode_u(n, L_, cid) if mode == "U" else synth.reads_mode_g(n, L_, G, e, cid)
+    d = ctx.alloc(rec.size + 64)
+    ctx.synth_reads(d, n, L_, mode, cid, 0, G, e)
+    assert np.array_equal(ctx.download(d, rec.size), rec.reshape(-1)), "device generator != numpy generator"
+    # chunked generation with first_read offsets gives the same bytes
+    half = n // 2
+    ctx.synth_reads(d + half * rec.shape[1], n - half, L_, mode, cid, half, G, e)
+    assert np.array_equal(ctx.download(d, rec.size), rec.reshape(-1))
+    m = HipDNAMap(ctx, k, n * (L_ - k + 1))
+    occ = m.count_reads_dev(d, n, L_)
+    ref = O.PMap(k, 1)
+    assert occ == ref.count_reads(rec.tobytes(), n) == n * (L_ - k + 1)
+    assert_same_table(m.sorted_items(), ref.export_sorted())
+    ms, kocc = m.last_count_kernel()
+    assert kocc == occ and ms > 0
+    m.close()
+    ctx.free(d)
+
+
+@pytest.mark.parametrize("k,P", [(21, 2), (31, 4), (31, 8), (55, 8), (63, 3)])
+def test_logical_partitions_vs_oracle(ctx, k, P):
+    """PartitionedDNAMap: sorted content is independent of P and of the partition function."""
+    n, L_ = 2000, 120
+    rec = synth.reads_mode_g(n, L_, 9000, 0.01, config_id=k + P)
+    d = ctx.alloc(rec.size + 64)
+    ctx.upload(d, rec)
+    pm = PartitionedDNAMap(ctx, k, P)
+    occ = pm.count_reads_dev(d, n, L_)
+    ref = O.PMap(k, P)
+    assert occ == ref.count_reads(rec.tobytes(), n)
+    assert_same_table(pm.sorted_items(), ref.export_sorted())
+    assert pm.size() == ref.size()
+    # every key sits in the partition the owner function names, and so would its reverse complement
+    sizes = []
+    for p, part in enumerate(pm.parts):
+        lo, hi, _ = part.items()
+        sizes.append(len(lo))
+        for a, b in list(zip(lo, hi))[:200]:
+            assert owner_of(k, int(a), int(b), P) == p
+            s = dna.unpack(int(a), int(b), k)
+            rlo, rhi = dna.pack(R.rev_comp(s))
+            assert owner_of(k, rlo, rhi, P) == p
+    assert min(sizes) > 0
+    pm.deleteAll_lt(3); ref.delete_lt(3)
+    assert_same_table(pm.sorted_items(), ref.export_sorted())
+    merged = pm.merged()
+    assert_same_table(merged.sorted_items(), ref.export_sorted())
+    keys = (ref.export_sorted()[0][:50], ref.export_sorted()[1][:50])
+    assert np.array_equal(pm.apply_batch(keys), ref.export_sorted()[2][:50])
+    merged.close(); pm.close(); ctx.free(d)
+
+
+def test_full_size_c2_properties(ctx):
+    """BASELINE.json configs[1]: 1M x 150 bp, k=31, one GPU.  The oracle cannot finish this in
+    seconds, so check size-independent properties: window count, sum of counts == occurrences,
+    additivity of a second pass, filter monotonicity, and a sampled exact comparison."""
+    n, L_, k = 1_000_000, 150, 31
+    stride = synth.record_stride(L_)
+    d = ctx.alloc(n * stride + 64)
+    ctx.synth_reads(d, n, L_, "G", 2, 0, 5_000_000, 0.01)
+    m = HipDNAMap(ctx, k, n * (L_ - k + 1))
+    occ = m.count_reads_dev(d, n, L_)
+    assert occ == n * (L_ - k + 1)
+    lo, hi, cnt = m.items()
+    assert len(lo) == m.size() and int(cnt.astype(np.int64).sum()) == occ
+    assert len(np.unique(lo)) == len(lo)                      # a key never lands in two slots
+    # sampled exactness: the first 300 reads through the oracle, every key's count must be >= and the
+    # key set must be contained
+    head = ctx.download(d, 300 * stride)
+    ref = O.PMap(k, 1)
+    ref.count_reads(head.tobytes(), 300)
+    rlo, rhi, rcnt = ref.export_sorted()
+    got = m.apply_batch((rlo, rhi))
+    assert (got >= rcnt).all()
+    size1 = m.size()
+    m.count_reads_dev(d, n, L_)
+    assert m.size() == size1
+    lo2, _, cnt2 = m.items()
+    o1, o2 = np.argsort(lo), np.argsort(lo2)
+    assert np.array_equal(lo[o1], lo2[o2]) and np.array_equal(cnt[o1] * 2, cnt2[o2])
+    ge3 = int((cnt2 >= 3).sum())
+    m.deleteAll_lt(3)
+    assert m.size() == ge3
+    m.close(); ctx.free(d)
