@@ -1,15 +1,1096 @@
-// placeholder, replaced below
+// gk_graph.hip — de Bruijn graph build and structural simplification as HIP kernels (gfx950).
+//
+// Reference path replaced (S/ = /root/reference/src/main/scala/ru/ifmo/genome/):
+//   Graph.buildGraph      S/data/graph/Graph.scala:269-382   k_classify, k_collect_terminals,
+//                                                            k_make_nodes, k_walk
+//   contains/incoming/outcoming          :270-282            gk::table_find_either (gk_device.h)
+//   MapGraph.addNode/addEdge/removeEdge  :172-195            node/edge arrays below
+//   MapGraph.simplifyGraph               :211-230            k_node_class, k_chain_*, k_simplify_finish
+//   Graph.removeBubbles                  :125-149            k_bubbles
+//   Graph.components + retain            :54-72, :161-165    k_cc_*, k_retain
+//
+// Layout in HBM: the k-mer table (array of 16/32-B slots) carries the degree annotation in its
+// `aux` word (in-mask, out-mask, TERMINAL, SECONDARY) so one probe during a walk touches one
+// sector.  The graph itself is structure-of-arrays: node k-mers, a 4-entry out-edge table per node
+// (indexed by first base) plus its insertion order (the reference's immutable Map1..Map4 order),
+// in-degree; edges as (start, end, length, byte offset) into one 2-bit-packed sequence pool.
+// All kernels are integer, HBM/latency bound; no MFMA.
+//
+// Ids: node/edge ids are array indices in compaction order — arbitrary, like the reference's
+// AtomicLong ids under `.par`; results are compared on canonical serialisations.
+// Where the reference's result depends on node iteration order (out-edge insertion order after
+// simplifyGraph), this file reproduces "ascending k-mer order", the oracle's deterministic choice.
+#include <algorithm>
+#include <string>
+#include <vector>
+
 #include "gk_internal.h"
+#include "gk_tile.h"
+
 using namespace gk;
-extern "C" {
-int gk_graph_build(gk_map *m, gk_graph **out) { (void)out; return fail(m ? m->ctx : nullptr, GK_E_STATE, "graph: not built yet"); }
-void gk_graph_destroy(gk_graph *) {}
-int gk_graph_counts(gk_graph *, uint64_t *, uint64_t *, uint64_t *) { return GK_E_STATE; }
-int gk_graph_simplify(gk_graph *) { return GK_E_STATE; }
-int gk_graph_remove_bubbles(gk_graph *) { return GK_E_STATE; }
-int gk_graph_remove_edges(gk_graph *, const uint64_t *, const uint64_t *, const uint8_t *, uint64_t, uint64_t *) { return GK_E_STATE; }
-int gk_graph_retain_largest(gk_graph *, uint64_t *, uint64_t *) { return GK_E_STATE; }
-int gk_graph_export_nodes(gk_graph *, uint64_t *, uint64_t *, uint64_t, uint64_t *) { return GK_E_STATE; }
-int gk_graph_export_edges(gk_graph *, uint64_t *, uint64_t *, uint64_t *, uint64_t *, int64_t *, int64_t *, uint64_t, uint64_t *, uint8_t *, uint64_t, uint64_t *) { return GK_E_STATE; }
-int gk_graph_out_order(gk_graph *, uint64_t, uint64_t, int *, int *) { return GK_E_STATE; }
+
+static constexpr u32 NONE = 0xFFFFFFFFu;
+static constexpr u32 AUX_TERMINAL = 1u << 8;
+static constexpr u32 AUX_SECONDARY = 1u << 9;
+
+// ---------------------------------------------------------------------------------------------
+// device-side view of a graph
+// ---------------------------------------------------------------------------------------------
+struct GraphView {
+    int k;
+    u64 n_nodes, n_edges;
+    u64 *node_lo, *node_hi;
+    uint8_t *node_alive;
+    u32 *out_edge;      // [n_nodes*4], by first base
+    u32 *out_order;     // count in bits 0..2, i-th base in bits 4+2i..5+2i
+    u32 *in_deg;
+    u32 *e_start, *e_end;
+    u64 *e_len, *e_off;
+    uint8_t *e_alive, *e_first;
+    uint8_t *pool;
+    u32 *nidx;          // open-addressed k-mer -> node id index
+    u64 nidx_mask;
+};
+
+struct gk_graph {
+    gk_ctx *ctx = nullptr;
+    int k = 0, W = 1;
+    GraphView v{};
+    u64 node_cap = 0, edge_cap = 0, pool_cap = 0, pool_used = 0;
+    u64 live_nodes = 0, live_edges = 0, live_len = 0;
+};
+
+__device__ __forceinline__ int order_count(u32 o) { return (int)(o & 7u); }
+__device__ __forceinline__ int order_base(u32 o, int i) { return (int)((o >> (4 + 2 * i)) & 3u); }
+__device__ __forceinline__ u32 order_append(u32 o, int b) {
+    int c = order_count(o);
+    return ((o & ~7u) | (u32)(c + 1)) | ((u32)b << (4 + 2 * c));
 }
+__device__ __forceinline__ u32 order_remove(u32 o, int b) {
+    u32 r = 0;
+    for (int i = 0; i < order_count(o); i++) if (order_base(o, i) != b) r = order_append(r, order_base(o, i));
+    return r;
+}
+__device__ __forceinline__ u32 rev4(u32 m) { return ((m & 1) << 3) | ((m & 2) << 1) | ((m & 4) >> 1) | ((m & 8) >> 3); }
+__device__ __forceinline__ int pool_get(const uint8_t *pool, u64 off, u64 i) { return (pool[off + (i >> 2)] >> ((i & 3) * 2)) & 3; }
+
+template <int W> __device__ __forceinline__ Kmer<W> node_kmer(const GraphView &g, u64 n);
+template <> __device__ __forceinline__ Kmer<1> node_kmer<1>(const GraphView &g, u64 n) { return Kmer<1>{g.node_lo[n]}; }
+template <> __device__ __forceinline__ Kmer<2> node_kmer<2>(const GraphView &g, u64 n) { return Kmer<2>{g.node_lo[n], g.node_hi[n]}; }
+__device__ __forceinline__ bool node_less(const GraphView &g, u32 a, u32 b) {   // unsigned (hi, lo) order
+    u64 ah = g.node_hi[a], bh = g.node_hi[b];
+    return ah != bh ? ah < bh : g.node_lo[a] < g.node_lo[b];
+}
+
+__device__ __forceinline__ u32 wave_incl_scan(u32 v) {
+    const int lane = threadIdx.x & 63;
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+// block-wide exclusive scan of small per-thread counts; *total = block sum
+__device__ __forceinline__ u32 block_excl_scan(u32 v, u32 *total, u32 *lds4) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 inc = wave_incl_scan(v);
+    __syncthreads();
+    if (lane == 63) lds4[wave] = inc;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+    for (int w = 0; w < BLOCK / 64; ++w) {
+        u32 c = lds4[w];
+        if (w < wave) base += c;
+        tot += c;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+// reserve `v` units per thread from a global cursor with ONE atomic per block; returns this
+// thread's first unit
+__device__ __forceinline__ u64 block_reserve(u32 v, unsigned long long *cursor, u32 *lds4, unsigned long long *s_base) {
+    u32 tot;
+    u32 pre = block_excl_scan(v, &tot, lds4);
+    if (threadIdx.x == 0) *s_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
+    __syncthreads();
+    u64 r = *s_base + pre;
+    __syncthreads();
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// build
+// ---------------------------------------------------------------------------------------------
+// op1 of Graph.buildGraph (Graph.scala:320-329) for every live stored key: incoming/outcoming
+// through `contains` on both strands (:270-282), 8 lookups per key; result kept in the slot.
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_classify(Table<W> t, int k, unsigned long long *n_term) {
+    __shared__ u32 s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    u32 cnt = 0;
+    const u64 ncap = t.mask + 1;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < ncap; i += (u64)gridDim.x * BLOCK) {
+        Slot<W> *s = &t.slots[i];
+        if (!slot_live(s)) continue;
+        Kmer<W> y = from_stored(load_stored(s));
+        u32 in = 0, out = 0;
+        bool f;
+        for (int b = 0; b < 4; b++) {
+            if (table_find_either(t, prepend_base(b, y, k), k, &f) >= 0) in |= 1u << b;
+            if (table_find_either(t, append_base(y, b, k), k, &f) >= 0) out |= 1u << b;
+        }
+        const int ni = __popc(in), no = __popc(out);
+        u32 aux = in | (out << 4);
+        const bool term = (ni != 1 || no != 1) && (ni != 0 || no != 0);     // Graph.scala:323
+        if (term) aux |= AUX_TERMINAL;
+        // hash-rule tie (FreqFilter.scala:31-32): x and rc(x) may both be stored; the larger one
+        // is marked SECONDARY so the pair yields one pair of nodes
+        Kmer<W> rc = revcomp(y, k);
+        bool secondary = false;
+        if (ref_hash(y) == ref_hash(rc) && !(y == rc) && kmer_less(rc, y) && table_find(t, rc) >= 0) secondary = true;
+        if (secondary) aux |= AUX_SECONDARY;
+        s->aux = aux;
+        if (term && !secondary) cnt++;
+    }
+    if (cnt) atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) atomicAdd(n_term, (unsigned long long)s_cnt);
+}
+
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_collect_terminals(Table<W> t, int k, u64 *tslots, unsigned long long *cursor,
+                                                             unsigned long long *n_edges) {
+    __shared__ u32 lds4[BLOCK / 64];
+    __shared__ unsigned long long s_base;
+    __shared__ u32 s_edges;
+    if (threadIdx.x == 0) s_edges = 0;
+    const u64 ncap = t.mask + 1;
+    const u64 ngroups = (ncap + BLOCK - 1) / BLOCK;
+    u32 edges = 0;
+    for (u64 g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        u64 i = g * BLOCK + threadIdx.x;
+        bool sel = false;
+        if (i < ncap && slot_live(&t.slots[i])) {
+            u32 aux = t.slots[i].aux;
+            sel = (aux & AUX_TERMINAL) && !(aux & AUX_SECONDARY);
+            if (sel) {
+                // out(y) + out(rc y) = popc(out) + popc(in); a palindrome (y == rc y, even k) is ONE node
+                Kmer<W> y = from_stored(load_stored(&t.slots[i]));
+                edges += (y == revcomp(y, k)) ? __popc((aux >> 4) & 15u) : __popc(aux & 0xffu);
+            }
+        }
+        u64 o = block_reserve(sel ? 1u : 0u, cursor, lds4, &s_base);
+        if (sel) tslots[o] = i;
+    }
+    if (edges) atomicAdd(&s_edges, edges);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_edges) atomicAdd(n_edges, (unsigned long long)s_edges);
+}
+
+// nodeMap (Graph.scala:343-347): node 2j = the stored terminal k-mer, node 2j+1 = its reverse
+// complement (termKmers = set ++ set.map(revComplement), :330-333); plus the (node, base) stubs of
+// buildEdges (:351): one edge per outgoing base, in A,G,C,T order.
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_make_nodes(Table<W> t, int k, const u64 *tslots, u64 nT, GraphView g, u32 *slot_node,
+                                                      unsigned long long *ecursor) {
+    __shared__ u32 lds4[BLOCK / 64];
+    __shared__ unsigned long long s_base;
+    const u64 ngroups = (nT + BLOCK - 1) / BLOCK;
+    for (u64 grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const u64 j = grp * BLOCK + threadIdx.x;
+        u32 m0 = 0, m1 = 0;
+        Kmer<W> y{}, rc{};
+        bool pal = false;
+        if (j < nT) {
+            const u64 slot = tslots[j];
+            const u32 aux = t.slots[slot].aux;
+            y = from_stored(load_stored(&t.slots[slot]));
+            rc = revcomp(y, k);
+            pal = (y == rc);
+            m0 = (aux >> 4) & 15u;                  // outcoming(y)
+            m1 = pal ? 0u : rev4(aux & 15u);        // outcoming(rc y) = complemented incoming(y)
+            slot_node[slot] = (u32)(2 * j);
+        }
+        u64 e = block_reserve((u32)(__popc(m0) + __popc(m1)), ecursor, lds4, &s_base);
+        if (j < nT) {
+            const u32 n0 = (u32)(2 * j), n1 = n0 + 1;
+            g.node_lo[n0] = y.lo; g.node_lo[n1] = rc.lo;
+            if constexpr (W == 2) { g.node_hi[n0] = y.hi; g.node_hi[n1] = rc.hi; }
+            else { g.node_hi[n0] = 0; g.node_hi[n1] = 0; }
+            g.node_alive[n0] = 1; g.node_alive[n1] = pal ? 0 : 1;
+            for (int side = 0; side < 2; side++) {
+                const u32 n = side ? n1 : n0, m = side ? m1 : m0;
+                u32 ord = 0;
+                for (int b = 0; b < 4; b++) {
+                    u32 id = NONE;
+                    if (m & (1u << b)) {
+                        id = (u32)e++;
+                        g.e_start[id] = n;
+                        g.e_first[id] = (uint8_t)b;
+                        g.e_alive[id] = 1;
+                        ord = order_append(ord, b);
+                    }
+                    g.out_edge[(u64)n * 4 + b] = id;
+                }
+                g.out_order[n] = ord;
+            }
+        }
+    }
+}
+
+// buildEdges (Graph.scala:349-365): from a node, follow the unique outgoing base until the next
+// terminal k-mer.  write == 0: measure (end node, length, in-degree); write == 1: emit the bases
+// 2 bits each into the pool at e_off.  One lane per edge; every step is one dependent table probe.
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_walk(Table<W> t, int k, GraphView g, const u32 *slot_node, int write, u64 max_steps,
+                                                u32 *err) {
+    for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < g.n_edges; e += (u64)gridDim.x * BLOCK) {
+        const u32 n = g.e_start[e];
+        const int b0 = g.e_first[e];
+        Kmer<W> cur = append_base(node_kmer<W>(g, n), b0, k);          // read.drop(1) :+ base  :353
+        u64 len = 1;
+        u32 acc = (u32)b0;                                              // builder += base        :352
+        const u64 off = write ? g.e_off[e] : 0;
+        u32 end = NONE;
+        for (u64 step = 0; step <= max_steps; step++) {
+            bool fwd;
+            i64 slot = table_find_either(t, cur, k, &fwd);
+            if (slot < 0) { *err = 1; break; }
+            const u32 aux = t.slots[slot].aux;
+            if (aux & AUX_TERMINAL) {                                   // nodeMap.contains(seq)  :355
+                end = slot_node[slot] + (fwd ? 0u : 1u);
+                break;
+            }
+            const u32 om = fwd ? ((aux >> 4) & 15u) : rev4(aux & 15u);  // outcoming(seq)         :356
+            if (__popc(om) != 1) { *err = 2; break; }                   // assert(out.size == 1)  :357
+            const int nb = __ffs(om) - 1;
+            if (write) {
+                acc |= (u32)nb << ((len & 3) * 2);
+                if ((len & 3) == 3) { g.pool[off + (len >> 2)] = (uint8_t)acc; acc = 0; }
+            }
+            len++;
+            cur = append_base(cur, nb, k);                              // seq.drop(1) :+ out(0)  :360
+        }
+        if (write) {
+            if (len & 3) g.pool[off + (len >> 2)] = (uint8_t)acc;
+        } else {
+            g.e_end[e] = end;
+            g.e_len[e] = len;
+            if (end != NONE) atomicAdd(&g.in_deg[end], 1u);             // end.inEdgeIds += id    :181
+            else *err = 3;
+        }
+    }
+}
+
+// byte offsets of the edge sequences in the pool (each edge starts on a byte boundary)
+__global__ __launch_bounds__(BLOCK) void k_reserve_pool(GraphView g, u64 first_edge, unsigned long long *cursor) {
+    __shared__ u32 lds4[BLOCK / 64];
+    __shared__ unsigned long long s_base;
+    const u64 n = g.n_edges - first_edge;
+    const u64 ngroups = (n + BLOCK - 1) / BLOCK;
+    for (u64 grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const u64 e = first_edge + grp * BLOCK + threadIdx.x;
+        // per-block totals stay < 2^32 for edges up to 16M bases each; longer ones reserve alone
+        u64 bytes = e < g.n_edges ? (g.e_len[e] + 3) / 4 : 0;
+        u32 small = bytes < (1u << 22) ? (u32)bytes : 0u;
+        u64 o = block_reserve(small, cursor, lds4, &s_base);
+        if (e < g.n_edges) g.e_off[e] = small == bytes ? o : atomicAdd(cursor, (unsigned long long)bytes);
+    }
+}
+
+// k-mer -> node id index (open addressing over node ids), for point queries on the graph
+template <int W> __global__ __launch_bounds__(BLOCK) void k_build_nidx(GraphView g) {
+    for (u64 n = (u64)blockIdx.x * BLOCK + threadIdx.x; n < g.n_nodes; n += (u64)gridDim.x * BLOCK) {
+        if (!g.node_alive[n]) continue;
+        u64 i = slot_hash(node_kmer<W>(g, n)) & g.nidx_mask;
+        while (atomicCAS(&g.nidx[i], NONE, (u32)n) != NONE) i = (i + 1) & g.nidx_mask;
+    }
+}
+template <int W> __device__ __forceinline__ u32 node_find(const GraphView &g, Kmer<W> x) {
+    u64 i = slot_hash(x) & g.nidx_mask;
+    for (u64 p = 0; p <= g.nidx_mask; p++) {
+        u32 n = g.nidx[i];
+        if (n == NONE) return NONE;
+        if (node_kmer<W>(g, n) == x) return n;
+        i = (i + 1) & g.nidx_mask;
+    }
+    return NONE;
+}
+
+// ---------------------------------------------------------------------------------------------
+// simplifyGraph (Graph.scala:211-230)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_in_single(GraphView g, u32 *in_single) {
+    for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < g.n_edges; e += (u64)gridDim.x * BLOCK)
+        if (g.e_alive[e] && g.in_deg[g.e_end[e]] == 1) in_single[g.e_end[e]] = (u32)e;
+}
+// 0 keep; 1 interior (1 in, 1 out, e1 != e2 : merged away, :222-226); 2 self-loop (e1 == e2, :220-221);
+// 3 isolated (:215-216)
+__global__ __launch_bounds__(BLOCK) void k_node_class(GraphView g, const u32 *in_single, uint8_t *cls) {
+    for (u64 n = (u64)blockIdx.x * BLOCK + threadIdx.x; n < g.n_nodes; n += (u64)gridDim.x * BLOCK) {
+        uint8_t c = 0;
+        if (g.node_alive[n]) {
+            const u32 o = g.out_order[n];
+            const int nout = order_count(o), nin = (int)g.in_deg[n];
+            if (nin == 0 && nout == 0) c = 3;
+            else if (nin == 1 && nout == 1) c = in_single[n] == g.out_edge[n * 4 + order_base(o, 0)] ? 2 : 1;
+        }
+        cls[n] = c;
+    }
+}
+// A chain = a live edge that leaves a kept node and enters an interior node, followed through
+// every interior node to the first non-interior end.  Sequential simplifyGraph produces exactly
+// one merged edge per chain (e1.seq ++ e2.seq, repeatedly) whatever the node order; chains of
+// interior nodes only (perfect cycles) vanish.  pass 0 counts, pass 1 writes.
+__global__ __launch_bounds__(BLOCK) void k_chain(GraphView g, const uint8_t *cls, int pass, u64 old_edges, u64 old_pool,
+                                                 unsigned long long *counters /* [0]=chains [1]=bytes */, u32 *merged_key) {
+    for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < old_edges; e += (u64)gridDim.x * BLOCK) {
+        if (!g.e_alive[e]) continue;
+        const u32 s = g.e_start[e];
+        if (cls[s] != 0 || cls[g.e_end[e]] != 1) continue;
+        u64 total = 0;
+        u32 cur = (u32)e, maxn = NONE;
+        for (u64 guard = 0; guard <= old_edges; guard++) {
+            total += g.e_len[cur];
+            const u32 v = g.e_end[cur];
+            if (cls[v] != 1) break;
+            if (maxn == NONE || node_less(g, maxn, v)) maxn = v;
+            cur = g.out_edge[(u64)v * 4 + order_base(g.out_order[v], 0)];
+        }
+        const u64 bytes = (total + 3) / 4;
+        if (pass == 0) {
+            atomicAdd(&counters[0], 1ull);
+            atomicAdd(&counters[1], (unsigned long long)bytes);
+            continue;
+        }
+        const u64 id = old_edges + atomicAdd(&counters[0], 1ull);
+        const u64 off = old_pool + atomicAdd(&counters[1], (unsigned long long)bytes);
+        // e1.seq ++ e2.seq ++ ...  (Graph.scala:225)
+        u64 w = 0;
+        u32 acc = 0;
+        cur = (u32)e;
+        for (u64 guard = 0; guard <= old_edges; guard++) {
+            const u64 so = g.e_off[cur], sl = g.e_len[cur];
+            for (u64 i = 0; i < sl; i++) {
+                acc |= (u32)pool_get(g.pool, so, i) << ((w & 3) * 2);
+                if ((w & 3) == 3) { g.pool[off + (w >> 2)] = (uint8_t)acc; acc = 0; }
+                w++;
+            }
+            g.e_alive[cur] = 0;                        // removeEdge(e1); removeEdge(e2)  :223-224
+            const u32 v = g.e_end[cur];
+            if (cls[v] != 1) break;
+            cur = g.out_edge[(u64)v * 4 + order_base(g.out_order[v], 0)];
+        }
+        if (w & 3) g.pool[off + (w >> 2)] = (uint8_t)acc;
+        g.e_start[id] = s;                             // addEdge(e1.start, e2.end, ...)   :225
+        g.e_end[id] = g.e_end[cur];
+        g.e_len[id] = total;
+        g.e_off[id] = off;
+        g.e_first[id] = g.e_first[e];
+        g.e_alive[id] = 1;
+        g.out_edge[(u64)s * 4 + g.e_first[e]] = (u32)id;
+        merged_key[(u64)s * 4 + g.e_first[e]] = maxn;
+    }
+}
+// Remove interior / self-loop / isolated nodes and whatever edges still hang off them (self-loops,
+// perfect cycles), and replay the out-edge insertion order at kept nodes: every merge step is
+// `outEdgeIds -= b` then `+= b` (removeEdge :192, addEdge :180), i.e. b moves to the end, and the
+// last step of a chain happens when its largest interior node (ascending k-mer order) is visited.
+__global__ __launch_bounds__(BLOCK) void k_simplify_finish(GraphView g, const uint8_t *cls, const u32 *merged_key) {
+    for (u64 n = (u64)blockIdx.x * BLOCK + threadIdx.x; n < g.n_nodes; n += (u64)gridDim.x * BLOCK) {
+        if (!g.node_alive[n]) continue;
+        const u32 o = g.out_order[n];
+        if (cls[n] != 0) {
+            for (int i = 0; i < order_count(o); i++) {
+                const int b = order_base(o, i);
+                const u32 e = g.out_edge[n * 4 + b];
+                if (e != NONE) g.e_alive[e] = 0;
+                g.out_edge[n * 4 + b] = NONE;
+            }
+            g.out_order[n] = 0;
+            g.in_deg[n] = 0;
+            g.node_alive[n] = 0;                       // removeNode :216,:227
+            continue;
+        }
+        u32 r = 0;
+        int mb[4], nm = 0;
+        for (int i = 0; i < order_count(o); i++) {
+            const int b = order_base(o, i);
+            if (merged_key[n * 4 + b] == NONE) r = order_append(r, b);
+            else mb[nm++] = b;
+        }
+        for (int i = 1; i < nm; i++)                   // insertion sort of <= 4 entries by chain key
+            for (int j = i; j > 0 && node_less(g, merged_key[n * 4 + mb[j]], merged_key[n * 4 + mb[j - 1]]); j--) {
+                int tmp = mb[j]; mb[j] = mb[j - 1]; mb[j - 1] = tmp;
+            }
+        for (int i = 0; i < nm; i++) r = order_append(r, mb[i]);
+        g.out_order[n] = r;
+    }
+}
+
+// Graph.removeBubbles (Graph.scala:125-149) — per node, on the out-edges in insertion order
+__global__ __launch_bounds__(BLOCK) void k_bubbles(GraphView g) {
+    for (u64 n = (u64)blockIdx.x * BLOCK + threadIdx.x; n < g.n_nodes; n += (u64)gridDim.x * BLOCK) {
+        if (!g.node_alive[n]) continue;
+        const u32 o = g.out_order[n];
+        const int cnt = order_count(o);
+        if (cnt < 2) continue;
+        u32 out[4];
+        bool rem[4] = {false, false, false, false};
+        for (int i = 0; i < cnt; i++) out[i] = g.out_edge[n * 4 + order_base(o, i)];
+        for (int i = 0; i < cnt; i++) {
+            if (rem[i]) continue;                                      // `if !toRemove(out(i))`  :142
+            for (int j = i + 1; j < cnt; j++) {
+                const u64 la = g.e_len[out[i]], lb = g.e_len[out[j]];
+                const u64 d = la > lb ? la - lb : lb - la, mx = la > lb ? la : lb;
+                if (g.e_end[out[i]] == g.e_end[out[j]] && d * 5 < mx) rem[j] = true;   // similar :121-123
+            }
+        }
+        u32 r = 0;
+        for (int i = 0; i < cnt; i++) {
+            const int b = order_base(o, i);
+            if (rem[i]) {                                              // removeEdge :191-195
+                g.e_alive[out[i]] = 0;
+                atomicSub(&g.in_deg[g.e_end[out[i]]], 1u);
+                g.out_edge[n * 4 + b] = NONE;
+            } else {
+                r = order_append(r, b);
+            }
+        }
+        g.out_order[n] = r;
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_remove_edges(GraphView g, const u64 *lo, const u64 *hi, const uint8_t *base, u64 n,
+                                                        unsigned long long *removed) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        Kmer<W> x;
+        if constexpr (W == 1) x = Kmer<1>{lo[i]};
+        else x = Kmer<2>{lo[i], hi[i]};
+        const u32 v = node_find<W>(g, x);
+        const int b = base[i] & 3;
+        if (v == NONE || !g.node_alive[v]) continue;
+        const u32 e = atomicExch(&g.out_edge[(u64)v * 4 + b], NONE);
+        if (e == NONE) continue;
+        g.e_alive[e] = 0;
+        atomicSub(&g.in_deg[g.e_end[e]], 1u);
+        u32 old = g.out_order[v], seen;
+        do {
+            seen = old;
+            old = atomicCAS(&g.out_order[v], seen, order_remove(seen, b));
+        } while (old != seen);
+        atomicAdd(removed, 1ull);
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_count_live(GraphView g, unsigned long long *out /* nodes, edges, len */) {
+    __shared__ unsigned long long s[3];
+    if (threadIdx.x < 3) s[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned long long a = 0, b = 0, c = 0;
+    const u64 tid = (u64)blockIdx.x * BLOCK + threadIdx.x, stride = (u64)gridDim.x * BLOCK;
+    for (u64 n = tid; n < g.n_nodes; n += stride) a += g.node_alive[n];
+    for (u64 e = tid; e < g.n_edges; e += stride) if (g.e_alive[e]) { b++; c += g.e_len[e]; }
+    if (a) atomicAdd(&s[0], a);
+    if (b) atomicAdd(&s[1], b);
+    if (c) atomicAdd(&s[2], c);
+    __syncthreads();
+    if (threadIdx.x < 3 && s[threadIdx.x]) atomicAdd(&out[threadIdx.x], s[threadIdx.x]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// components (Graph.scala:54-72) by min-label hooking + pointer jumping; retain (:161-165)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 cc_root(const u32 *parent, u32 v) {
+    u32 p = parent[v];
+    while (p != v) { v = p; p = parent[v]; }
+    return v;
+}
+__global__ __launch_bounds__(BLOCK) void k_cc_init(GraphView g, u32 *parent) {
+    for (u64 n = (u64)blockIdx.x * BLOCK + threadIdx.x; n < g.n_nodes; n += (u64)gridDim.x * BLOCK) parent[n] = (u32)n;
+}
+__global__ __launch_bounds__(BLOCK) void k_cc_hook(GraphView g, u32 *parent, u32 *changed) {
+    for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < g.n_edges; e += (u64)gridDim.x * BLOCK) {
+        if (!g.e_alive[e]) continue;
+        u32 ru = cc_root(parent, g.e_start[e]), rv = cc_root(parent, g.e_end[e]);
+        if (ru == rv) continue;
+        u32 hi = ru > rv ? ru : rv, lo = ru > rv ? rv : ru;
+        atomicMin(&parent[hi], lo);
+        *changed = 1;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_cc_compress(GraphView g, u32 *parent) {
+    for (u64 n = (u64)blockIdx.x * BLOCK + threadIdx.x; n < g.n_nodes; n += (u64)gridDim.x * BLOCK) parent[n] = cc_root(parent, (u32)n);
+}
+__global__ __launch_bounds__(BLOCK) void k_cc_sizes(GraphView g, const u32 *parent, u32 *size, unsigned long long *ncomp) {
+    for (u64 n = (u64)blockIdx.x * BLOCK + threadIdx.x; n < g.n_nodes; n += (u64)gridDim.x * BLOCK) {
+        if (!g.node_alive[n]) continue;
+        atomicAdd(&size[parent[n]], 1u);
+        if (parent[n] == n) atomicAdd(ncomp, 1ull);
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_cc_max(GraphView g, const u32 *size, u32 *best) {
+    for (u64 n = (u64)blockIdx.x * BLOCK + threadIdx.x; n < g.n_nodes; n += (u64)gridDim.x * BLOCK)
+        if (g.node_alive[n] && size[n]) atomicMax(best, size[n]);
+}
+// among the components of maximal size pick the one holding the smallest k-mer: stage 0 min hi,
+// stage 1 min lo among those, stage 2 record its root
+__global__ __launch_bounds__(BLOCK) void k_cc_pick(GraphView g, const u32 *parent, const u32 *size, u32 best, int stage,
+                                                   unsigned long long *mins /* hi, lo */, u32 *winner) {
+    for (u64 n = (u64)blockIdx.x * BLOCK + threadIdx.x; n < g.n_nodes; n += (u64)gridDim.x * BLOCK) {
+        if (!g.node_alive[n] || size[parent[n]] != best) continue;
+        if (stage == 0) atomicMin(&mins[0], (unsigned long long)g.node_hi[n]);
+        else if (stage == 1) { if (g.node_hi[n] == mins[0]) atomicMin(&mins[1], (unsigned long long)g.node_lo[n]); }
+        else if (g.node_hi[n] == mins[0] && g.node_lo[n] == mins[1]) *winner = parent[n];
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_retain(GraphView g, const u32 *parent, u32 winner) {
+    const u64 tid = (u64)blockIdx.x * BLOCK + threadIdx.x, stride = (u64)gridDim.x * BLOCK;
+    for (u64 e = tid; e < g.n_edges; e += stride)
+        if (g.e_alive[e] && !(parent[g.e_start[e]] == winner && parent[g.e_end[e]] == winner)) g.e_alive[e] = 0;
+    for (u64 n = tid; n < g.n_nodes; n += stride)
+        if (g.node_alive[n] && parent[n] != winner) {
+            g.node_alive[n] = 0;
+            g.out_order[n] = 0;
+            g.in_deg[n] = 0;
+            for (int b = 0; b < 4; b++) g.out_edge[n * 4 + b] = NONE;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// export
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_export_nodes(GraphView g, u64 *lo, u64 *hi, unsigned long long *cursor) {
+    __shared__ u32 lds4[BLOCK / 64];
+    __shared__ unsigned long long s_base;
+    const u64 ngroups = (g.n_nodes + BLOCK - 1) / BLOCK;
+    for (u64 grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const u64 n = grp * BLOCK + threadIdx.x;
+        const bool live = n < g.n_nodes && g.node_alive[n];
+        u64 o = block_reserve(live ? 1u : 0u, cursor, lds4, &s_base);
+        if (live) { lo[o] = g.node_lo[n]; hi[o] = g.node_hi[n]; }
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_export_edges(GraphView g, u64 *slo, u64 *shi, u64 *elo, u64 *ehi, i64 *len, i64 *off,
+                                                        uint8_t *seq, unsigned long long *cursors /* [0] edges [1] bytes */) {
+    __shared__ u32 lds4[BLOCK / 64];
+    __shared__ unsigned long long s_base;
+    const u64 ngroups = (g.n_edges + BLOCK - 1) / BLOCK;
+    for (u64 grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const u64 e = grp * BLOCK + threadIdx.x;
+        const bool live = e < g.n_edges && g.e_alive[e];
+        u64 o = block_reserve(live ? 1u : 0u, &cursors[0], lds4, &s_base);
+        if (!live) continue;
+        const u64 bytes = (g.e_len[e] + 3) / 4;
+        const u64 so = atomicAdd(&cursors[1], (unsigned long long)bytes);
+        const u32 s = g.e_start[e], t = g.e_end[e];
+        slo[o] = g.node_lo[s]; shi[o] = g.node_hi[s];
+        elo[o] = g.node_lo[t]; ehi[o] = g.node_hi[t];
+        len[o] = (i64)g.e_len[e];
+        off[o] = (i64)so;
+        const u64 src = g.e_off[e];
+        for (u64 i = 0; i < bytes; i++) seq[so + i] = g.pool[src + i];
+    }
+}
+template <int W> __global__ void k_out_order(GraphView g, u64 lo, u64 hi, int *out5) {
+    Kmer<W> x;
+    if constexpr (W == 1) x = Kmer<1>{lo};
+    else x = Kmer<2>{lo, hi};
+    const u32 v = node_find<W>(g, x);
+    if (v == NONE || !g.node_alive[v]) { out5[0] = -1; return; }
+    const u32 o = g.out_order[v];
+    out5[0] = order_count(o);
+    for (int i = 0; i < order_count(o); i++) out5[1 + i] = order_base(o, i);
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+static inline int ggrid(const gk_ctx *ctx, u64 items) {
+    u64 blocks = (items + BLOCK - 1) / BLOCK;
+    if (blocks < 1) blocks = 1;
+    return (int)std::min<u64>(blocks, (u64)ctx->cu_count * 8);
+}
+
+template <class T> static hipError_t dev_grow(T **p, u64 old_n, u64 new_n, hipStream_t st) {
+    T *np_ = nullptr;
+    hipError_t e = hipMalloc((void **)&np_, std::max<u64>(new_n, 1) * sizeof(T));
+    if (e != hipSuccess) return e;
+    if (*p && old_n) e = hipMemcpyAsync(np_, *p, old_n * sizeof(T), hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (*p) (void)hipFree(*p);
+    *p = np_;
+    return e;
+}
+
+static void graph_free_arrays(gk_graph *g) {
+    GraphView &v = g->v;
+    void *ptrs[] = {v.node_lo, v.node_hi, v.node_alive, v.out_edge, v.out_order, v.in_deg, v.e_start, v.e_end,
+                    v.e_len, v.e_off, v.e_alive, v.e_first, v.pool, v.nidx};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    v = GraphView{};
+}
+
+static int graph_alloc_nodes(gk_graph *g, u64 n) {
+    gk_ctx *ctx = g->ctx;
+    GraphView &v = g->v;
+    const u64 c = std::max<u64>(n, 1);
+    GK_HIP(ctx, hipMalloc((void **)&v.node_lo, c * 8));
+    GK_HIP(ctx, hipMalloc((void **)&v.node_hi, c * 8));
+    GK_HIP(ctx, hipMalloc((void **)&v.node_alive, c));
+    GK_HIP(ctx, hipMalloc((void **)&v.out_edge, c * 16));
+    GK_HIP(ctx, hipMalloc((void **)&v.out_order, c * 4));
+    GK_HIP(ctx, hipMalloc((void **)&v.in_deg, c * 4));
+    GK_HIP(ctx, hipMemsetAsync(v.node_alive, 0, c, ctx->stream));
+    GK_HIP(ctx, hipMemsetAsync(v.in_deg, 0, c * 4, ctx->stream));
+    GK_HIP(ctx, hipMemsetAsync(v.out_order, 0, c * 4, ctx->stream));
+    GK_HIP(ctx, hipMemsetAsync(v.out_edge, 0xff, c * 16, ctx->stream));
+    v.n_nodes = n;
+    g->node_cap = c;
+    return GK_OK;
+}
+static int graph_alloc_edges(gk_graph *g, u64 n) {
+    gk_ctx *ctx = g->ctx;
+    GraphView &v = g->v;
+    const u64 c = std::max<u64>(n, 1);
+    GK_HIP(ctx, hipMalloc((void **)&v.e_start, c * 4));
+    GK_HIP(ctx, hipMalloc((void **)&v.e_end, c * 4));
+    GK_HIP(ctx, hipMalloc((void **)&v.e_len, c * 8));
+    GK_HIP(ctx, hipMalloc((void **)&v.e_off, c * 8));
+    GK_HIP(ctx, hipMalloc((void **)&v.e_alive, c));
+    GK_HIP(ctx, hipMalloc((void **)&v.e_first, c));
+    GK_HIP(ctx, hipMemsetAsync(v.e_alive, 0, c, ctx->stream));
+    v.n_edges = n;
+    g->edge_cap = c;
+    return GK_OK;
+}
+static int graph_grow_edges(gk_graph *g, u64 new_n) {
+    gk_ctx *ctx = g->ctx;
+    GraphView &v = g->v;
+    if (new_n <= g->edge_cap) { return GK_OK; }
+    const u64 old = v.n_edges;
+    GK_HIP(ctx, dev_grow(&v.e_start, old, new_n, ctx->stream));
+    GK_HIP(ctx, dev_grow(&v.e_end, old, new_n, ctx->stream));
+    GK_HIP(ctx, dev_grow(&v.e_len, old, new_n, ctx->stream));
+    GK_HIP(ctx, dev_grow(&v.e_off, old, new_n, ctx->stream));
+    GK_HIP(ctx, dev_grow(&v.e_alive, old, new_n, ctx->stream));
+    GK_HIP(ctx, dev_grow(&v.e_first, old, new_n, ctx->stream));
+    GK_HIP(ctx, hipMemsetAsync(v.e_alive + old, 0, new_n - old, ctx->stream));
+    g->edge_cap = new_n;
+    return GK_OK;
+}
+
+static int graph_refresh_counts(gk_graph *g) {
+    gk_ctx *ctx = g->ctx;
+    unsigned long long *d = nullptr, h[3] = {0, 0, 0};
+    GK_HIP(ctx, hipMalloc((void **)&d, 24));
+    hipError_t e = hipMemsetAsync(d, 0, 24, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_count_live, dim3(ggrid(ctx, std::max(g->v.n_nodes, g->v.n_edges))), dim3(BLOCK), 0, ctx->stream, g->v, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, 24, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return hip_fail(ctx, e, "graph_refresh_counts");
+    g->live_nodes = h[0]; g->live_edges = h[1]; g->live_len = h[2];
+    return GK_OK;
+}
+
+static int graph_build_index(gk_graph *g) {
+    gk_ctx *ctx = g->ctx;
+    GraphView &v = g->v;
+    if (v.nidx) { GK_HIP(ctx, hipFree(v.nidx)); v.nidx = nullptr; }
+    const u64 cap = pow2ceil(std::max<u64>(16, 2 * v.n_nodes + 2));
+    GK_HIP(ctx, hipMalloc((void **)&v.nidx, cap * 4));
+    GK_HIP(ctx, hipMemsetAsync(v.nidx, 0xff, cap * 4, ctx->stream));
+    v.nidx_mask = cap - 1;
+    if (v.n_nodes) {
+        if (g->W == 1) hipLaunchKernelGGL(k_build_nidx<1>, dim3(ggrid(ctx, v.n_nodes)), dim3(BLOCK), 0, ctx->stream, v);
+        else hipLaunchKernelGGL(k_build_nidx<2>, dim3(ggrid(ctx, v.n_nodes)), dim3(BLOCK), 0, ctx->stream, v);
+        GK_HIP(ctx, hipGetLastError());
+    }
+    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GK_OK;
+}
+
+template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
+    gk_ctx *ctx = m->ctx;
+    Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->capacity - 1};
+    const int k = m->k;
+    unsigned long long *d_cnt = nullptr;     // [0] terminals [1] cursor [2] edges [3] ecursor [4] pool cursor
+    u32 *d_err = nullptr, *slot_node = nullptr;
+    u64 *tslots = nullptr;
+    int rc = GK_OK;
+    hipError_t e = hipMalloc((void **)&d_cnt, 8 * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_err, 4);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, 64, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_err, 0, 4, ctx->stream);
+    unsigned long long h_cnt[8] = {0};
+    u32 h_err = 0;
+    auto done = [&](int code) {
+        if (d_cnt) (void)hipFree(d_cnt);
+        if (d_err) (void)hipFree(d_err);
+        if (slot_node) (void)hipFree(slot_node);
+        if (tslots) (void)hipFree(tslots);
+        return code;
+    };
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: alloc"));
+    // 1. degree classification of every live key
+    hipLaunchKernelGGL(k_classify<W>, dim3(ggrid(ctx, m->capacity)), dim3(BLOCK), 0, ctx->stream, t, k, &d_cnt[0]);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: classify"));
+    const u64 nT = h_cnt[0];
+    if (2 * nT >= (u64)NONE) return done(fail(ctx, GK_E_CAPACITY, "more than 2^32 graph nodes"));
+    // 2. terminal slots -> nodes (both strands) and edge stubs
+    e = hipMalloc((void **)&tslots, std::max<u64>(nT, 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&slot_node, m->capacity * 4);
+    if (e == hipSuccess) e = hipMemsetAsync(slot_node, 0xff, m->capacity * 4, ctx->stream);
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: alloc nodes"));
+    hipLaunchKernelGGL(k_collect_terminals<W>, dim3(ggrid(ctx, m->capacity)), dim3(BLOCK), 0, ctx->stream, t, k, tslots, &d_cnt[1], &d_cnt[2]);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 24, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: collect"));
+    if (h_cnt[1] != nT) return done(fail(ctx, GK_E_STATE, "terminal count mismatch"));
+    const u64 nE = h_cnt[2];
+    if (nE >= (u64)NONE) return done(fail(ctx, GK_E_CAPACITY, "more than 2^32 graph edges"));
+    if ((rc = graph_alloc_nodes(g, 2 * nT)) != GK_OK) return done(rc);
+    if ((rc = graph_alloc_edges(g, nE)) != GK_OK) return done(rc);
+    g->v.k = k;
+    if (nT) {
+        hipLaunchKernelGGL(k_make_nodes<W>, dim3(ggrid(ctx, nT)), dim3(BLOCK), 0, ctx->stream, t, k, tslots, nT, g->v, slot_node, &d_cnt[3]);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 32, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: make_nodes"));
+        // every edge slot the walk will visit must have been written by k_make_nodes
+        if (h_cnt[3] != nE) return done(fail(ctx, GK_E_STATE, "edge stub count mismatch: " + std::to_string(h_cnt[3]) + " vs " + std::to_string(nE)));
+    }
+    // 3. walks: measure, reserve the sequence pool, emit
+    if (nE) {
+        hipLaunchKernelGGL(k_walk<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node, 0, m->capacity + 1, d_err);
+        e = hipGetLastError();
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_reserve_pool, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, g->v, (u64)0, &d_cnt[4]);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 40, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: walk"));
+        if (h_err) return done(fail(ctx, GK_E_STATE, "unitig walk failed (code " + std::to_string(h_err) +
+                                    "): the table changed since classification or is inconsistent"));
+        g->pool_used = h_cnt[4];
+        g->pool_cap = std::max<u64>(g->pool_used, 1);
+        e = hipMalloc((void **)&g->v.pool, g->pool_cap);
+        if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: pool"));
+        hipLaunchKernelGGL(k_walk<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node, 1, m->capacity + 1, d_err);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: emit"));
+    } else {
+        e = hipMalloc((void **)&g->v.pool, 1);
+        if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: pool"));
+        g->pool_cap = 1;
+    }
+    if ((rc = graph_build_index(g)) != GK_OK) return done(rc);
+    return done(graph_refresh_counts(g));
+}
+
+static int check_graph(const gk_graph *g) {
+    if (!g || !g->ctx) return fail(nullptr, GK_E_INVALID, "null graph handle");
+    hipError_t e = hipSetDevice(g->ctx->device);
+    if (e != hipSuccess) return hip_fail(g->ctx, e, "hipSetDevice");
+    return GK_OK;
+}
+
+extern "C" {
+
+int gk_graph_build(gk_map *m, gk_graph **out) {
+    if (!m || !m->ctx) return fail(nullptr, GK_E_INVALID, "null map handle");
+    if (!out) return fail(m->ctx, GK_E_INVALID, "gk_graph_build: out is NULL");
+    *out = nullptr;
+    GK_HIP(m->ctx, hipSetDevice(m->ctx->device));
+    gk_graph *g = new gk_graph();
+    g->ctx = m->ctx;
+    g->k = m->k;
+    g->W = m->W;
+    int rc = m->W == 1 ? graph_build_impl<1>(m, g) : graph_build_impl<2>(m, g);
+    if (rc != GK_OK) {
+        graph_free_arrays(g);
+        delete g;
+        return rc;
+    }
+    *out = g;
+    return GK_OK;
+}
+
+void gk_graph_destroy(gk_graph *g) {
+    if (!g) return;
+    (void)hipSetDevice(g->ctx->device);
+    (void)hipStreamSynchronize(g->ctx->stream);
+    graph_free_arrays(g);
+    delete g;
+}
+
+int gk_graph_counts(gk_graph *g, uint64_t *nodes, uint64_t *edges, uint64_t *total_edge_len) {
+    if (int rc = check_graph(g)) return rc;
+    if (nodes) *nodes = g->live_nodes;
+    if (edges) *edges = g->live_edges;
+    if (total_edge_len) *total_edge_len = g->live_len;
+    return GK_OK;
+}
+
+int gk_graph_simplify(gk_graph *g) {
+    if (int rc = check_graph(g)) return rc;
+    gk_ctx *ctx = g->ctx;
+    GraphView &v = g->v;
+    if (v.n_nodes == 0) return GK_OK;
+    u32 *in_single = nullptr, *merged_key = nullptr;
+    uint8_t *cls = nullptr;
+    unsigned long long *d_cnt = nullptr, h_cnt[2] = {0, 0};
+    auto done = [&](int code) {
+        if (in_single) (void)hipFree(in_single);
+        if (merged_key) (void)hipFree(merged_key);
+        if (cls) (void)hipFree(cls);
+        if (d_cnt) (void)hipFree(d_cnt);
+        return code;
+    };
+    hipError_t e = hipMalloc((void **)&in_single, v.n_nodes * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&merged_key, v.n_nodes * 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&cls, v.n_nodes);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_cnt, 16);
+    if (e == hipSuccess) e = hipMemsetAsync(in_single, 0xff, v.n_nodes * 4, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(merged_key, 0xff, v.n_nodes * 16, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, 16, ctx->stream);
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_simplify: alloc"));
+    const int gn = ggrid(ctx, v.n_nodes), ge = ggrid(ctx, std::max<u64>(v.n_edges, 1));
+    hipLaunchKernelGGL(k_in_single, dim3(ge), dim3(BLOCK), 0, ctx->stream, v, in_single);
+    hipLaunchKernelGGL(k_node_class, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, in_single, cls);
+    const u64 old_edges = v.n_edges, old_pool = g->pool_used;
+    hipLaunchKernelGGL(k_chain, dim3(ge), dim3(BLOCK), 0, ctx->stream, v, cls, 0, old_edges, old_pool, d_cnt, merged_key);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 16, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_simplify: count"));
+    if (h_cnt[0]) {
+        if (old_edges + h_cnt[0] >= (u64)NONE) return done(fail(ctx, GK_E_CAPACITY, "more than 2^32 graph edges"));
+        if (int rc = graph_grow_edges(g, old_edges + h_cnt[0])) return done(rc);
+        if (old_pool + h_cnt[1] > g->pool_cap) {
+            e = dev_grow(&v.pool, old_pool, old_pool + h_cnt[1], ctx->stream);
+            if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_simplify: pool"));
+            g->pool_cap = old_pool + h_cnt[1];
+        }
+        e = hipMemsetAsync(d_cnt, 0, 16, ctx->stream);
+        if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_simplify"));
+        hipLaunchKernelGGL(k_chain, dim3(ge), dim3(BLOCK), 0, ctx->stream, v, cls, 1, old_edges, old_pool, d_cnt, merged_key);
+        v.n_edges = old_edges + h_cnt[0];
+        g->pool_used = old_pool + h_cnt[1];
+    }
+    hipLaunchKernelGGL(k_simplify_finish, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, cls, merged_key);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_simplify: finish"));
+    return done(graph_refresh_counts(g));
+}
+
+int gk_graph_remove_bubbles(gk_graph *g) {
+    if (int rc = check_graph(g)) return rc;
+    gk_ctx *ctx = g->ctx;
+    if (g->v.n_nodes == 0) return GK_OK;
+    hipLaunchKernelGGL(k_bubbles, dim3(ggrid(ctx, g->v.n_nodes)), dim3(BLOCK), 0, ctx->stream, g->v);
+    GK_HIP(ctx, hipGetLastError());
+    return graph_refresh_counts(g);
+}
+
+int gk_graph_remove_edges(gk_graph *g, const uint64_t *start_lo, const uint64_t *start_hi, const uint8_t *base, uint64_t n,
+                          uint64_t *removed) {
+    if (int rc = check_graph(g)) return rc;
+    gk_ctx *ctx = g->ctx;
+    if (removed) *removed = 0;
+    if (n == 0) return GK_OK;
+    if (!start_lo || !base || (g->W == 2 && !start_hi)) return fail(ctx, GK_E_INVALID, "null argument");
+    u64 *d_lo = nullptr, *d_hi = nullptr;
+    uint8_t *d_b = nullptr;
+    unsigned long long *d_rm = nullptr, h_rm = 0;
+    hipError_t e = hipMalloc((void **)&d_lo, n * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_hi, n * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_b, n);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_rm, 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_lo, start_lo, n * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = start_hi ? hipMemcpyAsync(d_hi, start_hi, n * 8, hipMemcpyHostToDevice, ctx->stream)
+                                      : hipMemsetAsync(d_hi, 0, n * 8, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_b, base, n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_rm, 0, 8, ctx->stream);
+    if (e == hipSuccess) {
+        if (g->W == 1) hipLaunchKernelGGL(k_remove_edges<1>, dim3(ggrid(ctx, n)), dim3(BLOCK), 0, ctx->stream, g->v, d_lo, d_hi, d_b, n, d_rm);
+        else hipLaunchKernelGGL(k_remove_edges<2>, dim3(ggrid(ctx, n)), dim3(BLOCK), 0, ctx->stream, g->v, d_lo, d_hi, d_b, n, d_rm);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_rm, d_rm, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_lo); (void)hipFree(d_hi); (void)hipFree(d_b); (void)hipFree(d_rm);
+    if (e != hipSuccess) return hip_fail(ctx, e, "gk_graph_remove_edges");
+    if (removed) *removed = h_rm;
+    return graph_refresh_counts(g);
+}
+
+int gk_graph_retain_largest(gk_graph *g, uint64_t *kept_nodes, uint64_t *components) {
+    if (int rc = check_graph(g)) return rc;
+    gk_ctx *ctx = g->ctx;
+    GraphView &v = g->v;
+    if (kept_nodes) *kept_nodes = 0;
+    if (components) *components = 0;
+    if (g->live_nodes == 0) return GK_OK;
+    u32 *parent = nullptr, *size = nullptr, *d_u32 = nullptr;       // d_u32: [0] changed [1] best [2] winner
+    unsigned long long *d_u64 = nullptr;                            // [0] ncomp [1] min hi [2] min lo
+    auto done = [&](int code) {
+        if (parent) (void)hipFree(parent);
+        if (size) (void)hipFree(size);
+        if (d_u32) (void)hipFree(d_u32);
+        if (d_u64) (void)hipFree(d_u64);
+        return code;
+    };
+    hipError_t e = hipMalloc((void **)&parent, v.n_nodes * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&size, v.n_nodes * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_u32, 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_u64, 24);
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_retain_largest: alloc"));
+    const int gn = ggrid(ctx, v.n_nodes), ge = ggrid(ctx, std::max<u64>(v.n_edges, 1));
+    hipLaunchKernelGGL(k_cc_init, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, parent);
+    for (int it = 0; it < 100000; it++) {
+        u32 changed = 0;
+        e = hipMemsetAsync(d_u32, 0, 4, ctx->stream);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(k_cc_hook, dim3(ge), dim3(BLOCK), 0, ctx->stream, v, parent, &d_u32[0]);
+        hipLaunchKernelGGL(k_cc_compress, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, parent);
+        e = hipMemcpyAsync(&changed, d_u32, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess || !changed) break;
+    }
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_retain_largest: cc"));
+    unsigned long long h64[3] = {0, ~0ull, ~0ull};
+    u32 h32[3] = {0, 0, NONE};
+    e = hipMemsetAsync(size, 0, v.n_nodes * 4, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_u64, h64, 24, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_u32, h32, 12, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_retain_largest"));
+    hipLaunchKernelGGL(k_cc_sizes, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, parent, size, &d_u64[0]);
+    hipLaunchKernelGGL(k_cc_max, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, size, &d_u32[1]);
+    e = hipMemcpyAsync(h32, d_u32, 12, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_retain_largest: sizes"));
+    const u32 best = h32[1];
+    for (int stage = 0; stage < 3; stage++)
+        hipLaunchKernelGGL(k_cc_pick, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, parent, size, best, stage, &d_u64[1], &d_u32[2]);
+    e = hipMemcpyAsync(h32, d_u32, 12, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h64, d_u64, 24, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_retain_largest: pick"));
+    if (h32[2] == NONE) return done(fail(ctx, GK_E_STATE, "no component selected"));
+    hipLaunchKernelGGL(k_retain, dim3(ggrid(ctx, std::max(v.n_nodes, v.n_edges))), dim3(BLOCK), 0, ctx->stream, v, parent, h32[2]);
+    e = hipGetLastError();
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_retain_largest: retain"));
+    if (components) *components = h64[0];
+    int rc = graph_refresh_counts(g);
+    if (rc == GK_OK && kept_nodes) *kept_nodes = g->live_nodes;
+    return done(rc);
+}
+
+int gk_graph_export_nodes(gk_graph *g, uint64_t *lo, uint64_t *hi, uint64_t cap, uint64_t *n) {
+    if (int rc = check_graph(g)) return rc;
+    gk_ctx *ctx = g->ctx;
+    if (n) *n = g->live_nodes;
+    if (g->live_nodes > cap) return fail(ctx, GK_E_CAPACITY, "node export buffer too small: need " + std::to_string(g->live_nodes));
+    if (g->live_nodes == 0) return GK_OK;
+    if (!lo) return fail(ctx, GK_E_INVALID, "null export buffer");
+    const u64 cnt = g->live_nodes;
+    u64 *d_lo = nullptr, *d_hi = nullptr;
+    unsigned long long *d_cur = nullptr;
+    hipError_t e = hipMalloc((void **)&d_lo, cnt * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_hi, cnt * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_cur, 8);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cur, 0, 8, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_export_nodes, dim3(ggrid(ctx, g->v.n_nodes)), dim3(BLOCK), 0, ctx->stream, g->v, d_lo, d_hi, d_cur);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(lo, d_lo, cnt * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && hi) e = hipMemcpyAsync(hi, d_hi, cnt * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_lo); (void)hipFree(d_hi); (void)hipFree(d_cur);
+    if (e != hipSuccess) return hip_fail(ctx, e, "gk_graph_export_nodes");
+    return GK_OK;
+}
+
+int gk_graph_export_edges(gk_graph *g, uint64_t *start_lo, uint64_t *start_hi, uint64_t *end_lo, uint64_t *end_hi,
+                          int64_t *len, int64_t *seq_off, uint64_t cap, uint64_t *n,
+                          uint8_t *seq2bit, uint64_t seq_cap, uint64_t *seq_bytes) {
+    if (int rc = check_graph(g)) return rc;
+    gk_ctx *ctx = g->ctx;
+    if (n) *n = g->live_edges;
+    // upper bound on packed bytes: every live edge rounds up to a byte
+    const u64 max_bytes = (g->live_len + 3 * g->live_edges) / 4 + 1;
+    if (seq_bytes) *seq_bytes = max_bytes;
+    if (g->live_edges > cap) return fail(ctx, GK_E_CAPACITY, "edge export buffer too small: need " + std::to_string(g->live_edges));
+    if (g->live_edges == 0) { if (seq_bytes) *seq_bytes = 0; return GK_OK; }
+    if (seq_cap < max_bytes) return fail(ctx, GK_E_CAPACITY, "sequence buffer too small: need " + std::to_string(max_bytes));
+    if (!start_lo || !end_lo || !len || !seq_off || !seq2bit) return fail(ctx, GK_E_INVALID, "null export buffer");
+    const u64 cnt = g->live_edges;
+    u64 *d_k[4] = {nullptr, nullptr, nullptr, nullptr};
+    i64 *d_len = nullptr, *d_off = nullptr;
+    uint8_t *d_seq = nullptr;
+    unsigned long long *d_cur = nullptr, h_cur[2] = {0, 0};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipMalloc((void **)&d_k[i], cnt * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_len, cnt * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_off, cnt * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_seq, max_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_cur, 16);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cur, 0, 16, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_export_edges, dim3(ggrid(ctx, g->v.n_edges)), dim3(BLOCK), 0, ctx->stream, g->v, d_k[0], d_k[1], d_k[2],
+                           d_k[3], d_len, d_off, d_seq, d_cur);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h_cur, d_cur, 16, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(start_lo, d_k[0], cnt * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && start_hi) e = hipMemcpyAsync(start_hi, d_k[1], cnt * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(end_lo, d_k[2], cnt * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && end_hi) e = hipMemcpyAsync(end_hi, d_k[3], cnt * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(len, d_len, cnt * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(seq_off, d_off, cnt * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && h_cur[1]) e = hipMemcpy(seq2bit, d_seq, h_cur[1], hipMemcpyDeviceToHost);
+    for (int i = 0; i < 4; i++) (void)hipFree(d_k[i]);
+    (void)hipFree(d_len); (void)hipFree(d_off); (void)hipFree(d_seq); (void)hipFree(d_cur);
+    if (e != hipSuccess) return hip_fail(ctx, e, "gk_graph_export_edges");
+    if (h_cur[0] != cnt) return fail(ctx, GK_E_STATE, "edge export count mismatch");
+    if (seq_bytes) *seq_bytes = h_cur[1];
+    return GK_OK;
+}
+
+int gk_graph_out_order(gk_graph *g, uint64_t lo, uint64_t hi, int *bases4, int *count) {
+    if (int rc = check_graph(g)) return rc;
+    gk_ctx *ctx = g->ctx;
+    if (!bases4 || !count) return fail(ctx, GK_E_INVALID, "null argument");
+    int *d = nullptr, h[5] = {-1, 0, 0, 0, 0};
+    GK_HIP(ctx, hipMalloc((void **)&d, 20));
+    if (g->W == 1) hipLaunchKernelGGL(k_out_order<1>, dim3(1), dim3(1), 0, ctx->stream, g->v, lo, hi, d);
+    else hipLaunchKernelGGL(k_out_order<2>, dim3(1), dim3(1), 0, ctx->stream, g->v, lo, hi, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, 20, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return hip_fail(ctx, e, "gk_graph_out_order");
+    *count = h[0];
+    for (int i = 0; i < 4; i++) bases4[i] = i < h[0] ? h[1 + i] : 0;
+    return GK_OK;
+}
+
+}  // extern "C"

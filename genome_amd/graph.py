@@ -1,0 +1,116 @@
+"""Host-side mirror of `object Graph` / `trait Graph` / `MapGraph` (S/data/graph/Graph.scala) over
+the HIP library: buildGraph, simplifyGraph, removeBubbles, removeEdge, components+retain, and the
+canonical serialisation used for parity.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from . import dna
+from .dnamap import HipDNAMap
+from .partitioned import PartitionedDNAMap
+
+
+class HipGraph:
+    """A MapGraph resident in HBM."""
+
+    def __init__(self, ctx, k: int, handle):
+        self.ctx, self.k, self.h = ctx, k, handle
+
+    def close(self):
+        if self.h:
+            L.lib().gk_graph_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def counts(self):
+        n, e, ln = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        L.check(L.lib().gk_graph_counts(self.h, C.byref(n), C.byref(e), C.byref(ln)), self.ctx.h)
+        return n.value, e.value, ln.value
+
+    def simplifyGraph(self):                       # Graph.scala:211-230
+        L.check(L.lib().gk_graph_simplify(self.h), self.ctx.h)
+
+    def removeBubbles(self):                       # Graph.scala:125-149
+        L.check(L.lib().gk_graph_remove_bubbles(self.h), self.ctx.h)
+
+    def removeEdges(self, edges) -> int:           # Graph.scala:191-195, batched: [(start k-mer str, first base char)]
+        lo, hi = dna.pack_many([s for s, _ in edges])
+        base = np.array([dna.BASES.index(b) for _, b in edges], np.uint8)
+        removed = C.c_uint64()
+        L.check(L.lib().gk_graph_remove_edges(self.h, L.ptr(lo, C.c_uint64), L.ptr(hi, C.c_uint64), L.ptr(base, C.c_uint8),
+                                              len(base), C.byref(removed)), self.ctx.h)
+        return removed.value
+
+    def retainLargest(self):                       # Graph.scala:54-72,161-165; GraphBuilder.scala:52-54
+        kept, comps = C.c_uint64(), C.c_uint64()
+        L.check(L.lib().gk_graph_retain_largest(self.h, C.byref(kept), C.byref(comps)), self.ctx.h)
+        return kept.value, comps.value
+
+    def getNodes(self):
+        n = self.counts()[0]
+        lo, hi = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        got = C.c_uint64()
+        L.check(L.lib().gk_graph_export_nodes(self.h, L.ptr(lo, C.c_uint64), L.ptr(hi, C.c_uint64), n, C.byref(got)), self.ctx.h)
+        return lo, hi
+
+    def getEdges(self):
+        _, ne, ln = self.counts()
+        a = {key: np.zeros(ne, np.uint64) for key in ("slo", "shi", "elo", "ehi")}
+        length, off = np.zeros(ne, np.int64), np.zeros(ne, np.int64)
+        cap = (ln + 3 * ne) // 4 + 1
+        seq = np.zeros(cap, np.uint8)
+        got, used = C.c_uint64(), C.c_uint64()
+        L.check(L.lib().gk_graph_export_edges(self.h, L.ptr(a["slo"], C.c_uint64), L.ptr(a["shi"], C.c_uint64),
+                                              L.ptr(a["elo"], C.c_uint64), L.ptr(a["ehi"], C.c_uint64),
+                                              L.ptr(length, C.c_int64), L.ptr(off, C.c_int64), ne, C.byref(got),
+                                              L.ptr(seq, C.c_uint8), cap, C.byref(used)), self.ctx.h)
+        a.update(len=length, off=off, seq=seq[:used.value])
+        return a
+
+    def out_order(self, kmer: str):
+        lo, hi = dna.pack(kmer)
+        arr, cnt = (C.c_int * 4)(), C.c_int()
+        L.check(L.lib().gk_graph_out_order(self.h, lo, hi, arr, C.byref(cnt)), self.ctx.h)
+        return None if cnt.value < 0 else [arr[i] for i in range(cnt.value)]
+
+    def canonical(self):
+        """(sorted node strings, edges (start, end, seq) sorted by (start k-mer, first base))."""
+        k = self.k
+        lo, hi = self.getNodes()
+        order = np.lexsort((lo, hi))
+        nodes = [dna.unpack(int(lo[i]), int(hi[i]), k) for i in order]
+        e = self.getEdges()
+        first = np.array([(int(e["seq"][o]) & 3) if ln else 0 for o, ln in zip(e["off"], e["len"])], np.int64)
+        order = np.lexsort((first, e["slo"], e["shi"]))
+        edges = []
+        for i in order:
+            o, ln = int(e["off"][i]), int(e["len"][i])
+            edges.append((dna.unpack(int(e["slo"][i]), int(e["shi"][i]), k),
+                          dna.unpack(int(e["elo"][i]), int(e["ehi"][i]), k),
+                          dna.unpack_2bit(e["seq"][o:o + (ln + 3) // 4], ln)))
+        return nodes, edges
+
+
+def buildGraph(k: int, kmersFreq) -> HipGraph:
+    """Graph.buildGraph(k, kmersFreq) (Graph.scala:269-382).  A PartitionedDNAMap is gathered into
+    one table first (the walk crosses partitions arbitrarily)."""
+    own = None
+    if isinstance(kmersFreq, PartitionedDNAMap):
+        own = kmersFreq = kmersFreq.merged()
+    assert isinstance(kmersFreq, HipDNAMap) and kmersFreq.k == k
+    h = L.vp()
+    try:
+        L.check(L.lib().gk_graph_build(kmersFreq.h, C.byref(h)), kmersFreq.ctx.h)
+    finally:
+        if own is not None:
+            own.close()
+    return HipGraph(kmersFreq.ctx, k, h)

@@ -1,0 +1,208 @@
+"""GPU parity tests of Graph.buildGraph / simplifyGraph / removeBubbles / removeEdge / retain
+against the CPU oracle, bit-exact on the canonical node and edge serialisations."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from genome_amd import dna, synth
+from genome_amd.dnamap import Context, HipDNAMap
+from genome_amd.graph import buildGraph
+from genome_amd.partitioned import PartitionedDNAMap
+from oracle import oracle as O
+from oracle import pyref as R
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def oracle_canonical(og):
+    k = og.k
+    nlo, nhi = og.nodes()
+    nodes = [dna.unpack(int(a), int(b), k) for a, b in zip(nlo, nhi)]
+    e = og.edges()
+    edges = []
+    for i in range(len(e["len"])):
+        seq = synth.bases_to_str(e["bases"][e["off"][i]:e["off"][i] + e["len"][i]])
+        edges.append((dna.unpack(int(e["slo"][i]), int(e["shi"][i]), k),
+                      dna.unpack(int(e["elo"][i]), int(e["ehi"][i]), k), seq))
+    return nodes, edges
+
+
+@pytest.mark.parametrize("name", sorted(f[:-5] for f in os.listdir(GOLDEN) if f.endswith(".json")))
+def test_golden_graphs(ctx, name):
+    fx = json.load(open(os.path.join(GOLDEN, name + ".json")))
+    k, P, rounds = fx["k"], fx["P"], fx["rounds"]
+    m = PartitionedDNAMap(ctx, k, P) if P > 1 else HipDNAMap(ctx, k)
+    m.count_reads(bytes.fromhex(fx["bin_hex"]), fx["nreads"])
+    m.deleteAll_lt(rounds)
+    g = buildGraph(k, m)
+    nodes, edges = g.canonical()
+    assert nodes == fx["nodes"]
+    assert [list(e) for e in edges] == fx["edges"]
+    assert g.counts() == (len(nodes), len(edges), sum(len(e[2]) for e in edges))
+    g.removeBubbles()
+    assert [list(e) for e in g.canonical()[1]] == fx["edges_after_bubbles"]
+    g.simplifyGraph()
+    nodes, edges = g.canonical()
+    assert nodes == fx["nodes_after_simplify"]
+    assert [list(e) for e in edges] == fx["edges_after_simplify"]
+    g.close(); m.close()
+
+
+def _reads(rnd, n, lmin, lmax, glen, err, haplotypes=1):
+    g = "".join(rnd.choice("AGCT") for _ in range(glen))
+    haps = [g]
+    for _ in range(haplotypes - 1):
+        h = list(g)
+        for p in range(30, glen, 57):
+            h[p] = rnd.choice([c for c in "AGCT" if c != h[p]])
+        haps.append("".join(h))
+    out = []
+    for _ in range(n):
+        h = rnd.choice(haps)
+        ln = rnd.randint(lmin, lmax)
+        st = rnd.randrange(0, glen - ln + 1)
+        r = h[st:st + ln]
+        if rnd.random() < 0.5:
+            r = R.rev_comp(r)
+        out.append("".join(c if rnd.random() >= err else rnd.choice([x for x in "AGCT" if x != c]) for c in r))
+    return out
+
+
+@pytest.mark.parametrize("k,seed,hap", [(7, 1, 1), (11, 2, 2), (15, 3, 2), (21, 4, 1), (31, 5, 2), (35, 6, 2), (47, 7, 1), (63, 8, 2)])
+def test_build_bubbles_simplify_remove_retain_vs_oracle(ctx, k, seed, hap):
+    rnd = random.Random(seed)
+    reads = _reads(rnd, 900, k + 5, min(255, k + 90), 1500, 0.01, hap)
+    binb = dna.reads_to_bin(reads)
+    m = HipDNAMap(ctx, k)
+    ref = O.PMap(k, 1)
+    m.count_reads(binb, len(reads)); ref.count_reads(binb, len(reads))
+    m.deleteAll_lt(2); ref.delete_lt(2)
+    g, og = buildGraph(k, m), O.Graph(ref)
+    assert g.canonical() == oracle_canonical(og)
+    n0, e0, l0 = g.counts()
+    assert (n0, e0, l0) == (og.num_nodes(), og.num_edges(), og.total_edge_len()) and n0 > 0 and e0 > 0
+    # invariants of SURVEY §4 on the GPU result itself
+    nodes, edges = g.canonical()
+    nodeset = set(nodes)
+    assert {R.rev_comp(x) for x in nodes} == nodeset
+    for s, t, q in edges:
+        assert (s + q).endswith(t)
+    # out-edge insertion order of a fresh graph is A,G,C,T (Graph.scala:351 over Base.fromInt)
+    for s in nodes[:40]:
+        assert g.out_order(s) == og.out_order(*dna.pack(s))
+    g.removeBubbles(); og.remove_bubbles()
+    assert g.canonical() == oracle_canonical(og)
+    g.simplifyGraph(); og.simplify()
+    assert g.canonical() == oracle_canonical(og)
+    for s in g.canonical()[0][:60]:      # insertion order after the merges (removeEdge/addEdge :180,:192)
+        assert g.out_order(s) == og.out_order(*dna.pack(s)), s
+    # removeEdge of every third edge, then simplify again: long (1,1) chains, self-loops, dead ends
+    _, edges = g.canonical()
+    victims = [(s, q[0]) for i, (s, _, q) in enumerate(edges) if i % 3 == 0]
+    assert g.removeEdges(victims) == len(victims)
+    assert g.removeEdges(victims[:5]) == 0          # already gone
+    for s, b in victims:
+        assert og.remove_edge(*dna.pack(s), "AGCT".index(b))
+    assert g.canonical() == oracle_canonical(og)
+    g.simplifyGraph(); og.simplify()
+    assert g.canonical() == oracle_canonical(og)
+    for s in g.canonical()[0][:60]:
+        assert g.out_order(s) == og.out_order(*dna.pack(s)), s
+    g.removeBubbles(); og.remove_bubbles()
+    assert g.canonical() == oracle_canonical(og)
+    kept, comps = g.retainLargest()
+    assert comps == og.num_components()
+    assert kept == og.retain_largest()
+    assert g.canonical() == oracle_canonical(og)
+    assert g.counts()[0] == kept
+    g.close(); m.close()
+
+
+def test_two_components_and_perfect_cycle(ctx):
+    """A circular genome alone is an all-(1,1) cycle: buildGraph yields nothing (Graph.scala:375
+    'perfect cycles are ignored'); next to a linear one only the linear component appears."""
+    rnd = random.Random(5)
+    k = 15
+    circ = "".join(rnd.choice("AGCT") for _ in range(120))
+    lin = "".join(rnd.choice("AGCT") for _ in range(200))
+    cc = circ + circ[:60]
+    reads = [cc[i:i + 50] for i in range(0, 121)] * 2
+    m = HipDNAMap(ctx, k); ref = O.PMap(k, 1)
+    b = dna.reads_to_bin(reads)
+    m.count_reads(b, len(reads)); ref.count_reads(b, len(reads))
+    g, og = buildGraph(k, m), O.Graph(ref)
+    assert g.counts() == (0, 0, 0) and og.num_nodes() == 0
+    assert g.canonical() == ([], [])
+    g.simplifyGraph(); g.removeBubbles()
+    assert g.retainLargest() == (0, 0)
+    g.close()
+    reads2 = [lin[i:i + 50] for i in range(0, 151)] * 2
+    b2 = dna.reads_to_bin(reads2)
+    m.count_reads(b2, len(reads2)); ref.count_reads(b2, len(reads2))
+    g, og = buildGraph(k, m), O.Graph(ref)
+    assert g.canonical() == oracle_canonical(og)
+    assert g.counts()[0] == 4
+    g.close(); m.close()
+
+
+def test_even_k_palindromes(ctx):
+    """Even k admits x == rc(x): a tie filed under rcx == x (FreqFilter.scala:32), one node not two."""
+    k = 6
+    rnd = random.Random(9)
+    core = "AGGCCT"                      # its own reverse complement
+    assert R.rev_comp(core) == core
+    left = "".join(rnd.choice("AGCT") for _ in range(40))
+    reads = []
+    for tail in ("".join(rnd.choice("AGCT") for _ in range(40)) for _ in range(3)):
+        s = left + core + tail
+        reads += [s[i:i + 30] for i in range(0, len(s) - 29)]
+    b = dna.reads_to_bin(reads)
+    m = HipDNAMap(ctx, k); ref = O.PMap(k, 1)
+    m.count_reads(b, len(reads)); ref.count_reads(b, len(reads))
+    for a, c in zip(m.sorted_items(), ref.export_sorted()):
+        assert np.array_equal(a, c)
+    g, og = buildGraph(k, m), O.Graph(ref)
+    assert g.canonical() == oracle_canonical(og)
+    g.removeBubbles(); og.remove_bubbles(); g.simplifyGraph(); og.simplify()
+    assert g.canonical() == oracle_canonical(og)
+    g.close(); m.close()
+
+
+def test_graph_at_scale_properties(ctx):
+    """200k x 150 bp reads over a 300 kbp genome (k=31): too slow for the oracle's literal graph
+    build at full tilt, so check properties: strand symmetry of nodes and edges, edge/node
+    consistency, every genome k-mer covered by the graph (CheckGraph.scala:48-55)."""
+    n, L_, k, G = 200_000, 150, 31, 300_000
+    d = ctx.alloc(n * synth.record_stride(L_) + 64)
+    ctx.synth_reads(d, n, L_, "G", 11, 0, G, 0.005)
+    m = HipDNAMap(ctx, k, n * 40)
+    m.count_reads_dev(d, n, L_)
+    m.deleteAll_lt(3)
+    g = buildGraph(k, m)
+    nn, ne, ln = g.counts()
+    assert nn > 0 and ne > 0
+    lo, hi = g.getNodes()
+    e = g.getEdges()
+    nodes = set(int(x) for x in lo)
+    assert len(nodes) == nn
+    assert set(int(x) for x in e["slo"]) <= nodes and set(int(x) for x in e["elo"]) <= nodes
+    # reverse-complement closure of the node set
+    sample = list(nodes)[:2000]
+    for x in sample:
+        assert O.revcomp(x, 0, k)[0] in nodes
+    # total walked length is strand symmetric: every edge has a mirror of the same length
+    assert ln % 2 == 0 and ne % 2 == 0
+    g.simplifyGraph()
+    assert g.counts()[:2] == (nn, ne)            # a fresh graph has no (1,1)/(0,0) node
+    g.close(); m.close(); ctx.free(d)
