@@ -174,8 +174,11 @@ static constexpr u64 KEY_EMPTY = ~0ULL;       // never a valid key word (top bit
 static constexpr u64 KEY_TOMB = ~0ULL - 1;    // deleteAll tombstone (ArrayDNAMap.scala:168): probes run through it
 
 template <int W> struct Slot;
-template <> struct __attribute__((aligned(16))) Slot<1> { u64 w0; u32 count; u32 aux; };
-template <> struct __attribute__((aligned(32))) Slot<2> { u64 w0; u64 w1; u32 count; u32 aux; u64 pad; };
+// `extra` = count - 1: the lane whose CAS claims a slot has thereby recorded the first occurrence
+// (v0 = 1, ArrayDNAMap.scala:146), so a new key costs ONE atomic (the CAS) and only repeats pay an
+// atomic add.  Readers add the 1 back (slot_count).
+template <> struct __attribute__((aligned(16))) Slot<1> { u64 w0; u32 extra; u32 aux; };
+template <> struct __attribute__((aligned(32))) Slot<2> { u64 w0; u64 w1; u32 extra; u32 aux; u64 pad; };
 
 // Stored form.  W=1: the key itself (k<=31 leaves the two top bits clear).  W=2: two 63-bit
 // halves, bits 0..62 and 63..125 of the 128-bit k-mer, so each word has a spare top bit and each
@@ -222,7 +225,11 @@ GK_D int table_add(const Table<1> &t, Kmer<1> key, u32 add, u32 *err) {
             cur = cas64(&s->w0, KEY_EMPTY, key.lo);
             if (cur == KEY_EMPTY) { cur = key.lo; claimed = 1; }
         }
-        if (cur == key.lo) { add32_noret(&s->count, add); return claimed; }
+        if (cur == key.lo) {
+            const u32 a = add - (u32)claimed;
+            if (a) add32_noret(&s->extra, a);
+            return claimed;
+        }
         i = (i + 1) & t.mask;
     }
     *err = 1;
@@ -248,7 +255,11 @@ GK_D int table_add(const Table<2> &t, Kmer<2> key, u32 add, u32 *err) {
                 c1 = cas64(&s->w1, KEY_EMPTY, k.w1);
                 if (c1 == KEY_EMPTY) { c1 = k.w1; claimed = 1; }
             }
-            if (c1 == k.w1) { add32_noret(&s->count, add); return claimed; }
+            if (c1 == k.w1) {
+                const u32 a = add - (u32)claimed;
+                if (a) add32_noret(&s->extra, a);
+                return claimed;
+            }
         }
         i = (i + 1) & t.mask;
     }
@@ -279,6 +290,7 @@ GK_D i64 table_find(const Table<2> &t, Kmer<2> key) {
     return -1;
 }
 template <int W> GK_D bool slot_live(const Slot<W> *s) { return s->w0 != KEY_EMPTY && s->w0 != KEY_TOMB; }
+template <int W> GK_D u32 slot_count(const Slot<W> *s) { return s->extra + 1u; }
 
 // Graph.buildGraph `contains` (Graph.scala:270): either strand.  Only the hash-rule canonical
 // orientation can be a stored key, except in the tie h(x) == h(rc x) where occurrences seen as x

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(BLOCK) void k_rehash(const Slot<W> *__restrict__ ol
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < ncap; i += (u64)gridDim.x * BLOCK) {
         if (!slot_live(&old[i])) continue;
         Kmer<W> key = from_stored(load_stored(&old[i]));
-        table_add(t, key, old[i].count, &err);
+        table_add(t, key, slot_count(&old[i]), &err);
     }
     if (err) ctr->error = 1;
 }
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(BLOCK) void k_filter_lt(Slot<W> *slots, u64 ncap, i
     __syncthreads();
     u32 rm = 0;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < ncap; i += (u64)gridDim.x * BLOCK) {
-        if (slot_live(&slots[i]) && (i32)slots[i].count < rounds) {
+        if (slot_live(&slots[i]) && (i32)slot_count(&slots[i]) < rounds) {
             slots[i].w0 = KEY_TOMB;
             rm++;
         }
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(BLOCK) void k_get(const u64 *__restrict__ lo, const
         if constexpr (W == 1) key = Kmer<1>{lo[i]};
         else key = Kmer<2>{lo[i], hi[i]};
         i64 s = table_find(t, key);
-        if (counts) counts[i] = s >= 0 ? (i32)t.slots[s].count : -1;
+        if (counts) counts[i] = s >= 0 ? (i32)slot_count(&t.slots[s]) : -1;
         if (found) found[i] = s >= 0;
     }
 }
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(BLOCK) void k_export(const Slot<W> *__restrict__ sl
             lo[o] = key.lo;
             if constexpr (W == 2) { if (hi) hi[o] = key.hi; }
             else { if (hi) hi[o] = 0; }
-            cnt[o] = (i32)slots[i].count;
+            cnt[o] = (i32)slot_count(&slots[i]);
         }
         __syncthreads();
     }
