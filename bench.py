@@ -95,6 +95,7 @@ def main():
 
     from genome_amd import synth
     from genome_amd.dnamap import Context, HipDNAMap
+    from genome_amd.partitioned import exchange_keys
 
     n, L, k = args.reads, args.read_len, args.k
     W = 1 if k <= 32 else 2
@@ -120,22 +121,13 @@ def main():
             kernel_ms.append(ms); kernel_units.append(kocc)
             return
         counts = ctx.shard_reads(k, rec.data_ptr(), n, L, world, send.data_ptr(), occ_rank)
-        sc = torch.as_tensor(counts.astype(np.int64), device=dev)
-        rc = torch.empty_like(sc)
-        dist.all_to_all_single(rc, sc)
-        rcn = rc.cpu().numpy()
-        nrecv = int(rcn.sum())
         nonlocal recv
-        if nrecv * W > recv.numel():
-            recv = torch.empty(nrecv * W + 1024, dtype=torch.int64, device=dev)
-        dist.all_to_all_single(recv[:nrecv * W], send[:occ_rank * W],
-                               output_split_sizes=[int(c) * W for c in rcn], input_split_sizes=[int(c) * W for c in counts])
+        recv, rcn = exchange_keys(dist, send, counts, W, recv)
+        nrecv = int(rcn.sum())
         torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         m.update_inc_dev(recv.data_ptr(), nrecv)
         kernel_ms.append((time.perf_counter() - t0) * 1e3); kernel_units.append(nrecv)
-        del ev0, ev1
 
     def fence():
         torch.cuda.synchronize()

@@ -1,0 +1,66 @@
+// graph_builder.cpp — C++ twin of GraphBuilder.startup (S/scripts/GraphBuilder.scala:18-59) over
+// genome.hpp: counts k-mers of a `.bin` read stream on the GPU, drops k-mers seen < rounds times,
+// builds the de Bruijn graph, keeps the largest component, and writes the graph as text.
+// The reference logs its counters through akka Logging (:34-53); here they are one JSON object.
+//
+//   graph_builder <reads.bin> <pairs> <k> [--rounds 3] [--take-first N] [--no-retain] [--out prefix]
+//
+// Build: g++ -std=c++17 -O2 -I include genome_amd/host/graph_builder.cpp -L genome_amd -lgenome_amd
+//        -Wl,-rpath,'$ORIGIN/..' -o genome_amd/host/graph_builder
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <iterator>
+
+#include "genome.hpp"
+
+int main(int argc, char **argv) {
+    if (argc < 4) {
+        std::fprintf(stderr, "usage: %s <reads.bin> <pairs> <k> [--rounds 3] [--take-first N] [--no-retain] [--out prefix]\n", argv[0]);
+        return 2;
+    }
+    const std::string infile = argv[1];
+    genome::PairedEndData data;
+    data.count = std::stoull(argv[2]);
+    const int k = std::stoi(argv[3]);
+    int rounds = 3;                               // GraphBuilder.scala:30
+    uint64_t takeFirst = UINT64_MAX;              // genome.takeFirst
+    bool retain = true;
+    std::string out;
+    for (int i = 4; i < argc; i++) {
+        if (!std::strcmp(argv[i], "--rounds") && i + 1 < argc) rounds = std::stoi(argv[++i]);
+        else if (!std::strcmp(argv[i], "--take-first") && i + 1 < argc) takeFirst = std::stoull(argv[++i]);
+        else if (!std::strcmp(argv[i], "--no-retain")) retain = false;
+        else if (!std::strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
+        else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
+    }
+    try {
+        std::ifstream f(infile, std::ios::binary);
+        if (!f) throw std::runtime_error("cannot open " + infile);
+        data.bin.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+        genome::Context ctx(0);
+        auto kmersFreq = genome::FreqFilter::extractFilteredKmers(ctx, data, k, rounds, takeFirst);      // :32
+        const uint64_t good = kmersFreq.size();                                                          // :34
+        auto graph = genome::Graph::buildGraph(k, kmersFreq);                                            // :36
+        auto [nodes, edges, totalLen] = graph.counts();                                                  // :39
+        uint64_t kept = nodes, comps = 0;
+        if (retain) std::tie(kept, comps) = graph.retainLargestComponent();                              // :52-54
+        auto [n2, e2, l2] = graph.counts();
+        std::printf("{\"k\":%d,\"rounds\":%d,\"good_kmers\":%llu,\"graph_nodes\":%llu,\"graph_edges\":%llu,"
+                    "\"total_edges_length\":%llu,\"components\":%llu,\"max_component_size\":%llu,"
+                    "\"retained_nodes\":%llu,\"retained_edges\":%llu,\"retained_edges_length\":%llu}\n",
+                    k, rounds, (unsigned long long)good, (unsigned long long)nodes, (unsigned long long)edges,
+                    (unsigned long long)totalLen, (unsigned long long)comps, (unsigned long long)kept,
+                    (unsigned long long)n2, (unsigned long long)e2, (unsigned long long)l2);
+        if (!out.empty()) {                                                                              // :56 (Kryo file there)
+            std::ofstream nf(out + ".nodes.txt"), ef(out + ".edges.txt");
+            for (const auto &n : graph.getNodes()) nf << n.toString() << "\n";
+            for (const auto &e : graph.getEdges()) ef << e.start.toString() << " " << e.end.toString() << " " << e.seq << "\n";
+        }
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "graph_builder: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -132,10 +132,24 @@ class PartitionedDNAMap:
         return m
 
 
-def exchange_plan(send_counts: np.ndarray, dist, device=None):
-    """all-to-all of the per-owner counts: returns recv_counts (what each peer sends me)."""
+def exchange_keys(dist, send, send_counts, W: int, recv=None, group=None):
+    """The ONE exchange step of the sharded path: route every canonical key to its owner rank.
+
+    send: 1-D int64 tensor holding this rank's keys grouped by owner (W words per key, as
+    gk_shard_reads_dev writes them); send_counts[p] = keys destined to rank p.  Two collectives:
+    all_to_all_single of the P counts, then all_to_all_single of the keys with split sizes — RCCL
+    over xGMI when the tensors are on GPUs (backend "nccl"), gloo on CPU tensors in the CPU tests.
+    Returns (recv tensor view holding sum(recv_counts)*W words, recv_counts)."""
     import torch
-    sc = torch.as_tensor(send_counts.astype(np.int64), device=device)
+    sc = torch.as_tensor(np.asarray(send_counts, dtype=np.int64), device=send.device)
     rc = torch.empty_like(sc)
-    dist.all_to_all_single(rc, sc)
-    return rc.cpu().numpy().astype(np.int64)
+    dist.all_to_all_single(rc, sc, group=group)
+    recv_counts = rc.cpu().numpy().astype(np.int64)
+    nrecv = int(recv_counts.sum())
+    if recv is None or recv.numel() < nrecv * W:
+        recv = torch.empty(max(nrecv * W, 1), dtype=torch.int64, device=send.device)
+    nsend = int(np.asarray(send_counts, dtype=np.int64).sum())
+    dist.all_to_all_single(recv[:nrecv * W], send[:nsend * W],
+                           output_split_sizes=[int(c) * W for c in recv_counts],
+                           input_split_sizes=[int(c) * W for c in send_counts], group=group)
+    return recv, recv_counts
