@@ -193,15 +193,33 @@ GK_HD Kmer<2> from_stored(Stored<2> s) { return Kmer<2>{s.w0 | (s.w1 << 63), s.w
 GK_D Stored<1> load_stored(const Slot<1> *s) { return Stored<1>{s->w0}; }
 GK_D Stored<2> load_stored(const Slot<2> *s) { return Stored<2>{s->w0, s->w1}; }
 
+// The table is an array of SEGMENTS of 2^seg_bits slots (64 KiB each: 4096 16-B slots or 2048 32-B
+// slots), and linear probing wraps INSIDE a segment.  A segment is the unit one workgroup can hold
+// in LDS, which is what lets a batch be radix-partitioned by segment and built there with LDS
+// atomics and coalesced HBM traffic (gk_partition.hip) instead of one global atomic per key.
+// Segment id = (L1 bucket, fine bucket): L1 = top lnb1 bits of the slot hash (<= 256 buckets),
+// fine = 32 middle bits scaled to nb2 — so the number of segments need not be a power of two and
+// the table can be sized to the load factor wanted.  Start position = low seg_bits bits.
+template <int W> struct SegBits;
+template <> struct SegBits<1> { static constexpr u32 value = 12; };
+template <> struct SegBits<2> { static constexpr u32 value = 11; };
+
 template <int W> struct Table {
     Slot<W> *slots;
-    u64 mask;          // capacity - 1 (capacity is a power of two)
+    u32 nb2;           // fine buckets per L1 bucket
+    u32 lnb1;          // log2(L1 buckets), 0..8
+    GK_HD u64 nseg() const { return (u64)nb2 << lnb1; }
+    GK_HD u64 capacity() const { return nseg() << SegBits<W>::value; }
 };
+template <int W> GK_HD u32 seg_l1(const Table<W> &t, u64 h) { return t.lnb1 ? (u32)(h >> (64 - t.lnb1)) : 0u; }
+template <int W> GK_HD u32 seg_fine(const Table<W> &t, u64 h) { return (u32)((((h >> 24) & 0xffffffffULL) * (u64)t.nb2) >> 32); }
+template <int W> GK_HD u32 seg_of(const Table<W> &t, u64 h) { return seg_l1(t, h) * t.nb2 + seg_fine(t, h); }
+template <int W> GK_HD u32 seg_pos(u64 h) { return (u32)h & ((1u << SegBits<W>::value) - 1u); }
 
 struct Counters {      // device-resident, one per map
     unsigned long long size;        // live keys
     unsigned long long occurrences; // windows counted by the last count kernel
-    u32 error;                      // 1 = a probe ran the whole table (capacity exhausted)
+    u32 error;                      // 1 = a probe ran a whole segment (capacity exhausted)
     u32 pad;
 };
 
@@ -211,83 +229,105 @@ GK_D u64 cas64(u64 *p, u64 expect, u64 val) {
 }
 GK_D void add32_noret(u32 *p, u32 v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// Container.update(key, v0, f) with v0 = add, f = _ + add (ArrayDNAMap.scala:129-150), lock-free:
+// Container.update(key, v0, f) with v0 = add, f = _ + add (ArrayDNAMap.scala:129-150) on one
+// segment (`seg` points at its first slot; in HBM here, in LDS in gk_partition.hip), lock-free:
 // plain loads are only hints (a stale line can only read EMPTY, never a wrong key, because key
 // words are write-once during an insert phase); the CAS decides.  Returns 1 if this call claimed
-// a new slot.  *err is set when the probe wraps the whole table.
-GK_D int table_add(const Table<1> &t, Kmer<1> key, u32 add, u32 *err) {
-    u64 i = slot_hash(key) & t.mask;
-    for (u64 n = 0; n <= t.mask; ++n) {
-        Slot<1> *s = &t.slots[i];
+// a new slot, 0 if the key was there, -1 if the probe wrapped the whole segment (full).
+template <class CAS, class ADD>
+GK_D int seg_add(Slot<1> *seg, u32 pos, Kmer<1> key, u32 add, CAS cas, ADD addf) {
+    constexpr u32 smask = (1u << SegBits<1>::value) - 1u;
+    u32 i = pos;
+    for (u32 n = 0; n <= smask; ++n) {
+        Slot<1> *s = &seg[i];
         u64 cur = s->w0;
         int claimed = 0;
         if (cur == KEY_EMPTY) {
-            cur = cas64(&s->w0, KEY_EMPTY, key.lo);
+            cur = cas(&s->w0, KEY_EMPTY, key.lo);
             if (cur == KEY_EMPTY) { cur = key.lo; claimed = 1; }
         }
         if (cur == key.lo) {
             const u32 a = add - (u32)claimed;
-            if (a) add32_noret(&s->extra, a);
+            if (a) addf(&s->extra, a);
             return claimed;
         }
-        i = (i + 1) & t.mask;
+        i = (i + 1) & smask;
     }
-    *err = 1;
-    return 0;
+    return -1;
 }
 // 128-bit keys: claim w0 then w1, each write-once.  Two keys sharing w0 may race for w1; the
 // loser simply moves on to the next slot, and every later probe of that key makes the same
 // decision from the (now immutable) slot contents, so a key never lands in two slots.
-GK_D int table_add(const Table<2> &t, Kmer<2> key, u32 add, u32 *err) {
-    Stored<2> k = to_stored(key);
-    u64 i = slot_hash(key) & t.mask;
-    for (u64 n = 0; n <= t.mask; ++n) {
-        Slot<2> *s = &t.slots[i];
+template <class CAS, class ADD>
+GK_D int seg_add(Slot<2> *seg, u32 pos, Kmer<2> key, u32 add, CAS cas, ADD addf) {
+    constexpr u32 smask = (1u << SegBits<2>::value) - 1u;
+    const Stored<2> k = to_stored(key);
+    u32 i = pos;
+    for (u32 n = 0; n <= smask; ++n) {
+        Slot<2> *s = &seg[i];
         u64 c0 = s->w0;
         int claimed = 0;
         if (c0 == KEY_EMPTY) {
-            c0 = cas64(&s->w0, KEY_EMPTY, k.w0);
+            c0 = cas(&s->w0, KEY_EMPTY, k.w0);
             if (c0 == KEY_EMPTY) c0 = k.w0;
         }
         if (c0 == k.w0) {
             u64 c1 = s->w1;
             if (c1 == KEY_EMPTY) {
-                c1 = cas64(&s->w1, KEY_EMPTY, k.w1);
+                c1 = cas(&s->w1, KEY_EMPTY, k.w1);
                 if (c1 == KEY_EMPTY) { c1 = k.w1; claimed = 1; }
             }
             if (c1 == k.w1) {
                 const u32 a = add - (u32)claimed;
-                if (a) add32_noret(&s->extra, a);
+                if (a) addf(&s->extra, a);
                 return claimed;
             }
         }
-        i = (i + 1) & t.mask;
+        i = (i + 1) & smask;
     }
-    *err = 1;
-    return 0;
+    return -1;
+}
+struct GlobalCas { GK_D u64 operator()(u64 *p, u64 e, u64 v) const { return cas64(p, e, v); } };
+struct GlobalAdd { GK_D void operator()(u32 *p, u32 v) const { add32_noret(p, v); } };
+
+// the HBM form: one global CAS per new key, one no-return add per repeat
+template <int W> GK_D int table_add(const Table<W> &t, Kmer<W> key, u32 add, u32 *err) {
+    const u64 h = slot_hash(key);
+    Slot<W> *seg = t.slots + ((u64)seg_of(t, h) << SegBits<W>::value);
+    int r = seg_add(seg, seg_pos<W>(h), key, add, GlobalCas(), GlobalAdd());
+    if (r < 0) { *err = 1; return 0; }
+    return r;
 }
 
-// Container.apply (ArrayDNAMap.scala:90-101) on a quiescent table: slot index or -1.
-GK_D i64 table_find(const Table<1> &t, Kmer<1> key) {
-    u64 i = slot_hash(key) & t.mask;
-    for (u64 n = 0; n <= t.mask; ++n) {
-        u64 cur = t.slots[i].w0;
+// Container.apply (ArrayDNAMap.scala:90-101) on a quiescent table: global slot index or -1.
+GK_D i64 seg_find(const Slot<1> *seg, u32 pos, Kmer<1> key) {
+    constexpr u32 smask = (1u << SegBits<1>::value) - 1u;
+    u32 i = pos;
+    for (u32 n = 0; n <= smask; ++n) {
+        u64 cur = seg[i].w0;
         if (cur == key.lo) return (i64)i;
         if (cur == KEY_EMPTY) return -1;
-        i = (i + 1) & t.mask;
+        i = (i + 1) & smask;
     }
     return -1;
 }
-GK_D i64 table_find(const Table<2> &t, Kmer<2> key) {
-    Stored<2> k = to_stored(key);
-    u64 i = slot_hash(key) & t.mask;
-    for (u64 n = 0; n <= t.mask; ++n) {
-        u64 c0 = t.slots[i].w0;
-        if (c0 == k.w0 && t.slots[i].w1 == k.w1) return (i64)i;
+GK_D i64 seg_find(const Slot<2> *seg, u32 pos, Kmer<2> key) {
+    constexpr u32 smask = (1u << SegBits<2>::value) - 1u;
+    const Stored<2> k = to_stored(key);
+    u32 i = pos;
+    for (u32 n = 0; n <= smask; ++n) {
+        u64 c0 = seg[i].w0;
+        if (c0 == k.w0 && seg[i].w1 == k.w1) return (i64)i;
         if (c0 == KEY_EMPTY) return -1;
-        i = (i + 1) & t.mask;
+        i = (i + 1) & smask;
     }
     return -1;
+}
+template <int W> GK_D i64 table_find(const Table<W> &t, Kmer<W> key) {
+    const u64 h = slot_hash(key);
+    const u64 base = (u64)seg_of(t, h) << SegBits<W>::value;
+    i64 r = seg_find(t.slots + base, seg_pos<W>(h), key);
+    return r < 0 ? -1 : (i64)base + r;
 }
 template <int W> GK_D bool slot_live(const Slot<W> *s) { return s->w0 != KEY_EMPTY && s->w0 != KEY_TOMB; }
 template <int W> GK_D u32 slot_count(const Slot<W> *s) { return s->extra + 1u; }

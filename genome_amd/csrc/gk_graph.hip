@@ -129,7 +129,7 @@ __global__ __launch_bounds__(BLOCK) void k_classify(Table<W> t, int k, unsigned 
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
     u32 cnt = 0;
-    const u64 ncap = t.mask + 1;
+    const u64 ncap = t.capacity();
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < ncap; i += (u64)gridDim.x * BLOCK) {
         Slot<W> *s = &t.slots[i];
         if (!slot_live(s)) continue;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(BLOCK) void k_collect_terminals(Table<W> t, int k, 
     __shared__ unsigned long long s_base;
     __shared__ u32 s_edges;
     if (threadIdx.x == 0) s_edges = 0;
-    const u64 ncap = t.mask + 1;
+    const u64 ncap = t.capacity();
     const u64 ngroups = (ncap + BLOCK - 1) / BLOCK;
     u32 edges = 0;
     for (u64 g = blockIdx.x; g < ngroups; g += gridDim.x) {
@@ -718,7 +718,7 @@ static int graph_build_index(gk_graph *g) {
 
 template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
     gk_ctx *ctx = m->ctx;
-    Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->capacity - 1};
+    Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1};
     const int k = m->k;
     unsigned long long *d_cnt = nullptr;     // [0] terminals [1] cursor [2] edges [3] ecursor [4] pool cursor
     u32 *d_err = nullptr, *slot_node = nullptr;

@@ -20,7 +20,8 @@ struct gk_map {
     gk_ctx *ctx = nullptr;
     int k = 0;
     int W = 1;                   // 64-bit words per key
-    uint64_t capacity = 0;       // slots, power of two
+    uint64_t capacity = 0;       // slots = nseg * 2^seg_bits
+    uint32_t nb2 = 1, lnb1 = 0;  // segment geometry (gk::Table)
     void *slots = nullptr;       // Slot<W>[capacity]
     gk::Counters *d_ctr = nullptr;
     uint64_t size = 0;           // host mirror of d_ctr->size (valid after every public call)
@@ -51,6 +52,19 @@ int hip_fail(const gk_ctx *ctx, hipError_t e, const char *what);
 inline bool k_supported(int k) { return (k >= 2 && k <= 31) || (k >= 34 && k <= 63); }
 inline int words_for_k(int k) { return k <= 32 ? 1 : 2; }
 inline size_t slot_bytes(int W) { return W == 1 ? 16 : 32; }
+inline uint32_t seg_bits_for(int W) { return W == 1 ? 12u : 11u; }
+// segment geometry for at least `want_slots` slots: nb1 = 2^lnb1 <= 256 L1 buckets x nb2 fine buckets
+inline void plan_segments(int W, uint64_t want_slots, uint32_t *nb2, uint32_t *lnb1, uint64_t *capacity) {
+    const uint64_t S = 1ull << seg_bits_for(W);
+    uint64_t want_seg = (want_slots + S - 1) / S;
+    if (want_seg < 1) want_seg = 1;
+    uint32_t l = 0;
+    while (l < 8 && (2ull << l) <= want_seg) l++;
+    const uint64_t nb1 = 1ull << l;
+    *lnb1 = l;
+    *nb2 = (uint32_t)((want_seg + nb1 - 1) / nb1);
+    *capacity = ((uint64_t)*nb2 << l) * S;
+}
 inline uint64_t pow2ceil(uint64_t v) {
     uint64_t p = 1;
     while (p < v) p <<= 1;

@@ -225,7 +225,7 @@ static inline int grid_for(const gk_ctx *ctx, u64 work_items, int per_block) {
 }
 
 template <int W> static Table<W> table_of(const gk_map *m) {
-    return Table<W>{reinterpret_cast<Slot<W> *>(m->slots), m->capacity - 1};
+    return Table<W>{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1};
 }
 
 static int alloc_table(gk_ctx *ctx, int W, uint64_t cap, void **out) {
@@ -246,7 +246,7 @@ int map_sync_counters(gk_map *m) {
     m->size = c.size;
     if (c.error) {
         GK_HIP(m->ctx, hipMemsetAsync(&m->d_ctr->error, 0, sizeof(u32), m->ctx->stream));
-        return fail(m->ctx, GK_E_CAPACITY, "table probe exhausted the capacity (internal sizing error)");
+        return fail(m->ctx, GK_E_CAPACITY, "a table segment filled up (internal sizing error)");
     }
     return GK_OK;
 }
@@ -258,8 +258,9 @@ static constexpr double TARGET_LOAD = 0.5; // load right after a grow
 int map_reserve(gk_map *m, uint64_t extra_keys) {
     uint64_t need = m->size + m->tombstones + extra_keys;
     if ((double)need <= MAX_LOAD * (double)m->capacity) return GK_OK;
-    uint64_t ncap = pow2ceil((uint64_t)((double)(m->size + extra_keys) / TARGET_LOAD) + 1);
-    if (ncap < m->capacity) ncap = m->capacity;
+    uint32_t nnb2, nlnb1;
+    uint64_t ncap;
+    plan_segments(m->W, std::max<uint64_t>((uint64_t)((double)(m->size + extra_keys) / TARGET_LOAD) + 1, m->capacity + m->capacity / 2), &nnb2, &nlnb1, &ncap);
     gk_ctx *ctx = m->ctx;
     void *nslots = nullptr;
     int rc = alloc_table(ctx, m->W, ncap, &nslots);
@@ -267,15 +268,17 @@ int map_reserve(gk_map *m, uint64_t extra_keys) {
     int grid = grid_for(ctx, m->capacity, BLOCK);
     if (m->W == 1)
         hipLaunchKernelGGL(k_rehash<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, m->capacity,
-                           Table<1>{(Slot<1> *)nslots, ncap - 1}, m->d_ctr);
+                           Table<1>{(Slot<1> *)nslots, nnb2, nlnb1}, m->d_ctr);
     else
         hipLaunchKernelGGL(k_rehash<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots, m->capacity,
-                           Table<2>{(Slot<2> *)nslots, ncap - 1}, m->d_ctr);
+                           Table<2>{(Slot<2> *)nslots, nnb2, nlnb1}, m->d_ctr);
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     GK_HIP(ctx, hipFree(m->slots));
     m->slots = nslots;
     m->capacity = ncap;
+    m->nb2 = nnb2;
+    m->lnb1 = nlnb1;
     m->tombstones = 0;
     m->grows++;
     return map_sync_counters(m);
@@ -375,8 +378,7 @@ int gk_map_create(gk_ctx *ctx, int k, uint64_t capacity_hint, gk_map **out) {
     m->k = k;
     m->W = words_for_k(k);
     uint64_t want = capacity_hint ? capacity_hint : 1024;
-    m->capacity = pow2ceil((uint64_t)((double)want / TARGET_LOAD) + 1);
-    if (m->capacity < 1024) m->capacity = 1024;
+    plan_segments(m->W, (uint64_t)((double)want / TARGET_LOAD) + 1, &m->nb2, &m->lnb1, &m->capacity);
     int rc = alloc_table(ctx, m->W, m->capacity, &m->slots);
     if (rc == GK_OK) {
         hipError_t e = hipMalloc((void **)&m->d_ctr, sizeof(Counters));
@@ -670,23 +672,26 @@ int gk_map_filter_lt(gk_map *m, int32_t rounds) {
     // sized for the survivors whenever tombstones exist, so that the read-only graph phase probes a
     // clean, cache-friendlier table.
     if (m->tombstones) {
-        uint64_t ncap = pow2ceil((uint64_t)((double)m->size / TARGET_LOAD) + 1);
-        if (ncap < 1024) ncap = 1024;
-        if (ncap > m->capacity) ncap = m->capacity;
+        uint32_t nnb2, nlnb1;
+        uint64_t ncap;
+        plan_segments(m->W, (uint64_t)((double)m->size / TARGET_LOAD) + 1, &nnb2, &nlnb1, &ncap);
+        if (ncap > m->capacity) { nnb2 = m->nb2; nlnb1 = m->lnb1; ncap = m->capacity; }
         void *nslots = nullptr;
         if (alloc_table(ctx, m->W, ncap, &nslots) != GK_OK) return GK_OK;   // keep tombstones if memory is short
         int g2 = grid_for(ctx, m->capacity, BLOCK);
         if (m->W == 1)
             hipLaunchKernelGGL(k_rehash<1>, dim3(g2), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, m->capacity,
-                               Table<1>{(Slot<1> *)nslots, ncap - 1}, m->d_ctr);
+                               Table<1>{(Slot<1> *)nslots, nnb2, nlnb1}, m->d_ctr);
         else
             hipLaunchKernelGGL(k_rehash<2>, dim3(g2), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots, m->capacity,
-                               Table<2>{(Slot<2> *)nslots, ncap - 1}, m->d_ctr);
+                               Table<2>{(Slot<2> *)nslots, nnb2, nlnb1}, m->d_ctr);
         GK_HIP(ctx, hipGetLastError());
         GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         GK_HIP(ctx, hipFree(m->slots));
         m->slots = nslots;
         m->capacity = ncap;
+        m->nb2 = nnb2;
+        m->lnb1 = nlnb1;
         m->tombstones = 0;
         return map_sync_counters(m);
     }

@@ -80,7 +80,8 @@ def test_ragged_reads_vs_oracle(ctx, k):
     assert m.count_reads(binb, len(reads)) == occ
     assert_same_table(m.sorted_items(), ref.export_sorted())
     assert m.size() == ref.size()
-    assert m.stats()["grows"] >= 1
+    if ref.size() > 4096:
+        assert m.stats()["grows"] >= 1
     # a second pass over the same reads doubles every count (update(y, 1, _+1) is additive)
     m.count_reads(binb, len(reads))
     lo, hi, cnt = ref.export_sorted()
