@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--mode", choices=["U", "G"], default="U", help="U: uniform reads (every k-mer distinct w.h.p.); "
                     "G: 5 Mbp genome, 30x, 1%% error")
+    ap.add_argument("--insert-path", choices=["auto", "direct", "partitioned"], default="auto",
+                    help="direct: one global CAS/add per k-mer; partitioned: radix-partition by table segment, build in LDS")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -107,6 +109,7 @@ def main():
     ctx.synth_reads(rec.data_ptr(), n, L, args.mode, 2, rank * n, G, err)     # config_id 2 = C2
     occ_rank = n * nk
     m = HipDNAMap(ctx, k, int(occ_rank * 1.05))
+    m.set_insert_path(args.insert_path)
     if world > 1:
         send = torch.empty(occ_rank * W, dtype=torch.int64, device=dev)
         recv = torch.empty(int(occ_rank * W * 1.5) + 1024, dtype=torch.int64, device=dev)

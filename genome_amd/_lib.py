@@ -58,6 +58,7 @@ SIGNATURES = {
     "gk_map_destroy": (None, [vp]),
     "gk_map_k": (C.c_int, [vp]),
     "gk_map_clear": (C.c_int, [vp]),
+    "gk_map_set_insert_path": (C.c_int, [vp, C.c_int]),
     "gk_map_size": (C.c_int, [vp, u64p]),
     "gk_map_slots": (C.c_int, [vp, u64p]),
     "gk_map_count_reads": (C.c_int, [vp, u8p, C.c_size_t, C.c_uint64, u64p]),

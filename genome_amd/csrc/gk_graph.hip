@@ -816,6 +816,7 @@ int gk_graph_build(gk_map *m, gk_graph **out) {
     if (!out) return fail(m->ctx, GK_E_INVALID, "gk_graph_build: out is NULL");
     *out = nullptr;
     GK_HIP(m->ctx, hipSetDevice(m->ctx->device));
+    if (int rc = map_materialize(m)) return rc;
     gk_graph *g = new gk_graph();
     g->ctx = m->ctx;
     g->k = m->k;

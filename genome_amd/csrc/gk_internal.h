@@ -16,6 +16,8 @@ struct gk_ctx {
     std::string err;
 };
 
+namespace gk { struct PartScratch; }
+
 struct gk_map {
     gk_ctx *ctx = nullptr;
     int k = 0;
@@ -35,6 +37,11 @@ struct gk_map {
     size_t stage_bytes = 0;
     void *d_offsets = nullptr;
     size_t offsets_bytes = 0;
+    // partitioned insert path (gk_partition.hip)
+    gk::PartScratch *part = nullptr;
+    int insert_path = 0;         // 0 auto, 1 direct (global atomics), 2 partitioned (LDS build)
+    bool pending_clear = false;  // gk_map_clear deferred: slots are stale until materialised
+    uint64_t part_launches = 0, direct_launches = 0;
 };
 
 namespace gk {
@@ -74,5 +81,12 @@ inline uint64_t pow2ceil(uint64_t v) {
 // table ops used across translation units
 int map_reserve(gk_map *m, uint64_t extra_keys);     // grow so that size+extra stays under the load limit
 int map_sync_counters(gk_map *m);                    // refresh m->size, detect device-side error flag
+int map_materialize(gk_map *m);                      // run a deferred clear so that the slots are valid
+int map_add_keys_direct(gk_map *m, const uint64_t *d_keys, uint64_t n);   // k_add_keys on device keys (W words each)
+// partitioned path
+int part_count(gk_map *m, PartScratch **pps, const uint8_t *d_rec, uint64_t nreads, const uint32_t *d_off, uint32_t stride,
+               const uint64_t *d_keys, uint64_t nkeys_in, uint64_t nkeys_bound, bool from_empty);
+bool part_supported(const gk_map *m);
+void part_scratch_free(PartScratch *ps);
 
 }  // namespace gk

@@ -1,0 +1,480 @@
+// gk_partition.hip — the partitioned form of FreqFilter.add / DNAMap.update(key, 1, _+1):
+// radix-partition a batch of canonical k-mers by table SEGMENT, then let one workgroup per segment
+// build its 64 KiB piece of the table in LDS and stream it back.
+//
+// Why: the direct path (k_count_reads / k_add_keys) costs one memory-side atomic per distinct key
+// and one 64-B sector per 8-B touch — 15.8 GB of HBM traffic for 2.9 GB of algorithmic bytes at C2
+// (profiles/r01/pmc_count_reads_v2.json), and the chip's random-atomic rate (17.6 G/s) is the
+// ceiling.  Here every byte moves in coalesced 8/16-B-per-lane streams and all read-modify-write
+// happens in LDS:
+//
+//   P1 k_part_hist1     source -> 256-bin histogram of the L1 bucket (top bits of the slot hash)
+//   -- k_part_prefix1   exclusive scan (1 workgroup): L1 region bases, chunk table for P3/P4
+//   P2 k_part_scatter1  source -> keys written into their L1 region (tile histogram in LDS, one
+//                       global atomic per (tile, bucket) reserves a run, lanes fill it by LDS rank)
+//   P3 k_part_hist2     L1 region chunks -> per-segment histogram          (skipped if nb2 == 1)
+//   -- k_part_prefix2   per L1 bucket scan -> fine (per-segment) bases
+//   P4 k_part_scatter2  L1 region chunks -> keys in segment order
+//   P5 k_seg_insert     one workgroup per segment: load the segment into LDS (or start from
+//                       EMPTY when the table is known to be empty), insert the segment's keys with
+//                       LDS atomics (same probe sequence as gk::table_add), store it back.
+//
+// The source is either a `.bin` read stream (extract + canonicalise on the fly, FreqFilter.scala:28-36)
+// or an array of already-routed keys (the owner side of the all-to-all).  Results are identical
+// to the direct path: same slots layout, same probing; only the order of insertion differs, which
+// is unobservable (parity is on sorted content).
+//
+// Algorithmic bytes per occurrence (k<=31): P1 0.31, P2 0.31 + 8, P3 8, P4 8 + 8, P5 8 + slot
+// traffic (32 B of table per slot streamed in and out, or 16 B out only from empty).
+#include <algorithm>
+#include <string>
+
+#include "gk_internal.h"
+#include "gk_tile.h"
+
+using namespace gk;
+
+static constexpr int PBLOCK = 512;          // threads of the key-streaming kernels
+static constexpr int KEYS_PER_THREAD = 8;
+static constexpr int TILE2 = PBLOCK * KEYS_PER_THREAD;   // keys per chunk in P3/P4
+static constexpr u32 MAX_NB2 = 4096;        // LDS bound in P3/P4 (12 B per fine bucket, 48 KiB)
+
+struct PartArrays {
+    unsigned long long *hist1;      // [256]
+    unsigned long long *l1_base;    // [257]
+    unsigned long long *cursor1;    // [256]
+    unsigned long long *cbase;      // [257] chunk prefix
+    u32 *hist2;                     // [nseg]
+    unsigned long long *fine_base;  // [nseg + 1]
+    u32 *cursor2;                   // [nseg]
+    u32 *failed;                    // [nseg] list of segments that overflowed
+    u32 *n_failed;
+};
+
+template <int W> __device__ __forceinline__ Kmer<W> load_key(const u64 *keys, u64 i) {
+    if constexpr (W == 1) return Kmer<1>{keys[i]};
+    else return Kmer<2>{keys[2 * i], keys[2 * i + 1]};
+}
+template <int W> __device__ __forceinline__ void store_key(u64 *keys, u64 i, Kmer<W> x) {
+    if constexpr (W == 1) keys[i] = x.lo;
+    else { keys[2 * i] = x.lo; keys[2 * i + 1] = x.hi; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// P1 / P2 from a read stream
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_part_hist1_reads(const uint8_t *__restrict__ rec, u64 nreads, const u32 *__restrict__ offsets,
+                                                            u32 stride, int k, Table<W> t, unsigned long long *hist1, Counters *ctr) {
+    __shared__ __attribute__((aligned(16))) u32 tile[TILE_WORDS];
+    __shared__ u32 hist[256];
+    hist[threadIdx.x] = 0;
+    u32 occ = 0;
+    const u64 ntiles = (nreads + TILE_READS - 1) / TILE_READS;
+    for (u64 tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const u64 r0 = tl * TILE_READS;
+        const int nr = (int)min((u64)TILE_READS, nreads - r0);
+        const u64 gb = offsets ? (u64)offsets[r0] : r0 * stride, ge = offsets ? (u64)offsets[r0 + nr] : (r0 + nr) * stride;
+        __syncthreads();
+        const u64 a0 = stage_tile(tile, rec, gb, ge);
+        __syncthreads();
+        for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, [&](Kmer<W> x) {
+            atomicAdd(&hist[seg_l1(t, slot_hash(canonical(x, k)))], 1u);
+            occ++;
+        });
+    }
+    __syncthreads();
+    if (hist[threadIdx.x]) atomicAdd(&hist1[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+    // occurrences: wave-reduce then one atomic per wave
+    for (int d = 32; d; d >>= 1) occ += __shfl_down(occ, d);
+    if ((threadIdx.x & 63) == 0 && occ) atomicAdd(&ctr->occurrences, (unsigned long long)occ);
+}
+
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_part_scatter1_reads(const uint8_t *__restrict__ rec, u64 nreads, const u32 *__restrict__ offsets,
+                                                               u32 stride, int k, Table<W> t, const unsigned long long *l1_base,
+                                                               unsigned long long *cursor1, u64 *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) u32 tile[TILE_WORDS];
+    __shared__ u32 hist[256];
+    __shared__ unsigned long long base[256];
+    const u64 ntiles = (nreads + TILE_READS - 1) / TILE_READS;
+    for (u64 tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const u64 r0 = tl * TILE_READS;
+        const int nr = (int)min((u64)TILE_READS, nreads - r0);
+        const u64 gb = offsets ? (u64)offsets[r0] : r0 * stride, ge = offsets ? (u64)offsets[r0 + nr] : (r0 + nr) * stride;
+        __syncthreads();
+        hist[threadIdx.x] = 0;
+        const u64 a0 = stage_tile(tile, rec, gb, ge);
+        __syncthreads();
+        for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, [&](Kmer<W> x) {
+            atomicAdd(&hist[seg_l1(t, slot_hash(canonical(x, k)))], 1u);
+        });
+        __syncthreads();
+        {
+            const u32 c = hist[threadIdx.x];
+            if (c) base[threadIdx.x] = l1_base[threadIdx.x] + atomicAdd(&cursor1[threadIdx.x], (unsigned long long)c);
+            hist[threadIdx.x] = 0;          // becomes the rank counter
+        }
+        __syncthreads();
+        for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, [&](Kmer<W> x) {
+            const Kmer<W> y = canonical(x, k);
+            const u32 b = seg_l1(t, slot_hash(y));
+            store_key<W>(out, base[b] + atomicAdd(&hist[b], 1u), y);
+        });
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// P1 / P2 from a key array (keys already canonical and routed)
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_part_hist1_keys(const u64 *__restrict__ keys, u64 n, Table<W> t, unsigned long long *hist1) {
+    __shared__ u32 hist[256];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK)
+        atomicAdd(&hist[seg_l1(t, slot_hash(load_key<W>(keys, i)))], 1u);
+    __syncthreads();
+    if (hist[threadIdx.x]) atomicAdd(&hist1[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+}
+
+// generic chunked scatter of a key range into `nbins` bins: used for P2 (keys source, bin = L1
+// bucket) and P4 (bin = fine bucket inside one L1 bucket).  LDS: nbins u32.
+template <int W, int LEVEL>
+__device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u64 begin, u32 cnt, const Table<W> &t, u32 nbins,
+                                              u32 *lds_hist, unsigned long long *lds_base, const unsigned long long *bin_base,
+                                              unsigned long long *cursor64, u32 *cursor32, u64 bin0, u64 *__restrict__ out) {
+    Kmer<W> key[KEYS_PER_THREAD];
+    u32 bin[KEYS_PER_THREAD];
+    for (u32 b = threadIdx.x; b < nbins; b += PBLOCK) lds_hist[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KEYS_PER_THREAD; j++) {
+        const u32 i = threadIdx.x + j * PBLOCK;
+        bin[j] = 0xffffffffu;
+        if (i < cnt) {
+            key[j] = load_key<W>(in, begin + i);
+            const u64 h = slot_hash(key[j]);
+            bin[j] = LEVEL == 1 ? seg_l1(t, h) : seg_fine(t, h);
+            atomicAdd(&lds_hist[bin[j]], 1u);
+        }
+    }
+    __syncthreads();
+    for (u32 b = threadIdx.x; b < nbins; b += PBLOCK) {
+        const u32 c = lds_hist[b];
+        if (c) {
+            if (LEVEL == 1) lds_base[b] = bin_base[b] + atomicAdd(&cursor64[b], (unsigned long long)c);
+            else lds_base[b] = bin_base[bin0 + b] + atomicAdd(&cursor32[bin0 + b], c);
+        }
+        lds_hist[b] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KEYS_PER_THREAD; j++)
+        if (bin[j] != 0xffffffffu) store_key<W>(out, lds_base[bin[j]] + atomicAdd(&lds_hist[bin[j]], 1u), key[j]);
+    __syncthreads();
+}
+
+template <int W>
+__global__ __launch_bounds__(PBLOCK) void k_part_scatter1_keys(const u64 *__restrict__ keys, u64 n, Table<W> t,
+                                                               const unsigned long long *l1_base, unsigned long long *cursor1,
+                                                               u64 *__restrict__ out) {
+    __shared__ u32 lds_hist[256];
+    __shared__ unsigned long long lds_base[256];
+    const u64 nchunks = (n + TILE2 - 1) / TILE2;
+    for (u64 c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const u64 begin = c * TILE2;
+        const u32 cnt = (u32)min((u64)TILE2, n - begin);
+        scatter_chunk<W, 1>(keys, begin, cnt, t, 256u, lds_hist, lds_base, l1_base, cursor1, nullptr, 0, out);
+    }
+}
+
+// exclusive scan of the 256 L1 counts; chunk table for P3/P4 (chunks never straddle L1 buckets)
+__global__ __launch_bounds__(256) void k_part_prefix1(PartArrays a, u32 nb1) {
+    __shared__ unsigned long long s[256], c[256];
+    const u32 i = threadIdx.x;
+    s[i] = i < nb1 ? a.hist1[i] : 0;
+    c[i] = (s[i] + TILE2 - 1) / TILE2;
+    __syncthreads();
+    if (i == 0) {
+        unsigned long long acc = 0, cacc = 0;
+        for (u32 b = 0; b < 256; b++) {
+            const unsigned long long v = s[b], cv = c[b];
+            a.l1_base[b] = acc; a.cbase[b] = cacc;
+            acc += v; cacc += cv;
+        }
+        a.l1_base[256] = acc; a.cbase[256] = cacc;
+    }
+}
+
+// which L1 bucket does chunk `c` belong to (binary search over the 257-entry chunk prefix)
+__device__ __forceinline__ u32 chunk_bucket(const unsigned long long *cbase, u64 c) {
+    u32 lo = 0, hi = 256;
+    while (hi - lo > 1) {
+        const u32 mid = (lo + hi) >> 1;
+        if (cbase[mid] <= c) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <int W>
+__global__ __launch_bounds__(PBLOCK) void k_part_hist2(const u64 *__restrict__ bufA, Table<W> t, PartArrays a, u64 max_chunks) {
+    extern __shared__ u32 lds_hist[];
+    const u64 total_chunks = a.cbase[256];
+    for (u64 c = blockIdx.x; c < total_chunks && c < max_chunks; c += gridDim.x) {
+        const u32 b1 = chunk_bucket(a.cbase, c);
+        const u64 bsize = a.l1_base[b1 + 1] - a.l1_base[b1];
+        const u64 begin = (c - a.cbase[b1]) * TILE2;
+        const u32 cnt = (u32)min((u64)TILE2, bsize - begin);
+        for (u32 b = threadIdx.x; b < t.nb2; b += PBLOCK) lds_hist[b] = 0;
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < cnt; i += PBLOCK)
+            atomicAdd(&lds_hist[seg_fine(t, slot_hash(load_key<W>(bufA, a.l1_base[b1] + begin + i)))], 1u);
+        __syncthreads();
+        for (u32 b = threadIdx.x; b < t.nb2; b += PBLOCK)
+            if (lds_hist[b]) atomicAdd(&a.hist2[(u64)b1 * t.nb2 + b], lds_hist[b]);
+        __syncthreads();
+    }
+}
+
+// one workgroup per L1 bucket: fine_base[seg] = l1_base[b1] + exclusive scan of hist2 inside b1
+__global__ __launch_bounds__(256) void k_part_prefix2(PartArrays a, u32 nb1, u32 nb2) {
+    __shared__ unsigned long long s_carry;
+    __shared__ u32 wsum[4];
+    const u32 b1 = blockIdx.x;
+    if (threadIdx.x == 0) s_carry = a.l1_base[b1];
+    __syncthreads();
+    for (u32 base = 0; base < nb2; base += 256) {
+        const u32 i = base + threadIdx.x;
+        const u32 v = i < nb2 ? a.hist2[(u64)b1 * nb2 + i] : 0;
+        // block exclusive scan of v
+        u32 inc = v;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int d = 1; d < 64; d <<= 1) { u32 tt = __shfl_up(inc, d); if (lane >= d) inc += tt; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        u32 pre = 0, tot = 0;
+        for (int w = 0; w < 4; w++) { if (w < wave) pre += wsum[w]; tot += wsum[w]; }
+        if (i < nb2) a.fine_base[(u64)b1 * nb2 + i] = s_carry + pre + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += tot;
+        __syncthreads();
+    }
+    if (b1 == nb1 - 1 && threadIdx.x == 0) a.fine_base[(u64)nb1 * nb2] = s_carry;
+}
+
+template <int W>
+__global__ __launch_bounds__(PBLOCK) void k_part_scatter2(const u64 *__restrict__ bufA, Table<W> t, PartArrays a, u64 max_chunks,
+                                                          u64 *__restrict__ bufB) {
+    extern __shared__ unsigned long long lds_dyn[];
+    unsigned long long *lds_base = lds_dyn;                       // [nb2]
+    u32 *lds_hist = reinterpret_cast<u32 *>(lds_dyn + t.nb2);     // [nb2]
+    const u64 total_chunks = a.cbase[256];
+    for (u64 c = blockIdx.x; c < total_chunks && c < max_chunks; c += gridDim.x) {
+        const u32 b1 = chunk_bucket(a.cbase, c);
+        const u64 bsize = a.l1_base[b1 + 1] - a.l1_base[b1];
+        const u64 begin = (c - a.cbase[b1]) * TILE2;
+        const u32 cnt = (u32)min((u64)TILE2, bsize - begin);
+        scatter_chunk<W, 2>(bufA, a.l1_base[b1] + begin, cnt, t, t.nb2, lds_hist, lds_base, a.fine_base, nullptr, a.cursor2,
+                            (u64)b1 * t.nb2, bufB);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// P5: one workgroup owns one segment
+// ---------------------------------------------------------------------------------------------
+struct LdsCas {
+    __device__ __forceinline__ u64 operator()(u64 *p, u64 e, u64 v) const {
+        return atomicCAS(reinterpret_cast<unsigned long long *>(p), (unsigned long long)e, (unsigned long long)v);
+    }
+};
+struct LdsAdd {
+    __device__ __forceinline__ void operator()(u32 *p, u32 v) const { atomicAdd(p, v); }
+};
+
+template <int W>
+__global__ __launch_bounds__(PBLOCK) void k_seg_insert(Table<W> t, const u64 *__restrict__ keys, PartArrays a, int from_empty, Counters *ctr) {
+    extern __shared__ uint4 lds_raw[];
+    constexpr u32 S = 1u << SegBits<W>::value;
+    constexpr u32 NVEC = S * sizeof(Slot<W>) / 16;
+    Slot<W> *seg = reinterpret_cast<Slot<W> *>(lds_raw);
+    u32 *flags = reinterpret_cast<u32 *>(lds_raw + NVEC);         // [0] claims, [1] overflow
+    const u64 nseg = t.nseg();
+    for (u64 s = blockIdx.x; s < nseg; s += gridDim.x) {
+        const u64 kb = a.fine_base[s], ke = a.fine_base[s + 1];
+        uint4 *gseg = reinterpret_cast<uint4 *>(t.slots + (s << SegBits<W>::value));
+        if (kb == ke) {
+            if (from_empty) {       // materialise the pending clear of a segment that gets no key
+                for (u32 i = threadIdx.x; i < NVEC; i += PBLOCK) {
+                    if constexpr (W == 1) gseg[i] = make_uint4(~0u, ~0u, 0u, 0u);
+                    else gseg[i] = (i & 1) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
+                }
+            }
+            continue;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2) flags[threadIdx.x] = 0;
+        if (from_empty) {
+            for (u32 i = threadIdx.x; i < NVEC; i += PBLOCK) {
+                if constexpr (W == 1) lds_raw[i] = make_uint4(~0u, ~0u, 0u, 0u);
+                else lds_raw[i] = (i & 1) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
+            }
+        } else {
+            for (u32 i = threadIdx.x; i < NVEC; i += PBLOCK) lds_raw[i] = gseg[i];
+        }
+        __syncthreads();
+        u32 claims = 0;
+        bool overflow = false;
+        for (u64 i = kb + threadIdx.x; i < ke; i += PBLOCK) {
+            const Kmer<W> key = load_key<W>(keys, i);
+            const int r = seg_add(seg, seg_pos<W>(slot_hash(key)), key, 1u, LdsCas(), LdsAdd());
+            if (r < 0) overflow = true; else claims += (u32)r;
+        }
+        if (claims) atomicAdd(&flags[0], claims);
+        if (overflow) flags[1] = 1;
+        __syncthreads();
+        if (flags[1]) {
+            // segment full: leave the HBM copy as it was (or EMPTY) and hand the bucket to the host,
+            // which grows the table and replays these keys through the direct path
+            if (from_empty)
+                for (u32 i = threadIdx.x; i < NVEC; i += PBLOCK) {
+                    if constexpr (W == 1) gseg[i] = make_uint4(~0u, ~0u, 0u, 0u);
+                    else gseg[i] = (i & 1) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
+                }
+            if (threadIdx.x == 0) a.failed[atomicAdd(a.n_failed, 1u)] = (u32)s;
+            continue;
+        }
+        for (u32 i = threadIdx.x; i < NVEC; i += PBLOCK) gseg[i] = lds_raw[i];
+        if (threadIdx.x == 0 && flags[0]) atomicAdd(&ctr->size, (unsigned long long)flags[0]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------------
+namespace gk {
+
+struct PartScratch {
+    void *blob = nullptr;        // all the small arrays
+    size_t blob_bytes = 0;
+    u64 nseg = 0;
+    u64 *bufA = nullptr, *bufB = nullptr;
+    u64 buf_keys = 0;            // capacity in keys of each buffer
+    int W = 1;
+    bool lds_attr_set = false;
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int part_prepare(gk_map *m, PartScratch *ps, u64 nkeys, PartArrays *arr, bool need_a) {
+    gk_ctx *ctx = m->ctx;
+    const u64 nseg = (u64)m->nb2 << m->lnb1;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_hist1 = take(256 * 8), o_l1 = take(257 * 8), o_cur1 = take(256 * 8), o_cb = take(257 * 8);
+    const size_t o_hist2 = take(nseg * 4), o_fine = take((nseg + 1) * 8), o_cur2 = take(nseg * 4), o_failed = take(nseg * 4),
+                 o_nf = take(4);
+    if (ps->blob_bytes < off) {
+        if (ps->blob) GK_HIP(ctx, hipFree(ps->blob));
+        ps->blob = nullptr; ps->blob_bytes = 0;
+        GK_HIP(ctx, hipMalloc(&ps->blob, off));
+        ps->blob_bytes = off;
+    }
+    GK_HIP(ctx, hipMemsetAsync(ps->blob, 0, off, ctx->stream));
+    char *b = (char *)ps->blob;
+    arr->hist1 = (unsigned long long *)(b + o_hist1); arr->l1_base = (unsigned long long *)(b + o_l1);
+    arr->cursor1 = (unsigned long long *)(b + o_cur1); arr->cbase = (unsigned long long *)(b + o_cb);
+    arr->hist2 = (u32 *)(b + o_hist2); arr->fine_base = (unsigned long long *)(b + o_fine);
+    arr->cursor2 = (u32 *)(b + o_cur2); arr->failed = (u32 *)(b + o_failed); arr->n_failed = (u32 *)(b + o_nf);
+    if (ps->buf_keys < nkeys || ps->W != m->W) {
+        if (ps->bufA) GK_HIP(ctx, hipFree(ps->bufA));
+        if (ps->bufB) GK_HIP(ctx, hipFree(ps->bufB));
+        ps->bufA = ps->bufB = nullptr; ps->buf_keys = 0;
+        GK_HIP(ctx, hipMalloc((void **)&ps->bufA, std::max<u64>(nkeys, 1) * 8 * m->W));
+        GK_HIP(ctx, hipMalloc((void **)&ps->bufB, std::max<u64>(nkeys, 1) * 8 * m->W));
+        ps->buf_keys = nkeys; ps->W = m->W;
+    }
+    (void)need_a;
+    return GK_OK;
+}
+
+void part_scratch_free(PartScratch *ps) {
+    if (!ps) return;
+    if (ps->blob) (void)hipFree(ps->blob);
+    if (ps->bufA) (void)hipFree(ps->bufA);
+    if (ps->bufB) (void)hipFree(ps->bufB);
+    delete ps;
+}
+
+template <int W>
+static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads, const u32 *d_off, u32 stride,
+                    const u64 *d_keys, u64 nkeys_in, u64 nkeys_bound, bool from_empty) {
+    gk_ctx *ctx = m->ctx;
+    Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1};
+    PartArrays a;
+    if (int rc = part_prepare(m, ps, nkeys_bound, &a, true)) return rc;
+    const u32 nb1 = 1u << m->lnb1;
+    const u64 nseg = t.nseg();
+    const int cu8 = ctx->cu_count * 8;
+    // P1 + prefix + P2
+    if (d_rec) {
+        const u64 ntiles = (nreads + TILE_READS - 1) / TILE_READS;
+        const int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)cu8);
+        hipLaunchKernelGGL(k_part_hist1_reads<W>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k, t, a.hist1, m->d_ctr);
+        hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(256), 0, ctx->stream, a, nb1);
+        hipLaunchKernelGGL(k_part_scatter1_reads<W>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k, t,
+                           a.l1_base, a.cursor1, ps->bufA);
+    } else {
+        const int grid = (int)std::min<u64>(std::max<u64>((nkeys_in + BLOCK - 1) / BLOCK, 1), (u64)cu8);
+        hipLaunchKernelGGL(k_part_hist1_keys<W>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_keys, nkeys_in, t, a.hist1);
+        hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(256), 0, ctx->stream, a, nb1);
+        const int g2 = (int)std::min<u64>(std::max<u64>((nkeys_in + TILE2 - 1) / TILE2, 1), (u64)ctx->cu_count * 4);
+        hipLaunchKernelGGL(k_part_scatter1_keys<W>, dim3(g2), dim3(PBLOCK), 0, ctx->stream, d_keys, nkeys_in, t, a.l1_base, a.cursor1, ps->bufA);
+    }
+    GK_HIP(ctx, hipGetLastError());
+    // P3 + prefix + P4
+    const u64 max_chunks = nkeys_bound / TILE2 + 257;
+    const int gchunks = (int)std::min<u64>(max_chunks, (u64)ctx->cu_count * 4);
+    const u64 *fine_keys = ps->bufB;
+    hipLaunchKernelGGL(k_part_hist2<W>, dim3(gchunks), dim3(PBLOCK), m->nb2 * 4, ctx->stream, ps->bufA, t, a, max_chunks);
+    hipLaunchKernelGGL(k_part_prefix2, dim3(nb1), dim3(256), 0, ctx->stream, a, nb1, m->nb2);
+    hipLaunchKernelGGL(k_part_scatter2<W>, dim3(gchunks), dim3(PBLOCK), m->nb2 * 12, ctx->stream, ps->bufA, t, a, max_chunks, ps->bufB);
+    GK_HIP(ctx, hipGetLastError());
+    // P5
+    const size_t lds = ((size_t)1 << SegBits<W>::value) * sizeof(Slot<W>) + 16;
+    if (!ps->lds_attr_set) {
+        GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_seg_insert<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ps->lds_attr_set = true;
+    }
+    const int gseg = (int)std::min<u64>(nseg, (u64)ctx->cu_count * 2 * 8);
+    hipLaunchKernelGGL(k_seg_insert<W>, dim3(gseg), dim3(PBLOCK), lds, ctx->stream, t, fine_keys, a, from_empty ? 1 : 0, m->d_ctr);
+    GK_HIP(ctx, hipGetLastError());
+    // failures (a segment filled up): grow, then replay those buckets through the direct path
+    u32 n_failed = 0;
+    GK_HIP(ctx, hipMemcpyAsync(&n_failed, a.n_failed, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (int rc = map_sync_counters(m)) return rc;
+    if (n_failed) {
+        std::vector<u32> failed(n_failed);
+        std::vector<unsigned long long> fb(nseg + 1);
+        GK_HIP(ctx, hipMemcpy(failed.data(), a.failed, n_failed * 4ull, hipMemcpyDeviceToHost));
+        GK_HIP(ctx, hipMemcpy(fb.data(), a.fine_base, (nseg + 1) * 8, hipMemcpyDeviceToHost));
+        u64 total = 0;
+        for (u32 s : failed) total += fb[s + 1] - fb[s];
+        if (int rc = map_reserve(m, std::max<u64>(total, m->capacity / 2))) return rc;
+        for (u32 s : failed) {
+            if (int rc = map_add_keys_direct(m, fine_keys + fb[s] * m->W, fb[s + 1] - fb[s])) return rc;
+        }
+    }
+    return GK_OK;
+}
+
+int part_count(gk_map *m, PartScratch **pps, const uint8_t *d_rec, u64 nreads, const u32 *d_off, u32 stride, const u64 *d_keys,
+               u64 nkeys_in, u64 nkeys_bound, bool from_empty) {
+    if (!*pps) *pps = new PartScratch();
+    if (m->W == 1) return part_run<1>(m, *pps, d_rec, nreads, d_off, stride, d_keys, nkeys_in, nkeys_bound, from_empty);
+    return part_run<2>(m, *pps, d_rec, nreads, d_off, stride, d_keys, nkeys_in, nkeys_bound, from_empty);
+}
+
+bool part_supported(const gk_map *m) { return m->nb2 <= MAX_NB2; }
+
+}  // namespace gk

@@ -16,18 +16,6 @@ using namespace gk;
 
 static constexpr int MAX_PARTS = 64;
 
-// Walk every window of a staged tile; f(kmer) is called once per window by the lane that owns it.
-template <int W, class F>
-__device__ __forceinline__ void for_each_window(const u32 *tile, const uint8_t *tb, u64 a0, u64 r0, int nr, u32 stride, int k, F f) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int r = wave; r < nr; r += BLOCK / 64) {
-        const u32 ro = (u32)((r0 + r) * stride - a0);
-        const int nk = (int)tb[ro] - k + 1;
-        const u32 bit0 = (ro + 1) * 8;
-        for (int p = lane; p < nk; p += 64) f(tile_kmer(tile, bit0 + 2 * p, k, (Kmer<W> *)nullptr));
-    }
-}
-
 // pass 1: how many canonical k-mers go to each owner
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_shard_count(const uint8_t *__restrict__ rec, u64 nreads, u32 stride, int k, int P,
@@ -42,7 +30,7 @@ __global__ __launch_bounds__(BLOCK) void k_shard_count(const uint8_t *__restrict
         __syncthreads();
         const u64 a0 = stage_tile(tile, rec, r0 * stride, (r0 + nr) * stride);
         __syncthreads();
-        for_each_window<W>(tile, reinterpret_cast<const uint8_t *>(tile), a0, r0, nr, stride, k, [&](Kmer<W> x) {
+        for_each_window<W>(tile, a0, r0, nr, nullptr, stride, k, [&](Kmer<W> x) {
             atomicAdd(&hist[owner_of(x, k, P)], 1u);
         });
     }
@@ -66,12 +54,11 @@ __global__ __launch_bounds__(BLOCK) void k_shard_scatter(const uint8_t *__restri
         if (threadIdx.x < MAX_PARTS) { hist[threadIdx.x] = 0; rank[threadIdx.x] = 0; }
         const u64 a0 = stage_tile(tile, rec, r0 * stride, (r0 + nr) * stride);
         __syncthreads();
-        const uint8_t *tb = reinterpret_cast<const uint8_t *>(tile);
-        for_each_window<W>(tile, tb, a0, r0, nr, stride, k, [&](Kmer<W> x) { atomicAdd(&hist[owner_of(x, k, P)], 1u); });
+        for_each_window<W>(tile, a0, r0, nr, nullptr, stride, k, [&](Kmer<W> x) { atomicAdd(&hist[owner_of(x, k, P)], 1u); });
         __syncthreads();
         if (threadIdx.x < P && hist[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursors[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
         __syncthreads();
-        for_each_window<W>(tile, tb, a0, r0, nr, stride, k, [&](Kmer<W> x) {
+        for_each_window<W>(tile, a0, r0, nr, nullptr, stride, k, [&](Kmer<W> x) {
             Kmer<W> y = canonical(x, k);                 // FreqFilter.scala:31-32, done by the sender
             int p = owner_of(x, k, P);                   // same owner for x and rc(x)
             u64 o = base[p] + atomicAdd(&rank[p], 1u);

@@ -284,13 +284,28 @@ int map_reserve(gk_map *m, uint64_t extra_keys) {
     return map_sync_counters(m);
 }
 
+int map_materialize(gk_map *m) {
+    if (!m->pending_clear) return GK_OK;
+    gk_ctx *ctx = m->ctx;
+    int grid = grid_for(ctx, m->capacity, BLOCK * 4);
+    if (m->W == 1) hipLaunchKernelGGL(k_clear<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (Slot<1> *)m->slots, m->capacity);
+    else hipLaunchKernelGGL(k_clear<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (Slot<2> *)m->slots, m->capacity);
+    GK_HIP(ctx, hipGetLastError());
+    m->pending_clear = false;
+    return GK_OK;
+}
+
 }  // namespace gk
 
-static int check_map(const gk_map *m) {
+static int check_map_lazy(const gk_map *m) {       // does not touch the slots
     if (!m || !m->ctx) return fail(nullptr, GK_E_INVALID, "null map handle");
     hipError_t e = hipSetDevice(m->ctx->device);
     if (e != hipSuccess) return hip_fail(m->ctx, e, "hipSetDevice");
     return GK_OK;
+}
+static int check_map(gk_map *m) {                  // slots must be valid afterwards
+    if (int rc = check_map_lazy(m)) return rc;
+    return map_materialize(m);
 }
 
 extern "C" {
@@ -404,20 +419,28 @@ void gk_map_destroy(gk_map *m) {
     if (m->d_ctr) (void)hipFree(m->d_ctr);
     if (m->d_stage) (void)hipFree(m->d_stage);
     if (m->d_offsets) (void)hipFree(m->d_offsets);
+    part_scratch_free(m->part);
     delete m;
 }
 
 int gk_map_k(const gk_map *m) { return m ? m->k : 0; }
 
+int gk_map_set_insert_path(gk_map *m, int path) {
+    if (int rc = check_map_lazy(m)) return rc;
+    if (path < 0 || path > 2) return fail(m->ctx, GK_E_INVALID, "insert path must be 0 (auto), 1 (direct) or 2 (partitioned)");
+    if (path == 2 && !part_supported(m)) return fail(m->ctx, GK_E_INVALID, "table too large for the partitioned path");
+    m->insert_path = path;
+    return GK_OK;
+}
+
 int gk_map_clear(gk_map *m) {
-    if (int rc = check_map(m)) return rc;
+    if (int rc = check_map_lazy(m)) return rc;
     gk_ctx *ctx = m->ctx;
-    int grid = grid_for(ctx, m->capacity, BLOCK * 4);
-    if (m->W == 1) hipLaunchKernelGGL(k_clear<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (Slot<1> *)m->slots, m->capacity);
-    else hipLaunchKernelGGL(k_clear<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (Slot<2> *)m->slots, m->capacity);
-    GK_HIP(ctx, hipGetLastError());
+    // Deferred: the next partitioned insert rebuilds every segment from EMPTY without reading it;
+    // anything else materialises the clear first (map_materialize).
     GK_HIP(ctx, hipMemsetAsync(m->d_ctr, 0, sizeof(Counters), ctx->stream));
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    m->pending_clear = true;
     m->size = 0;
     m->tombstones = 0;
     m->total_occurrences = 0;
@@ -425,14 +448,14 @@ int gk_map_clear(gk_map *m) {
 }
 
 int gk_map_size(gk_map *m, uint64_t *n) {
-    if (int rc = check_map(m)) return rc;
+    if (int rc = check_map_lazy(m)) return rc;
     if (!n) return fail(m->ctx, GK_E_INVALID, "gk_map_size: n is NULL");
     *n = m->size;
     return GK_OK;
 }
 
 int gk_map_slots(gk_map *m, uint64_t *slots) {
-    if (int rc = check_map(m)) return rc;
+    if (int rc = check_map_lazy(m)) return rc;
     if (!slots) return fail(m->ctx, GK_E_INVALID, "gk_map_slots: slots is NULL");
     *slots = m->capacity;
     return GK_OK;
@@ -456,6 +479,7 @@ static int launch_count(gk_map *m, const uint8_t *d_rec, u64 nreads, const u32 *
     float ms = 0.f;
     GK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     m->last_count_ms += ms;
+    m->direct_launches++;
     return GK_OK;
 }
 
@@ -471,6 +495,35 @@ static int read_occ_counter(gk_map *m, uint64_t *occ) {
     return GK_OK;
 }
 
+// Direct path: ~130 B of HBM traffic per occurrence (one 64-B sector read + one 64-B atomic,
+// profiles/r01/pmc_count_reads_v2.json).  Partitioned path: ~40 B per occurrence per key word of
+// streaming plus the table itself streamed out (and in, unless it is known to be empty).
+static bool use_partitioned(const gk_map *m, u64 occ) {
+    if (m->insert_path == 1 || !part_supported(m)) return false;
+    if (m->insert_path == 2) return true;
+    const double tb = (double)m->capacity * (double)slot_bytes(m->W);
+    const double cost_direct = (double)occ * 130.0 + (m->pending_clear ? tb : 0.0);
+    const double cost_part = (double)occ * 40.0 * m->W + tb * (m->pending_clear ? 1.0 : 2.0) + 3e8;
+    return cost_part < cost_direct;
+}
+
+// partitioned launch over device records or device keys, timed with the same events as launch_count
+static int launch_partitioned(gk_map *m, const uint8_t *d_rec, u64 nreads, const u32 *d_off, u32 stride, const u64 *d_keys,
+                              u64 nkeys_in, u64 bound) {
+    gk_ctx *ctx = m->ctx;
+    GK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    const bool from_empty = m->pending_clear;
+    m->pending_clear = false;
+    if (int rc = part_count(m, &m->part, d_rec, nreads, d_off, stride, d_keys, nkeys_in, bound, from_empty)) return rc;
+    GK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    GK_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    GK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    m->last_count_ms += ms;
+    m->part_launches++;
+    return GK_OK;
+}
+
 // how many reads (of nk windows each) may go into one launch without risking the load limit
 static u64 reads_per_launch(gk_map *m, u64 nk) {
     if (nk == 0) return ~0ull;
@@ -481,7 +534,7 @@ static u64 reads_per_launch(gk_map *m, u64 nk) {
 }
 
 int gk_map_count_reads_dev(gk_map *m, const void *dev_records, uint64_t nreads, int read_len, uint64_t *occurrences) {
-    if (int rc = check_map(m)) return rc;
+    if (int rc = check_map_lazy(m)) return rc;
     gk_ctx *ctx = m->ctx;
     if (occurrences) *occurrences = 0;
     if (!dev_records && nreads) return fail(ctx, GK_E_INVALID, "gk_map_count_reads_dev: null records");
@@ -496,8 +549,14 @@ int gk_map_count_reads_dev(gk_map *m, const void *dev_records, uint64_t nreads, 
     u64 done = 0;
     while (done < nreads) {
         u64 chunk = std::min(nreads - done, reads_per_launch(m, nk));
-        if (int rc = map_reserve(m, chunk * nk)) return rc;
-        if (int rc = launch_count(m, rec + done * stride, chunk, nullptr, stride)) return rc;
+        if (nk && use_partitioned(m, chunk * nk)) {
+            if (!m->pending_clear) { if (int rc = map_reserve(m, chunk * nk)) return rc; }
+            if (int rc = launch_partitioned(m, rec + done * stride, chunk, nullptr, stride, nullptr, 0, chunk * nk)) return rc;
+        } else {
+            if (int rc = map_materialize(m)) return rc;
+            if (int rc = map_reserve(m, chunk * nk)) return rc;
+            if (int rc = launch_count(m, rec + done * stride, chunk, nullptr, stride)) return rc;
+        }
         done += chunk;
     }
     uint64_t occ = 0;
@@ -509,7 +568,7 @@ int gk_map_count_reads_dev(gk_map *m, const void *dev_records, uint64_t nreads, 
 }
 
 int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nreads, uint64_t *occurrences) {
-    if (int rc = check_map(m)) return rc;
+    if (int rc = check_map_lazy(m)) return rc;
     gk_ctx *ctx = m->ctx;
     if (occurrences) *occurrences = 0;
     if (!bin && nreads) return fail(ctx, GK_E_INVALID, "gk_map_count_reads: null stream");
@@ -544,7 +603,9 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
         offs.push_back((u32)(pos - chunk_begin));
         const size_t cbytes = pos - chunk_begin;
         const u64 creads = r - r_begin;
-        if (int rc = map_reserve(m, occ)) return rc;
+        const bool partitioned = occ && use_partitioned(m, occ);
+        if (!partitioned) { if (int rc = map_materialize(m)) return rc; }
+        if (!(partitioned && m->pending_clear)) { if (int rc = map_reserve(m, occ)) return rc; }
         if (m->stage_bytes < cbytes + 64) {
             if (m->d_stage) GK_HIP(ctx, hipFree(m->d_stage));
             m->d_stage = nullptr;
@@ -561,7 +622,11 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
         }
         GK_HIP(ctx, hipMemcpyAsync(m->d_stage, bin + chunk_begin, cbytes, hipMemcpyHostToDevice, ctx->stream));
         GK_HIP(ctx, hipMemcpyAsync(m->d_offsets, offs.data(), offs.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
-        if (int rc = launch_count(m, (const uint8_t *)m->d_stage, creads, (const u32 *)m->d_offsets, 0)) return rc;
+        if (partitioned) {
+            if (int rc = launch_partitioned(m, (const uint8_t *)m->d_stage, creads, (const u32 *)m->d_offsets, 0, nullptr, 0, occ)) return rc;
+        } else {
+            if (int rc = launch_count(m, (const uint8_t *)m->d_stage, creads, (const u32 *)m->d_offsets, 0)) return rc;
+        }
     }
     uint64_t occ = 0;
     if (int rc = read_occ_counter(m, &occ)) return rc;
@@ -591,11 +656,40 @@ static int add_keys_dev(gk_map *m, const u64 *d_keys, const i32 *d_counts, u64 n
     return GK_OK;
 }
 
+}  // extern "C"
+namespace gk {
+int map_add_keys_direct(gk_map *m, const uint64_t *d_keys, uint64_t n) { return n ? add_keys_dev(m, d_keys, nullptr, n) : GK_OK; }
+}
+extern "C" {
+
 int gk_map_update_inc_dev(gk_map *m, const void *dev_keys, uint64_t n) {
-    if (int rc = check_map(m)) return rc;
+    if (int rc = check_map_lazy(m)) return rc;
     if (!dev_keys && n) return fail(m->ctx, GK_E_INVALID, "gk_map_update_inc_dev: null keys");
     if (n == 0) return GK_OK;
-    return add_keys_dev(m, (const u64 *)dev_keys, nullptr, n);
+    m->last_count_ms = 0.f;
+    m->last_count_occ = n;
+    const u64 *keys = (const u64 *)dev_keys;
+    u64 done = 0;
+    while (done < n) {
+        const u64 chunk = std::min(n - done, reads_per_launch(m, 1));
+        if (use_partitioned(m, chunk)) {
+            if (!m->pending_clear) { if (int rc = map_reserve(m, chunk)) return rc; }
+            if (int rc = launch_partitioned(m, nullptr, 0, nullptr, 0, keys + done * m->W, chunk, chunk)) return rc;
+        } else {
+            if (int rc = map_materialize(m)) return rc;
+            gk_ctx *ctx = m->ctx;
+            GK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+            if (int rc = add_keys_dev(m, keys + done * m->W, nullptr, chunk)) return rc;
+            GK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+            GK_HIP(ctx, hipEventSynchronize(ctx->ev1));
+            float ms = 0.f;
+            GK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            m->last_count_ms += ms;
+            m->direct_launches++;
+        }
+        done += chunk;
+    }
+    return GK_OK;
 }
 
 // validate that every key fits in 2k bits — the C-ABI form of `assert(key.length == k)`
@@ -764,22 +858,23 @@ int gk_map_export(gk_map *m, uint64_t *lo, uint64_t *hi, int32_t *counts, uint64
 }
 
 int gk_map_stats(gk_map *m, char *json, size_t cap) {
-    if (int rc = check_map(m)) return rc;
+    if (int rc = check_map_lazy(m)) return rc;
     if (!json || cap == 0) return fail(m->ctx, GK_E_INVALID, "null stats buffer");
     int w = snprintf(json, cap,
                      "{\"k\":%d,\"key_words\":%d,\"slot_bytes\":%zu,\"slots\":%llu,\"size\":%llu,\"tombstones\":%llu,"
                      "\"load\":%.6f,\"occurrences\":%llu,\"grows\":%llu,\"last_count_kernel_ms\":%.6f,"
-                     "\"last_count_occurrences\":%llu,\"device\":%d,\"cu_count\":%d}",
+                     "\"last_count_occurrences\":%llu,\"partitioned_launches\":%llu,\"direct_launches\":%llu,\"device\":%d,\"cu_count\":%d}",
                      m->k, m->W, slot_bytes(m->W), (unsigned long long)m->capacity, (unsigned long long)m->size,
                      (unsigned long long)m->tombstones, m->capacity ? (double)m->size / (double)m->capacity : 0.0,
                      (unsigned long long)m->total_occurrences, (unsigned long long)m->grows, m->last_count_ms,
-                     (unsigned long long)m->last_count_occ, m->ctx->device, m->ctx->cu_count);
+                     (unsigned long long)m->last_count_occ, (unsigned long long)m->part_launches,
+                     (unsigned long long)m->direct_launches, m->ctx->device, m->ctx->cu_count);
     if (w < 0 || (size_t)w >= cap) return fail(m->ctx, GK_E_CAPACITY, "stats buffer too small");
     return GK_OK;
 }
 
 int gk_map_last_count_kernel(gk_map *m, float *ms, uint64_t *occurrences) {
-    if (int rc = check_map(m)) return rc;
+    if (int rc = check_map_lazy(m)) return rc;
     if (ms) *ms = m->last_count_ms;
     if (occurrences) *occurrences = m->last_count_occ;
     return GK_OK;

@@ -40,9 +40,23 @@ __device__ __forceinline__ u64 stage_tile(u32 *tile, const uint8_t *rec, u64 gb,
     u32 nvec = (u32)((a1 - a0) >> 4);
     const uint4 *src = reinterpret_cast<const uint4 *>(rec + (i64)a0);
     uint4 *dst = reinterpret_cast<uint4 *>(tile);
-    for (u32 i = threadIdx.x; i < nvec; i += BLOCK) dst[i] = src[i];
+    for (u32 i = threadIdx.x; i < nvec; i += blockDim.x) dst[i] = src[i];
     return a0;
 }
 
+
+// Walk every window of a staged tile: f(kmer) is called once per window by the lane that owns it
+// (waves take reads round-robin, lanes take window positions).  offsets == nullptr: fixed stride.
+template <int W, class F>
+__device__ __forceinline__ void for_each_window(const u32 *tile, u64 a0, u64 r0, int nr, const u32 *offsets, u32 stride, int k, F f) {
+    const uint8_t *tb = reinterpret_cast<const uint8_t *>(tile);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    for (int r = wave; r < nr; r += nwaves) {
+        const u32 ro = (u32)((offsets ? (u64)offsets[r0 + r] : (r0 + r) * stride) - a0);
+        const int nk = (int)tb[ro] - k + 1;           // [len:u8]; reads shorter than k are skipped
+        const u32 bit0 = (ro + 1) * 8;
+        for (int p = lane; p < nk; p += 64) f(tile_kmer(tile, bit0 + 2 * p, k, (Kmer<W> *)nullptr));
+    }
+}
 
 }  // namespace gk

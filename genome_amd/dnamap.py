@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import json
+import os
 
 import numpy as np
 
@@ -84,6 +85,14 @@ class HipDNAMap:
         self.ctx, self.k = ctx, k
         self.h = L.vp()
         L.check(L.lib().gk_map_create(ctx.h, k, capacity_hint, C.byref(self.h)), ctx.h)
+        forced = os.environ.get("GENOME_AMD_INSERT_PATH")     # test hook: "direct" | "partitioned"
+        if forced:
+            self.set_insert_path(forced)
+
+    def set_insert_path(self, path):
+        """'auto' | 'direct' (global atomics) | 'partitioned' (LDS segment build): same results."""
+        code = {"auto": 0, "direct": 1, "partitioned": 2}.get(path, path)
+        L.check(L.lib().gk_map_set_insert_path(self.h, int(code)), self.ctx.h)
 
     def close(self):
         if self.h:

@@ -72,6 +72,10 @@ int gk_map_create(gk_ctx *ctx, int k, uint64_t capacity_hint, gk_map **out);
 void gk_map_destroy(gk_map *m);
 int gk_map_k(const gk_map *m);
 int gk_map_clear(gk_map *m);                               /* back to an empty table of the same capacity */
+/* How batches are inserted.  0 = auto (cost model), 1 = direct: one global CAS/add per k-mer
+ * (k_count_reads / k_add_keys), 2 = partitioned: radix-partition the batch by 64-KiB table segment
+ * and build each segment in LDS (gk_partition.hip).  Results are identical; only speed differs. */
+int gk_map_set_insert_path(gk_map *m, int path);
 int gk_map_size(gk_map *m, uint64_t *n);                   /* DNAMap.size :50 (live keys) */
 int gk_map_slots(gk_map *m, uint64_t *slots);              /* current table capacity in slots */
 

@@ -235,3 +235,71 @@ def test_full_size_c2_properties(ctx):
     m.deleteAll_lt(3)
     assert m.size() == ge3
     m.close(); ctx.free(d)
+
+
+@pytest.mark.parametrize("k,L_,n,hint", [(31, 150, 40000, 0), (31, 150, 40000, 6_000_000), (21, 100, 30000, 100), (55, 150, 30000, 0),
+                                          (63, 120, 20000, 3_000_000), (11, 60, 50000, 0)])
+def test_partitioned_path_equals_direct_and_oracle(ctx, k, L_, n, hint):
+    """The LDS segment-build path (gk_partition.hip) and the global-atomic path must produce the
+    same table as the oracle: from empty, on top of existing content, after a deferred clear, and
+    for routed key arrays (owner side of the all-to-all)."""
+    rec = synth.reads_mode_g(n, L_, 60000, 0.01, config_id=k)
+    d = ctx.alloc(rec.size + 64)
+    ctx.upload(d, rec)
+    ref = O.PMap(k, 1)
+    occ = ref.count_reads(rec.tobytes(), n)
+    want1 = ref.export_sorted()
+    tables = {}
+    for path in ("direct", "partitioned"):
+        m = HipDNAMap(ctx, k, hint)
+        m.set_insert_path(path)
+        assert m.count_reads_dev(d, n, L_) == occ
+        assert_same_table(m.sorted_items(), want1)
+        assert m.size() == ref.size()
+        m.count_reads_dev(d, n // 2, L_)                       # second batch on top of a non-empty table
+        tables[path] = m
+    ref.count_reads(rec[:n // 2].tobytes(), n // 2)
+    want2 = ref.export_sorted()
+    for path, m in tables.items():
+        assert_same_table(m.sorted_items(), want2)
+        st = m.stats()
+        assert (st["partitioned_launches"] > 0) == (path == "partitioned"), st
+        m.clear()                                              # deferred clear, then rebuild from empty
+        assert m.size() == 0
+        assert m.count_reads(rec.tobytes(), n) == occ          # host stream entry point
+        assert_same_table(m.sorted_items(), want1)
+        m.clear()
+        assert m.apply_batch((want1[0][:5], want1[1][:5])).tolist() == [-1] * 5   # a lookup materialises the clear
+    # routed keys: shard into 1 partition = plain canonical key stream, insert through both paths
+    W = 1 if k <= 32 else 2
+    nk = n * (L_ - k + 1)
+    dk = ctx.alloc(nk * 8 * W)
+    counts = ctx.shard_reads(k, d, n, L_, 1, dk, nk)
+    assert int(counts[0]) == occ
+    for path, m in tables.items():
+        m.clear()
+        m.update_inc_dev(dk, nk)
+        assert_same_table(m.sorted_items(), want1)
+        m.deleteAll_lt(2)
+        m.close()
+    ctx.free(dk); ctx.free(d)
+
+
+def test_partitioned_path_heavy_hitters_and_tiny_batches(ctx):
+    """Skew: one k-mer repeated 300k times lands in ONE segment bucket; empty and 1-read batches."""
+    k = 21
+    reads = ["A" * 150] * 3000 + ["AG" * 75] * 2000
+    rnd = random.Random(4)
+    reads += ["".join(rnd.choice("AGCT") for _ in range(150)) for _ in range(3000)]
+    binb = dna.reads_to_bin(reads)
+    ref = O.PMap(k, 1)
+    ref.count_reads(binb, len(reads))
+    m = HipDNAMap(ctx, k)
+    m.set_insert_path("partitioned")
+    assert m.count_reads(binb, len(reads)) == len(reads) * 130
+    assert_same_table(m.sorted_items(), ref.export_sorted())
+    assert m.count_reads(b"", 0) == 0
+    one = dna.reads_to_bin(["AGCT" * 10])
+    m.count_reads(one, 1); ref.count_reads(one, 1)
+    assert_same_table(m.sorted_items(), ref.export_sorted())
+    m.close()
