@@ -108,7 +108,7 @@ def main():
     G, err = 5_000_000 * world, 0.01
     ctx.synth_reads(rec.data_ptr(), n, L, args.mode, 2, rank * n, G, err)     # config_id 2 = C2
     occ_rank = n * nk
-    m = HipDNAMap(ctx, k, int(occ_rank * 1.05))
+    m = HipDNAMap(ctx, k, int(occ_rank * 1.05 * float(os.environ.get('GK_HINT_SCALE', '1'))))
     m.set_insert_path(args.insert_path)
     if world > 1:
         send = torch.empty(occ_rank * W, dtype=torch.int64, device=dev)

@@ -193,7 +193,7 @@ GK_HD Kmer<2> from_stored(Stored<2> s) { return Kmer<2>{s.w0 | (s.w1 << 63), s.w
 GK_D Stored<1> load_stored(const Slot<1> *s) { return Stored<1>{s->w0}; }
 GK_D Stored<2> load_stored(const Slot<2> *s) { return Stored<2>{s->w0, s->w1}; }
 
-// The table is an array of SEGMENTS of 2^seg_bits slots (64 KiB each: 4096 16-B slots or 2048 32-B
+// The table is an array of SEGMENTS of 2^seg_bits slots (32 KiB each: 2048 16-B slots or 1024 32-B
 // slots), and linear probing wraps INSIDE a segment.  A segment is the unit one workgroup can hold
 // in LDS, which is what lets a batch be radix-partitioned by segment and built there with LDS
 // atomics and coalesced HBM traffic (gk_partition.hip) instead of one global atomic per key.
@@ -201,8 +201,11 @@ GK_D Stored<2> load_stored(const Slot<2> *s) { return Stored<2>{s->w0, s->w1}; }
 // fine = 32 middle bits scaled to nb2 — so the number of segments need not be a power of two and
 // the table can be sized to the load factor wanted.  Start position = low seg_bits bits.
 template <int W> struct SegBits;
-template <> struct SegBits<1> { static constexpr u32 value = 12; };
-template <> struct SegBits<2> { static constexpr u32 value = 11; };
+#ifndef GK_SEG_BITS1
+#define GK_SEG_BITS1 11
+#endif
+template <> struct SegBits<1> { static constexpr u32 value = GK_SEG_BITS1; };
+template <> struct SegBits<2> { static constexpr u32 value = GK_SEG_BITS1 - 1; };
 
 template <int W> struct Table {
     Slot<W> *slots;

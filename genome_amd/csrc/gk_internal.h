@@ -59,7 +59,7 @@ int hip_fail(const gk_ctx *ctx, hipError_t e, const char *what);
 inline bool k_supported(int k) { return (k >= 2 && k <= 31) || (k >= 34 && k <= 63); }
 inline int words_for_k(int k) { return k <= 32 ? 1 : 2; }
 inline size_t slot_bytes(int W) { return W == 1 ? 16 : 32; }
-inline uint32_t seg_bits_for(int W) { return W == 1 ? 12u : 11u; }
+inline uint32_t seg_bits_for(int W) { return W == 1 ? gk::SegBits<1>::value : gk::SegBits<2>::value; }
 // segment geometry for at least `want_slots` slots: nb1 = 2^lnb1 <= 256 L1 buckets x nb2 fine buckets
 inline void plan_segments(int W, uint64_t want_slots, uint32_t *nb2, uint32_t *lnb1, uint64_t *capacity) {
     const uint64_t S = 1ull << seg_bits_for(W);

@@ -27,6 +27,7 @@
 // Algorithmic bytes per occurrence (k<=31): P1 0.31, P2 0.31 + 8, P3 8, P4 8 + 8, P5 8 + slot
 // traffic (32 B of table per slot streamed in and out, or 16 B out only from empty).
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 
 #include "gk_internal.h"
@@ -35,7 +36,9 @@
 using namespace gk;
 
 static constexpr int PBLOCK = 512;          // threads of the key-streaming kernels
-static constexpr int KEYS_PER_THREAD = 8;
+static constexpr int KEYS_PER_THREAD = 16;
+static constexpr int PTILE_READS = 256;     // reads per LDS tile in P1/P2 (runs of ~120 keys per bucket)
+static constexpr int PTILE_WORDS = PTILE_READS * 65 / 4 + 64;
 static constexpr int TILE2 = PBLOCK * KEYS_PER_THREAD;   // keys per chunk in P3/P4
 static constexpr u32 MAX_NB2 = 4096;        // LDS bound in P3/P4 (12 B per fine bucket, 48 KiB)
 
@@ -64,16 +67,16 @@ template <int W> __device__ __forceinline__ void store_key(u64 *keys, u64 i, Kme
 // P1 / P2 from a read stream
 // ---------------------------------------------------------------------------------------------
 template <int W>
-__global__ __launch_bounds__(BLOCK) void k_part_hist1_reads(const uint8_t *__restrict__ rec, u64 nreads, const u32 *__restrict__ offsets,
+__global__ __launch_bounds__(PBLOCK) void k_part_hist1_reads(const uint8_t *__restrict__ rec, u64 nreads, const u32 *__restrict__ offsets,
                                                             u32 stride, int k, Table<W> t, unsigned long long *hist1, Counters *ctr) {
-    __shared__ __attribute__((aligned(16))) u32 tile[TILE_WORDS];
+    __shared__ __attribute__((aligned(16))) u32 tile[PTILE_WORDS];
     __shared__ u32 hist[256];
-    hist[threadIdx.x] = 0;
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
     u32 occ = 0;
-    const u64 ntiles = (nreads + TILE_READS - 1) / TILE_READS;
+    const u64 ntiles = (nreads + PTILE_READS - 1) / PTILE_READS;
     for (u64 tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
-        const u64 r0 = tl * TILE_READS;
-        const int nr = (int)min((u64)TILE_READS, nreads - r0);
+        const u64 r0 = tl * PTILE_READS;
+        const int nr = (int)min((u64)PTILE_READS, nreads - r0);
         const u64 gb = offsets ? (u64)offsets[r0] : r0 * stride, ge = offsets ? (u64)offsets[r0 + nr] : (r0 + nr) * stride;
         __syncthreads();
         const u64 a0 = stage_tile(tile, rec, gb, ge);
@@ -84,33 +87,38 @@ __global__ __launch_bounds__(BLOCK) void k_part_hist1_reads(const uint8_t *__res
         });
     }
     __syncthreads();
-    if (hist[threadIdx.x]) atomicAdd(&hist1[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
-    // occurrences: wave-reduce then one atomic per wave
+    if (threadIdx.x < 256 && hist[threadIdx.x]) atomicAdd(&hist1[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+    // occurrences: wave-reduce, then LDS, then one atomic per workgroup
     for (int d = 32; d; d >>= 1) occ += __shfl_down(occ, d);
-    if ((threadIdx.x & 63) == 0 && occ) atomicAdd(&ctr->occurrences, (unsigned long long)occ);
+    __syncthreads();
+    if (threadIdx.x == 0) hist[0] = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && occ) atomicAdd(&hist[0], occ);
+    __syncthreads();
+    if (threadIdx.x == 0 && hist[0]) atomicAdd(&ctr->occurrences, (unsigned long long)hist[0]);
 }
 
 template <int W>
-__global__ __launch_bounds__(BLOCK) void k_part_scatter1_reads(const uint8_t *__restrict__ rec, u64 nreads, const u32 *__restrict__ offsets,
+__global__ __launch_bounds__(PBLOCK) void k_part_scatter1_reads(const uint8_t *__restrict__ rec, u64 nreads, const u32 *__restrict__ offsets,
                                                                u32 stride, int k, Table<W> t, const unsigned long long *l1_base,
                                                                unsigned long long *cursor1, u64 *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) u32 tile[TILE_WORDS];
+    __shared__ __attribute__((aligned(16))) u32 tile[PTILE_WORDS];
     __shared__ u32 hist[256];
     __shared__ unsigned long long base[256];
-    const u64 ntiles = (nreads + TILE_READS - 1) / TILE_READS;
+    const u64 ntiles = (nreads + PTILE_READS - 1) / PTILE_READS;
     for (u64 tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
-        const u64 r0 = tl * TILE_READS;
-        const int nr = (int)min((u64)TILE_READS, nreads - r0);
+        const u64 r0 = tl * PTILE_READS;
+        const int nr = (int)min((u64)PTILE_READS, nreads - r0);
         const u64 gb = offsets ? (u64)offsets[r0] : r0 * stride, ge = offsets ? (u64)offsets[r0 + nr] : (r0 + nr) * stride;
         __syncthreads();
-        hist[threadIdx.x] = 0;
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
         const u64 a0 = stage_tile(tile, rec, gb, ge);
         __syncthreads();
         for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, [&](Kmer<W> x) {
             atomicAdd(&hist[seg_l1(t, slot_hash(canonical(x, k)))], 1u);
         });
         __syncthreads();
-        {
+        if (threadIdx.x < 256) {
             const u32 c = hist[threadIdx.x];
             if (c) base[threadIdx.x] = l1_base[threadIdx.x] + atomicAdd(&cursor1[threadIdx.x], (unsigned long long)c);
             hist[threadIdx.x] = 0;          // becomes the rank counter
@@ -148,12 +156,18 @@ __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u64 be
     u32 bin[KEYS_PER_THREAD];
     for (u32 b = threadIdx.x; b < nbins; b += PBLOCK) lds_hist[b] = 0;
     __syncthreads();
+    // all loads first, unconditionally (index clamped): one memory round trip per chunk instead of
+    // one per key — a load inside `if (i < cnt)` is sunk next to its use and serialises
+#pragma unroll
+    for (int j = 0; j < KEYS_PER_THREAD; j++) {
+        const u32 i = threadIdx.x + j * PBLOCK;
+        key[j] = load_key<W>(in, begin + (i < cnt ? i : cnt - 1));
+    }
 #pragma unroll
     for (int j = 0; j < KEYS_PER_THREAD; j++) {
         const u32 i = threadIdx.x + j * PBLOCK;
         bin[j] = 0xffffffffu;
         if (i < cnt) {
-            key[j] = load_key<W>(in, begin + i);
             const u64 h = slot_hash(key[j]);
             bin[j] = LEVEL == 1 ? seg_l1(t, h) : seg_fine(t, h);
             atomicAdd(&lds_hist[bin[j]], 1u);
@@ -228,8 +242,18 @@ __global__ __launch_bounds__(PBLOCK) void k_part_hist2(const u64 *__restrict__ b
         const u32 cnt = (u32)min((u64)TILE2, bsize - begin);
         for (u32 b = threadIdx.x; b < t.nb2; b += PBLOCK) lds_hist[b] = 0;
         __syncthreads();
-        for (u32 i = threadIdx.x; i < cnt; i += PBLOCK)
-            atomicAdd(&lds_hist[seg_fine(t, slot_hash(load_key<W>(bufA, a.l1_base[b1] + begin + i)))], 1u);
+        {
+            Kmer<W> key[KEYS_PER_THREAD];
+            const u64 kb = a.l1_base[b1] + begin;
+#pragma unroll
+            for (int j = 0; j < KEYS_PER_THREAD; j++) {
+                const u32 i = threadIdx.x + j * PBLOCK;
+                key[j] = load_key<W>(bufA, kb + (i < cnt ? i : cnt - 1));
+            }
+#pragma unroll
+            for (int j = 0; j < KEYS_PER_THREAD; j++)
+                if (threadIdx.x + j * PBLOCK < cnt) atomicAdd(&lds_hist[seg_fine(t, slot_hash(key[j]))], 1u);
+        }
         __syncthreads();
         for (u32 b = threadIdx.x; b < t.nb2; b += PBLOCK)
             if (lds_hist[b]) atomicAdd(&a.hist2[(u64)b1 * t.nb2 + b], lds_hist[b]);
@@ -292,20 +316,24 @@ struct LdsAdd {
     __device__ __forceinline__ void operator()(u32 *p, u32 v) const { atomicAdd(p, v); }
 };
 
+static constexpr int SBLOCK = GK_SEG_BITS1 <= 10 ? 256 : 512;                 // threads per segment workgroup
+static constexpr int SEG_KPT = (1 << GK_SEG_BITS1) / SBLOCK;                  // keys preloaded per thread
 template <int W>
-__global__ __launch_bounds__(PBLOCK) void k_seg_insert(Table<W> t, const u64 *__restrict__ keys, PartArrays a, int from_empty, Counters *ctr) {
+__global__ __launch_bounds__(SBLOCK) void k_seg_insert(Table<W> t, const u64 *__restrict__ keys, PartArrays a, int from_empty, Counters *ctr) {
     extern __shared__ uint4 lds_raw[];
     constexpr u32 S = 1u << SegBits<W>::value;
     constexpr u32 NVEC = S * sizeof(Slot<W>) / 16;
     Slot<W> *seg = reinterpret_cast<Slot<W> *>(lds_raw);
     u32 *flags = reinterpret_cast<u32 *>(lds_raw + NVEC);         // [0] claims, [1] overflow
     const u64 nseg = t.nseg();
+    u32 wg_claims = 0;      // thread 0 only: ONE global atomic per workgroup at the end (a same-address
+                            // atomic per segment caps the kernel at ~88 segments/us chip-wide)
     for (u64 s = blockIdx.x; s < nseg; s += gridDim.x) {
         const u64 kb = a.fine_base[s], ke = a.fine_base[s + 1];
         uint4 *gseg = reinterpret_cast<uint4 *>(t.slots + (s << SegBits<W>::value));
         if (kb == ke) {
             if (from_empty) {       // materialise the pending clear of a segment that gets no key
-                for (u32 i = threadIdx.x; i < NVEC; i += PBLOCK) {
+                for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) {
                     if constexpr (W == 1) gseg[i] = make_uint4(~0u, ~0u, 0u, 0u);
                     else gseg[i] = (i & 1) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
                 }
@@ -314,39 +342,57 @@ __global__ __launch_bounds__(PBLOCK) void k_seg_insert(Table<W> t, const u64 *__
         }
         __syncthreads();
         if (threadIdx.x < 2) flags[threadIdx.x] = 0;
+        // the segment's keys: issue every load now (clamped index, no branch) so that their latency
+        // overlaps the LDS fill below — one memory round trip per segment
+        const u32 nk = (u32)min(ke - kb, (u64)SBLOCK * SEG_KPT);
+        Kmer<W> key[SEG_KPT];
+#pragma unroll
+        for (int j = 0; j < SEG_KPT; j++) {
+            const u32 i = threadIdx.x + j * SBLOCK;
+            key[j] = load_key<W>(keys, kb + (i < nk ? i : nk - 1));
+        }
         if (from_empty) {
-            for (u32 i = threadIdx.x; i < NVEC; i += PBLOCK) {
+            for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) {
                 if constexpr (W == 1) lds_raw[i] = make_uint4(~0u, ~0u, 0u, 0u);
                 else lds_raw[i] = (i & 1) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
             }
         } else {
-            for (u32 i = threadIdx.x; i < NVEC; i += PBLOCK) lds_raw[i] = gseg[i];
+            for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) lds_raw[i] = gseg[i];
         }
         __syncthreads();
         u32 claims = 0;
         bool overflow = false;
-        for (u64 i = kb + threadIdx.x; i < ke; i += PBLOCK) {
-            const Kmer<W> key = load_key<W>(keys, i);
-            const int r = seg_add(seg, seg_pos<W>(slot_hash(key)), key, 1u, LdsCas(), LdsAdd());
+#pragma unroll
+        for (int j = 0; j < SEG_KPT; j++) {
+            if (threadIdx.x + j * SBLOCK < nk) {
+                const int r = seg_add(seg, seg_pos<W>(slot_hash(key[j])), key[j], 1u, LdsCas(), LdsAdd());
+                if (r < 0) overflow = true; else claims += (u32)r;
+            }
+        }
+        for (u64 i = kb + (u64)SBLOCK * SEG_KPT + threadIdx.x; i < ke; i += SBLOCK) {   // heavy buckets (repeats)
+            const Kmer<W> kx = load_key<W>(keys, i);
+            const int r = seg_add(seg, seg_pos<W>(slot_hash(kx)), kx, 1u, LdsCas(), LdsAdd());
             if (r < 0) overflow = true; else claims += (u32)r;
         }
-        if (claims) atomicAdd(&flags[0], claims);
+        for (int d = 32; d; d >>= 1) claims += __shfl_down(claims, d);
+        if ((threadIdx.x & 63) == 0 && claims) atomicAdd(&flags[0], claims);
         if (overflow) flags[1] = 1;
         __syncthreads();
         if (flags[1]) {
             // segment full: leave the HBM copy as it was (or EMPTY) and hand the bucket to the host,
             // which grows the table and replays these keys through the direct path
             if (from_empty)
-                for (u32 i = threadIdx.x; i < NVEC; i += PBLOCK) {
+                for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) {
                     if constexpr (W == 1) gseg[i] = make_uint4(~0u, ~0u, 0u, 0u);
                     else gseg[i] = (i & 1) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
                 }
             if (threadIdx.x == 0) a.failed[atomicAdd(a.n_failed, 1u)] = (u32)s;
             continue;
         }
-        for (u32 i = threadIdx.x; i < NVEC; i += PBLOCK) gseg[i] = lds_raw[i];
-        if (threadIdx.x == 0 && flags[0]) atomicAdd(&ctr->size, (unsigned long long)flags[0]);
+        for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) gseg[i] = lds_raw[i];
+        if (threadIdx.x == 0) wg_claims += flags[0];
     }
+    if (threadIdx.x == 0 && wg_claims) atomicAdd(&ctr->size, (unsigned long long)wg_claims);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -418,11 +464,11 @@ static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads
     const int cu8 = ctx->cu_count * 8;
     // P1 + prefix + P2
     if (d_rec) {
-        const u64 ntiles = (nreads + TILE_READS - 1) / TILE_READS;
-        const int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)cu8);
-        hipLaunchKernelGGL(k_part_hist1_reads<W>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k, t, a.hist1, m->d_ctr);
+        const u64 ntiles = (nreads + PTILE_READS - 1) / PTILE_READS;
+        const int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)ctx->cu_count * 4);
+        hipLaunchKernelGGL(k_part_hist1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k, t, a.hist1, m->d_ctr);
         hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(256), 0, ctx->stream, a, nb1);
-        hipLaunchKernelGGL(k_part_scatter1_reads<W>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k, t,
+        hipLaunchKernelGGL(k_part_scatter1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k, t,
                            a.l1_base, a.cursor1, ps->bufA);
     } else {
         const int grid = (int)std::min<u64>(std::max<u64>((nkeys_in + BLOCK - 1) / BLOCK, 1), (u64)cu8);
@@ -446,8 +492,8 @@ static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads
         GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_seg_insert<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ps->lds_attr_set = true;
     }
-    const int gseg = (int)std::min<u64>(nseg, (u64)ctx->cu_count * 2 * 8);
-    hipLaunchKernelGGL(k_seg_insert<W>, dim3(gseg), dim3(PBLOCK), lds, ctx->stream, t, fine_keys, a, from_empty ? 1 : 0, m->d_ctr);
+    const int gseg = (int)std::min<u64>(nseg, (u64)ctx->cu_count * 24);
+    hipLaunchKernelGGL(k_seg_insert<W>, dim3(gseg), dim3(SBLOCK), lds, ctx->stream, t, fine_keys, a, from_empty ? 1 : 0, m->d_ctr);
     GK_HIP(ctx, hipGetLastError());
     // failures (a segment filled up): grow, then replay those buckets through the direct path
     u32 n_failed = 0;

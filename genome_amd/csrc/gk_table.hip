@@ -251,8 +251,8 @@ int map_sync_counters(gk_map *m) {
     return GK_OK;
 }
 
-static constexpr double MAX_LOAD = 0.75;   // grow before a batch could exceed this
-static constexpr double TARGET_LOAD = 0.5; // load right after a grow
+static constexpr double MAX_LOAD = 0.8;     // grow before a batch could exceed this
+static constexpr double TARGET_LOAD = 0.65; // load right after sizing / a grow
 
 // ArrayDNAMap.rescale analogue: make room for `extra_keys` more distinct keys.
 int map_reserve(gk_map *m, uint64_t extra_keys) {
