@@ -114,14 +114,14 @@ def main():
         send = torch.empty(occ_rank * W, dtype=torch.int64, device=dev)
         recv = torch.empty(int(occ_rank * W * 1.5) + 1024, dtype=torch.int64, device=dev)
 
-    kernel_ms, kernel_units = [], []
+    kernel_ms, kernel_units, phase_ms = [], [], []
 
     def step():
         m.clear()
         if world == 1:
             m.count_reads_dev(rec.data_ptr(), n, L)
             ms, kocc = m.last_count_kernel()
-            kernel_ms.append(ms); kernel_units.append(kocc)
+            kernel_ms.append(ms); kernel_units.append(kocc); phase_ms.append(m.last_phase_ms())
             return
         counts = ctx.shard_reads(k, rec.data_ptr(), n, L, world, send.data_ptr(), occ_rank)
         nonlocal recv
@@ -130,7 +130,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         m.update_inc_dev(recv.data_ptr(), nrecv)
-        kernel_ms.append((time.perf_counter() - t0) * 1e3); kernel_units.append(nrecv)
+        kernel_ms.append((time.perf_counter() - t0) * 1e3); kernel_units.append(nrecv); phase_ms.append(m.last_phase_ms())
 
     def fence():
         torch.cuda.synchronize()
@@ -145,7 +145,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    kernel_ms.clear(); kernel_units.clear()
+    kernel_ms.clear(); kernel_units.clear(); phase_ms.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -164,17 +164,39 @@ def main():
 
     if rank == 0:
         ms_per_step = dt_max / args.steps * 1e3
-        avg_kernel_ms = float(np.mean(kernel_ms))
         units = float(np.mean(kernel_units))
-        if world == 1:
-            abytes = algorithmic_bytes_count_kernel(units, distinct_rank, L, k)
-            kname = "k_count_reads<1>" if W == 1 else "k_count_reads<2>"
-            timing = "HIP events on the library stream (gk_map_last_count_kernel)"
+        phases = np.mean(np.array(phase_ms), axis=0)
+        stats = m.stats()
+        partitioned = stats["partitioned_launches"] > 0
+        slot_b = 16 if W == 1 else 32
+        # ALGORITHMIC bytes of one insert+count pass, whatever kernels carry it
+        abytes = (algorithmic_bytes_count_kernel(units, distinct_rank, L, k) if world == 1
+                  else algorithmic_bytes_insert_kernel(units, distinct_rank, k))
+        if partitioned:
+            names = ["k_part_hist1", "k_part_scatter1", "k_part_hist2", "k_part_scatter2", "k_seg_insert"]
+            kernel_time_ms = float(phases.sum())
+            kname = "partitioned insert pipeline: " + " + ".join(f"{n}<{W}>" for n in names)
+            timing = "HIP events on the library stream around each phase (gk_map_last_phase_ms), summed"
+            dom = int(np.argmax(phases))
+            # what the dominant kernel itself must move: its keys in, its table segments out (+ in unless built from empty)
+            dom_bytes = {4: units * 8 * W + m.slots() * slot_b, 3: units * 16 * W, 2: units * 8 * W,
+                         1: units * (8 * W + 2.0 * L / (8 * nk)), 0: units * 2.0 * L / (8 * nk)}[dom]
+            dominant = {"kernel": f"{names[dom]}<{W}>", "ms": float(phases[dom]), "own_streaming_bytes": dom_bytes,
+                        "GB_per_s": dom_bytes / (float(phases[dom]) * 1e-3) / 1e9,
+                        "frac_of_peak": dom_bytes / (float(phases[dom]) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            phase_detail = {n: float(x) for n, x in zip(names, phases)}
         else:
-            abytes = algorithmic_bytes_insert_kernel(units, distinct_rank, k)
-            kname = "k_add_keys<1>" if W == 1 else "k_add_keys<2>"
-            timing = "host wall around the synchronous gk_map_update_inc_dev call"
+            kernel_time_ms = float(np.mean(kernel_ms))
+            kname = ("k_count_reads" if world == 1 else "k_add_keys") + f"<{W}>"
+            timing = "HIP events on the library stream (gk_map_last_count_kernel)"
+            dominant, phase_detail = None, None
+        avg_kernel_ms = kernel_time_ms
         achieved = abytes / (avg_kernel_ms * 1e-3) / 1e9
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_pipeline_v3.json" if partitioned else "pmc_count_reads_v2.json")
+        if world == 1 and args.mode == "U" and n == 1_000_000 and L == 150 and k == 31 and os.path.exists(pmc_file):
+            pj = json.load(open(pmc_file))
+            traffic = pj.get("hbm_bytes_per_launch", pj.get("k_count_reads<1>", {}).get("hbm_bytes_per_launch"))
         out = {
             "metric": "distinct k-mers/s inserted (k=31, 150bp reads)",
             "value": distinct_total / (dt_max / args.steps),
@@ -186,13 +208,16 @@ def main():
                                    + ("single-partition DNAMap kernel" if world == 1 else
                                       f"minimizer-sharded PartitionedDNAMap, {world} partitions, RCCL all-to-all"),
                        "reads_per_gpu": n, "read_len": L, "k": k, "mode": args.mode,
-                       "table_slots_per_gpu": m.slots(), "slot_bytes": 16 if W == 1 else 32},
+                       "table_slots_per_gpu": m.slots(), "slot_bytes": 16 if W == 1 else 32,
+                       "insert_path": "partitioned" if partitioned else "direct"},
             "occurrences_per_s": occ_total / (dt_max / args.steps),
             "distinct_per_step": distinct_total, "occurrences_per_step": occ_total,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
                          "kernel_ms": avg_kernel_ms, "units_per_launch": units,
-                         "algorithmic_bytes_per_launch": abytes, "timing": timing},
+                         "algorithmic_bytes_per_launch": abytes, "timing": timing,
+                         "phases_ms": phase_detail, "dominant": dominant,
+                         "traffic_source": (os.path.relpath(pmc_file, ROOT) if traffic else None)},
         }
         if not args.no_cpu_baseline and world == 1:
             sample_reads = min(n, 400_000)

@@ -71,6 +71,7 @@ SIGNATURES = {
     "gk_map_export": (C.c_int, [vp, u64p, u64p, i32p, C.c_uint64, u64p]),
     "gk_map_stats": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
     "gk_map_last_count_kernel": (C.c_int, [vp, C.POINTER(C.c_float), u64p]),
+    "gk_map_last_phase_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
     "gk_shard_reads_dev": (C.c_int, [vp, C.c_int, vp, C.c_uint64, C.c_int, C.c_int, vp, C.c_uint64, u64p]),
     "gk_owner_of": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_int]),
     "gk_graph_build": (C.c_int, [vp, C.POINTER(vp)]),

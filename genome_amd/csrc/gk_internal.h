@@ -12,6 +12,7 @@ struct gk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // phase boundaries of the partitioned path
     int cu_count = 256;
     std::string err;
 };
@@ -42,6 +43,7 @@ struct gk_map {
     int insert_path = 0;         // 0 auto, 1 direct (global atomics), 2 partitioned (LDS build)
     bool pending_clear = false;  // gk_map_clear deferred: slots are stale until materialised
     uint64_t part_launches = 0, direct_launches = 0;
+    float phase_ms[5] = {0, 0, 0, 0, 0};   // last insert: hist1, scatter1, hist2, scatter2, seg_insert (or [0] = direct kernel)
 };
 
 namespace gk {

@@ -463,29 +463,35 @@ static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads
     const u64 nseg = t.nseg();
     const int cu8 = ctx->cu_count * 8;
     // P1 + prefix + P2
+    GK_HIP(ctx, hipEventRecord(ctx->pev[0], ctx->stream));
     if (d_rec) {
         const u64 ntiles = (nreads + PTILE_READS - 1) / PTILE_READS;
         const int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)ctx->cu_count * 4);
         hipLaunchKernelGGL(k_part_hist1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k, t, a.hist1, m->d_ctr);
         hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(256), 0, ctx->stream, a, nb1);
+        GK_HIP(ctx, hipEventRecord(ctx->pev[1], ctx->stream));
         hipLaunchKernelGGL(k_part_scatter1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k, t,
                            a.l1_base, a.cursor1, ps->bufA);
     } else {
         const int grid = (int)std::min<u64>(std::max<u64>((nkeys_in + BLOCK - 1) / BLOCK, 1), (u64)cu8);
         hipLaunchKernelGGL(k_part_hist1_keys<W>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_keys, nkeys_in, t, a.hist1);
         hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(256), 0, ctx->stream, a, nb1);
+        GK_HIP(ctx, hipEventRecord(ctx->pev[1], ctx->stream));
         const int g2 = (int)std::min<u64>(std::max<u64>((nkeys_in + TILE2 - 1) / TILE2, 1), (u64)ctx->cu_count * 4);
         hipLaunchKernelGGL(k_part_scatter1_keys<W>, dim3(g2), dim3(PBLOCK), 0, ctx->stream, d_keys, nkeys_in, t, a.l1_base, a.cursor1, ps->bufA);
     }
     GK_HIP(ctx, hipGetLastError());
+    GK_HIP(ctx, hipEventRecord(ctx->pev[2], ctx->stream));
     // P3 + prefix + P4
     const u64 max_chunks = nkeys_bound / TILE2 + 257;
     const int gchunks = (int)std::min<u64>(max_chunks, (u64)ctx->cu_count * 4);
     const u64 *fine_keys = ps->bufB;
     hipLaunchKernelGGL(k_part_hist2<W>, dim3(gchunks), dim3(PBLOCK), m->nb2 * 4, ctx->stream, ps->bufA, t, a, max_chunks);
     hipLaunchKernelGGL(k_part_prefix2, dim3(nb1), dim3(256), 0, ctx->stream, a, nb1, m->nb2);
+    GK_HIP(ctx, hipEventRecord(ctx->pev[3], ctx->stream));
     hipLaunchKernelGGL(k_part_scatter2<W>, dim3(gchunks), dim3(PBLOCK), m->nb2 * 12, ctx->stream, ps->bufA, t, a, max_chunks, ps->bufB);
     GK_HIP(ctx, hipGetLastError());
+    GK_HIP(ctx, hipEventRecord(ctx->pev[4], ctx->stream));
     // P5
     const size_t lds = ((size_t)1 << SegBits<W>::value) * sizeof(Slot<W>) + 16;
     if (!ps->lds_attr_set) {
@@ -495,6 +501,7 @@ static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads
     const int gseg = (int)std::min<u64>(nseg, (u64)ctx->cu_count * 24);
     hipLaunchKernelGGL(k_seg_insert<W>, dim3(gseg), dim3(SBLOCK), lds, ctx->stream, t, fine_keys, a, from_empty ? 1 : 0, m->d_ctr);
     GK_HIP(ctx, hipGetLastError());
+    GK_HIP(ctx, hipEventRecord(ctx->pev[5], ctx->stream));
     // failures (a segment filled up): grow, then replay those buckets through the direct path
     u32 n_failed = 0;
     GK_HIP(ctx, hipMemcpyAsync(&n_failed, a.n_failed, 4, hipMemcpyDeviceToHost, ctx->stream));

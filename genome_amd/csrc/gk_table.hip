@@ -328,6 +328,7 @@ int gk_ctx_create(int device, gk_ctx **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
+    for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&ctx->pev[i]);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) {
@@ -346,6 +347,7 @@ void gk_ctx_destroy(gk_ctx *ctx) {
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (int i = 0; i < 6; i++) if (ctx->pev[i]) (void)hipEventDestroy(ctx->pev[i]);
     delete ctx;
 }
 
@@ -479,6 +481,7 @@ static int launch_count(gk_map *m, const uint8_t *d_rec, u64 nreads, const u32 *
     float ms = 0.f;
     GK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     m->last_count_ms += ms;
+    m->phase_ms[0] += ms;
     m->direct_launches++;
     return GK_OK;
 }
@@ -520,6 +523,11 @@ static int launch_partitioned(gk_map *m, const uint8_t *d_rec, u64 nreads, const
     float ms = 0.f;
     GK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     m->last_count_ms += ms;
+    for (int i = 0; i < 5; i++) {
+        float pm = 0.f;
+        GK_HIP(ctx, hipEventElapsedTime(&pm, ctx->pev[i], ctx->pev[i + 1]));
+        m->phase_ms[i] += pm;
+    }
     m->part_launches++;
     return GK_OK;
 }
@@ -541,6 +549,7 @@ int gk_map_count_reads_dev(gk_map *m, const void *dev_records, uint64_t nreads, 
     if (read_len < 0 || read_len > 255) return fail(ctx, GK_E_FORMAT, "read_len must be 0..255 (one length byte per record)");
     m->last_count_ms = 0.f;
     m->last_count_occ = 0;
+    for (float &x : m->phase_ms) x = 0.f;
     if (nreads == 0) return GK_OK;
     const u32 stride = 1 + (read_len + 3) / 4;
     const u64 nk = read_len >= m->k ? (u64)(read_len - m->k + 1) : 0;
@@ -574,6 +583,7 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
     if (!bin && nreads) return fail(ctx, GK_E_INVALID, "gk_map_count_reads: null stream");
     m->last_count_ms = 0.f;
     m->last_count_occ = 0;
+    for (float &x : m->phase_ms) x = 0.f;
     if (nreads == 0) return GK_OK;
     if (int rc = reset_occ_counter(m)) return rc;
     // Walk the record framing once on the host (one length byte per record, PairedEndData.scala:24-31),
@@ -668,6 +678,7 @@ int gk_map_update_inc_dev(gk_map *m, const void *dev_keys, uint64_t n) {
     if (n == 0) return GK_OK;
     m->last_count_ms = 0.f;
     m->last_count_occ = n;
+    for (float &x : m->phase_ms) x = 0.f;
     const u64 *keys = (const u64 *)dev_keys;
     u64 done = 0;
     while (done < n) {
@@ -870,6 +881,13 @@ int gk_map_stats(gk_map *m, char *json, size_t cap) {
                      (unsigned long long)m->last_count_occ, (unsigned long long)m->part_launches,
                      (unsigned long long)m->direct_launches, m->ctx->device, m->ctx->cu_count);
     if (w < 0 || (size_t)w >= cap) return fail(m->ctx, GK_E_CAPACITY, "stats buffer too small");
+    return GK_OK;
+}
+
+int gk_map_last_phase_ms(gk_map *m, float *ms5) {
+    if (int rc = check_map_lazy(m)) return rc;
+    if (!ms5) return fail(m->ctx, GK_E_INVALID, "null buffer");
+    for (int i = 0; i < 5; i++) ms5[i] = m->phase_ms[i];
     return GK_OK;
 }
 

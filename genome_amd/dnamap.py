@@ -182,6 +182,11 @@ class HipDNAMap:
         L.check(L.lib().gk_map_stats(self.h, buf, 1024), self.ctx.h)
         return json.loads(buf.value.decode())
 
+    def last_phase_ms(self):
+        arr = (C.c_float * 5)()
+        L.check(L.lib().gk_map_last_phase_ms(self.h, arr), self.ctx.h)
+        return [float(x) for x in arr]
+
     def last_count_kernel(self):
         ms, occ = C.c_float(), C.c_uint64()
         L.check(L.lib().gk_map_last_count_kernel(self.h, C.byref(ms), C.byref(occ)), self.ctx.h)

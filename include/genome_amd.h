@@ -114,6 +114,9 @@ int gk_map_stats(gk_map *m, char *json, size_t cap);
 /* duration (ms, HIP events on the context stream) and occurrence count of the most recent
  * insert+count kernel launched by gk_map_count_reads[_dev] — used by bench.py's roofline. */
 int gk_map_last_count_kernel(gk_map *m, float *ms, uint64_t *occurrences);
+/* per-phase device time (ms, HIP events) of the most recent insert: ms5 = {hist1, scatter1, hist2,
+ * scatter2, seg_insert} for the partitioned path; {kernel, 0, 0, 0, 0} for the direct path. */
+int gk_map_last_phase_ms(gk_map *m, float *ms5);
 
 /* ---- PartitionedDNAMap: owner routing (S/ds/PartitionedDNAMap.scala:60-63) ----------------- */
 /* Extract + canonicalise every k-mer of fixed-length device reads and bucket the canonical keys
