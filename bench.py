@@ -67,6 +67,11 @@ def cpu_baseline(rec_host: np.ndarray, nreads_total: int, k: int, target_s: floa
 
 
 def main():
+    # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version banner) write to
+    # fd 1 behind Python's back, so fd 1 is pointed at stderr until the result is ready.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -78,6 +83,8 @@ def main():
                     "G: 5 Mbp genome, 30x, 1%% error")
     ap.add_argument("--insert-path", choices=["auto", "direct", "partitioned"], default="auto",
                     help="direct: one global CAS/add per k-mer; partitioned: radix-partition by table segment, build in LDS")
+    ap.add_argument("--sharded", action="store_true", help="run the N>1 code path (owner bucketing + all-to-all + owner insert) "
+                    "even with one rank: the only way to exercise it on a 1-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -91,9 +98,11 @@ def main():
             sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or args.sharded
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from genome_amd import synth
     from genome_amd.dnamap import Context, HipDNAMap
@@ -110,7 +119,7 @@ def main():
     occ_rank = n * nk
     m = HipDNAMap(ctx, k, int(occ_rank * 1.05 * float(os.environ.get('GK_HINT_SCALE', '1'))))
     m.set_insert_path(args.insert_path)
-    if world > 1:
+    if sharded:
         send = torch.empty(occ_rank * W, dtype=torch.int64, device=dev)
         recv = torch.empty(int(occ_rank * W * 1.5) + 1024, dtype=torch.int64, device=dev)
 
@@ -118,7 +127,7 @@ def main():
 
     def step():
         m.clear()
-        if world == 1:
+        if not sharded:
             m.count_reads_dev(rec.data_ptr(), n, L)
             ms, kocc = m.last_count_kernel()
             kernel_ms.append(ms); kernel_units.append(kocc); phase_ms.append(m.last_phase_ms())
@@ -135,7 +144,7 @@ def main():
     def fence():
         torch.cuda.synchronize()
         ctx_sync()
-        if world > 1:
+        if sharded:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -155,7 +164,7 @@ def main():
 
     distinct_rank = m.size()
     tt = torch.tensor([dt, float(distinct_rank), float(occ_rank)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if sharded:
         tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt_max, distinct_total, occ_total = float(tmax[0]), float(tsum[1]), float(tsum[2])
@@ -170,7 +179,7 @@ def main():
         partitioned = stats["partitioned_launches"] > 0
         slot_b = 16 if W == 1 else 32
         # ALGORITHMIC bytes of one insert+count pass, whatever kernels carry it
-        abytes = (algorithmic_bytes_count_kernel(units, distinct_rank, L, k) if world == 1
+        abytes = (algorithmic_bytes_count_kernel(units, distinct_rank, L, k) if not sharded
                   else algorithmic_bytes_insert_kernel(units, distinct_rank, k))
         if partitioned:
             names = ["k_part_hist1", "k_part_scatter1", "k_part_hist2", "k_part_scatter2", "k_seg_insert"]
@@ -179,22 +188,23 @@ def main():
             timing = "HIP events on the library stream around each phase (gk_map_last_phase_ms), summed"
             dom = int(np.argmax(phases))
             # what the dominant kernel itself must move: its keys in, its table segments out (+ in unless built from empty)
+            src_b = 8.0 * W if sharded else 2.0 * L / (8 * nk)       # P1/P2 read routed keys or packed reads
             dom_bytes = {4: units * 8 * W + m.slots() * slot_b, 3: units * 16 * W, 2: units * 8 * W,
-                         1: units * (8 * W + 2.0 * L / (8 * nk)), 0: units * 2.0 * L / (8 * nk)}[dom]
+                         1: units * (8 * W + src_b), 0: units * src_b}[dom]
             dominant = {"kernel": f"{names[dom]}<{W}>", "ms": float(phases[dom]), "own_streaming_bytes": dom_bytes,
                         "GB_per_s": dom_bytes / (float(phases[dom]) * 1e-3) / 1e9,
                         "frac_of_peak": dom_bytes / (float(phases[dom]) * 1e-3) / 1e9 / HBM_PEAK_GBS}
             phase_detail = {n: float(x) for n, x in zip(names, phases)}
         else:
             kernel_time_ms = float(np.mean(kernel_ms))
-            kname = ("k_count_reads" if world == 1 else "k_add_keys") + f"<{W}>"
+            kname = ("k_count_reads" if not sharded else "k_add_keys") + f"<{W}>"
             timing = "HIP events on the library stream (gk_map_last_count_kernel)"
             dominant, phase_detail = None, None
         avg_kernel_ms = kernel_time_ms
         achieved = abytes / (avg_kernel_ms * 1e-3) / 1e9
         traffic = None
         pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_pipeline_v3.json" if partitioned else "pmc_count_reads_v2.json")
-        if world == 1 and args.mode == "U" and n == 1_000_000 and L == 150 and k == 31 and os.path.exists(pmc_file):
+        if not sharded and args.mode == "U" and n == 1_000_000 and L == 150 and k == 31 and os.path.exists(pmc_file):
             pj = json.load(open(pmc_file))
             traffic = pj.get("hbm_bytes_per_launch", pj.get("k_count_reads<1>", {}).get("hbm_bytes_per_launch"))
         out = {
@@ -205,7 +215,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64" if W == 1 else "u128", "data": "synthetic",
             "config": {"workload": f"C2: {n} x {L}bp synthetic reads per GPU (SplitMix64 mode {args.mode}), k={k}, "
-                                   + ("single-partition DNAMap kernel" if world == 1 else
+                                   + ("single-partition DNAMap kernel" if not sharded else
                                       f"minimizer-sharded PartitionedDNAMap, {world} partitions, RCCL all-to-all"),
                        "reads_per_gpu": n, "read_len": L, "k": k, "mode": args.mode,
                        "table_slots_per_gpu": m.slots(), "slot_bytes": 16 if W == 1 else 32,
@@ -219,15 +229,18 @@ def main():
                          "phases_ms": phase_detail, "dominant": dominant,
                          "traffic_source": (os.path.relpath(pmc_file, ROOT) if traffic else None)},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not sharded:
             sample_reads = min(n, 400_000)
             host = ctx.download(rec.data_ptr(), sample_reads * stride).reshape(sample_reads, stride)
             out["cpu_baseline"] = cpu_baseline(host, sample_reads, k)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     m.close()
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 
