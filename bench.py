@@ -6,9 +6,10 @@ in HBM: clear the table, then FreqFilter.add for every read (extract -> canonica
 count).  Workload = BASELINE.json configs[1] ("C2"): 1M x 150 bp reads per GPU, k=31.
   N = 1 : single-partition DNAMap kernel (gk_map_count_reads_dev).
   N > 1 : weak scaling, one rank per GPU: every rank owns 1M reads and one table partition; k-mers are
-          bucketed by strand-symmetric minimizer owner (gk_shard_reads_dev), exchanged with ONE RCCL
-          all-to-all (torch.distributed, backend nccl) and inserted by their owner
-          (gk_map_update_inc_dev).  value = distinct k-mers over all partitions / max-over-ranks time.
+          routed by strand-symmetric minimizer owner as SUPER-K-MER records (gk_shard_superkmers_dev:
+          runs of same-owner windows, 2 bits/base in 16-B slots), exchanged with ONE RCCL all-to-all
+          (torch.distributed, backend nccl) and counted by their owner with the same pipeline as
+          reads (gk_map_count_superkmers_dev).  value = distinct k-mers over all partitions / max-over-ranks time.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -36,9 +37,10 @@ def algorithmic_bytes_count_kernel(occ, distinct, L, k):
 
 
 def algorithmic_bytes_insert_kernel(keys, distinct, k):
-    """Owner-side insert of routed keys: stream the key (W B) + slot read (W B) + count RMW (8 B)."""
+    """Owner-side count of routed super-k-mer records: ~1.6 B of record per window (16-B slot per
+    ~10 windows) + slot read (W B) + count RMW (8 B); + W B per distinct key."""
     W = 8 if k <= 32 else 16
-    return keys * (W + W + 8.0) + distinct * W
+    return keys * (1.6 + W + 8.0) + distinct * W
 
 
 def cpu_baseline(rec_host: np.ndarray, nreads_total: int, k: int, target_s: float = 12.0):
@@ -106,7 +108,8 @@ def main():
 
     from genome_amd import synth
     from genome_amd.dnamap import Context, HipDNAMap
-    from genome_amd.partitioned import exchange_keys
+    from genome_amd.dnamap import skm_slot_bytes
+    from genome_amd.partitioned import exchange_records
 
     n, L, k = args.reads, args.read_len, args.k
     W = 1 if k <= 32 else 2
@@ -120,8 +123,10 @@ def main():
     m = HipDNAMap(ctx, k, int(occ_rank * 1.05 * float(os.environ.get('GK_HINT_SCALE', '1'))))
     m.set_insert_path(args.insert_path)
     if sharded:
-        send = torch.empty(occ_rank * W, dtype=torch.int64, device=dev)
-        recv = torch.empty(int(occ_rank * W * 1.5) + 1024, dtype=torch.int64, device=dev)
+        slot = skm_slot_bytes(k)
+        send_cap = n * 24 // world * world                       # records, world regions of send_cap/world slots
+        send = torch.empty(send_cap * slot, dtype=torch.uint8, device=dev)
+        recv = torch.empty(send_cap * slot, dtype=torch.uint8, device=dev)
 
     kernel_ms, kernel_units, phase_ms = [], [], []
 
@@ -132,13 +137,12 @@ def main():
             ms, kocc = m.last_count_kernel()
             kernel_ms.append(ms); kernel_units.append(kocc); phase_ms.append(m.last_phase_ms())
             return
-        counts = ctx.shard_reads(k, rec.data_ptr(), n, L, world, send.data_ptr(), occ_rank)
         nonlocal recv
-        recv, rcn = exchange_keys(dist, send, counts, W, recv)
-        nrecv = int(rcn.sum())
+        recs, kmers = ctx.shard_superkmers(k, rec.data_ptr(), n, L, world, send.data_ptr(), send_cap)
+        recv, nrec, nrecv = exchange_records(dist, send, recs, kmers, slot, send_cap // world, recv)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        m.update_inc_dev(recv.data_ptr(), nrecv)
+        m.count_superkmers_dev(recv.data_ptr(), nrec, nrecv)
         kernel_ms.append((time.perf_counter() - t0) * 1e3); kernel_units.append(nrecv); phase_ms.append(m.last_phase_ms())
 
     def fence():
@@ -188,7 +192,7 @@ def main():
             timing = "HIP events on the library stream around each phase (gk_map_last_phase_ms), summed"
             dom = int(np.argmax(phases))
             # what the dominant kernel itself must move: its keys in, its table segments out (+ in unless built from empty)
-            src_b = 8.0 * W if sharded else 2.0 * L / (8 * nk)       # P1/P2 read routed keys or packed reads
+            src_b = 1.6 if sharded else 2.0 * L / (8 * nk)           # P1/P2 read super-k-mer records or packed reads
             dom_bytes = {4: units * 8 * W + m.slots() * slot_b, 3: units * 16 * W, 2: units * 8 * W,
                          1: units * (8 * W + src_b), 0: units * src_b}[dom]
             dominant = {"kernel": f"{names[dom]}<{W}>", "ms": float(phases[dom]), "own_streaming_bytes": dom_bytes,

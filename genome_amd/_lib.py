@@ -74,6 +74,9 @@ SIGNATURES = {
     "gk_map_last_phase_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
     "gk_shard_reads_dev": (C.c_int, [vp, C.c_int, vp, C.c_uint64, C.c_int, C.c_int, vp, C.c_uint64, u64p]),
     "gk_owner_of": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_int]),
+    "gk_skm_slot_bytes": (C.c_int, [C.c_int]),
+    "gk_shard_superkmers_dev": (C.c_int, [vp, C.c_int, vp, C.c_uint64, C.c_int, C.c_int, vp, C.c_uint64, u64p, u64p]),
+    "gk_map_count_superkmers_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, u64p]),
     "gk_graph_build": (C.c_int, [vp, C.POINTER(vp)]),
     "gk_graph_destroy": (None, [vp]),
     "gk_graph_counts": (C.c_int, [vp, u64p, u64p, u64p]),

@@ -86,8 +86,10 @@ int map_sync_counters(gk_map *m);                    // refresh m->size, detect 
 int map_materialize(gk_map *m);                      // run a deferred clear so that the slots are valid
 int map_add_keys_direct(gk_map *m, const uint64_t *d_keys, uint64_t n);   // k_add_keys on device keys (W words each)
 // partitioned path
-int part_count(gk_map *m, PartScratch **pps, const uint8_t *d_rec, uint64_t nreads, const uint32_t *d_off, uint32_t stride,
+int part_count(gk_map *m, PartScratch **pps, const uint8_t *d_rec, uint64_t nreads, const uint32_t *d_off, uint32_t stride, int group,
                const uint64_t *d_keys, uint64_t nkeys_in, uint64_t nkeys_bound, bool from_empty);
+// lanes per read in the window loops: 64 for reads, 32/16 for short records (super-k-mers)
+inline int lanes_per_read(int max_windows) { return max_windows > 32 ? 64 : max_windows > 16 ? 32 : 16; }
 bool part_supported(const gk_map *m);
 void part_scratch_free(PartScratch *ps);
 

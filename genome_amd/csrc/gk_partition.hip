@@ -68,7 +68,7 @@ template <int W> __device__ __forceinline__ void store_key(u64 *keys, u64 i, Kme
 // ---------------------------------------------------------------------------------------------
 template <int W>
 __global__ __launch_bounds__(PBLOCK) void k_part_hist1_reads(const uint8_t *__restrict__ rec, u64 nreads, const u32 *__restrict__ offsets,
-                                                            u32 stride, int k, Table<W> t, unsigned long long *hist1, Counters *ctr) {
+                                                            u32 stride, int k, int group, Table<W> t, unsigned long long *hist1, Counters *ctr) {
     __shared__ __attribute__((aligned(16))) u32 tile[PTILE_WORDS];
     __shared__ u32 hist[256];
     if (threadIdx.x < 256) hist[threadIdx.x] = 0;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(PBLOCK) void k_part_hist1_reads(const uint8_t *__re
         __syncthreads();
         const u64 a0 = stage_tile(tile, rec, gb, ge);
         __syncthreads();
-        for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, [&](Kmer<W> x) {
+        for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, group, [&](Kmer<W> x) {
             atomicAdd(&hist[seg_l1(t, slot_hash(canonical(x, k)))], 1u);
             occ++;
         });
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(PBLOCK) void k_part_hist1_reads(const uint8_t *__re
 
 template <int W>
 __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_reads(const uint8_t *__restrict__ rec, u64 nreads, const u32 *__restrict__ offsets,
-                                                               u32 stride, int k, Table<W> t, const unsigned long long *l1_base,
+                                                               u32 stride, int k, int group, Table<W> t, const unsigned long long *l1_base,
                                                                unsigned long long *cursor1, u64 *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) u32 tile[PTILE_WORDS];
     __shared__ u32 hist[256];
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_reads(const uint8_t *_
         if (threadIdx.x < 256) hist[threadIdx.x] = 0;
         const u64 a0 = stage_tile(tile, rec, gb, ge);
         __syncthreads();
-        for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, [&](Kmer<W> x) {
+        for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, group, [&](Kmer<W> x) {
             atomicAdd(&hist[seg_l1(t, slot_hash(canonical(x, k)))], 1u);
         });
         __syncthreads();
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_reads(const uint8_t *_
             hist[threadIdx.x] = 0;          // becomes the rank counter
         }
         __syncthreads();
-        for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, [&](Kmer<W> x) {
+        for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, group, [&](Kmer<W> x) {
             const Kmer<W> y = canonical(x, k);
             const u32 b = seg_l1(t, slot_hash(y));
             store_key<W>(out, base[b] + atomicAdd(&hist[b], 1u), y);
@@ -453,7 +453,7 @@ void part_scratch_free(PartScratch *ps) {
 }
 
 template <int W>
-static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads, const u32 *d_off, u32 stride,
+static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads, const u32 *d_off, u32 stride, int group,
                     const u64 *d_keys, u64 nkeys_in, u64 nkeys_bound, bool from_empty) {
     gk_ctx *ctx = m->ctx;
     Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1};
@@ -467,10 +467,10 @@ static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads
     if (d_rec) {
         const u64 ntiles = (nreads + PTILE_READS - 1) / PTILE_READS;
         const int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)ctx->cu_count * 4);
-        hipLaunchKernelGGL(k_part_hist1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k, t, a.hist1, m->d_ctr);
+        hipLaunchKernelGGL(k_part_hist1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k, group, t, a.hist1, m->d_ctr);
         hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(256), 0, ctx->stream, a, nb1);
         GK_HIP(ctx, hipEventRecord(ctx->pev[1], ctx->stream));
-        hipLaunchKernelGGL(k_part_scatter1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k, t,
+        hipLaunchKernelGGL(k_part_scatter1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k, group, t,
                            a.l1_base, a.cursor1, ps->bufA);
     } else {
         const int grid = (int)std::min<u64>(std::max<u64>((nkeys_in + BLOCK - 1) / BLOCK, 1), (u64)cu8);
@@ -521,11 +521,11 @@ static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads
     return GK_OK;
 }
 
-int part_count(gk_map *m, PartScratch **pps, const uint8_t *d_rec, u64 nreads, const u32 *d_off, u32 stride, const u64 *d_keys,
-               u64 nkeys_in, u64 nkeys_bound, bool from_empty) {
+int part_count(gk_map *m, PartScratch **pps, const uint8_t *d_rec, u64 nreads, const u32 *d_off, u32 stride, int group,
+               const u64 *d_keys, u64 nkeys_in, u64 nkeys_bound, bool from_empty) {
     if (!*pps) *pps = new PartScratch();
-    if (m->W == 1) return part_run<1>(m, *pps, d_rec, nreads, d_off, stride, d_keys, nkeys_in, nkeys_bound, from_empty);
-    return part_run<2>(m, *pps, d_rec, nreads, d_off, stride, d_keys, nkeys_in, nkeys_bound, from_empty);
+    if (m->W == 1) return part_run<1>(m, *pps, d_rec, nreads, d_off, stride, group, d_keys, nkeys_in, nkeys_bound, from_empty);
+    return part_run<2>(m, *pps, d_rec, nreads, d_off, stride, group, d_keys, nkeys_in, nkeys_bound, from_empty);
 }
 
 bool part_supported(const gk_map *m) { return m->nb2 <= MAX_NB2; }

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(BLOCK) void k_shard_count(const uint8_t *__restrict
         __syncthreads();
         const u64 a0 = stage_tile(tile, rec, r0 * stride, (r0 + nr) * stride);
         __syncthreads();
-        for_each_window<W>(tile, a0, r0, nr, nullptr, stride, k, [&](Kmer<W> x) {
+        for_each_window<W>(tile, a0, r0, nr, nullptr, stride, k, 64, [&](Kmer<W> x) {
             atomicAdd(&hist[owner_of(x, k, P)], 1u);
         });
     }
@@ -54,11 +54,11 @@ __global__ __launch_bounds__(BLOCK) void k_shard_scatter(const uint8_t *__restri
         if (threadIdx.x < MAX_PARTS) { hist[threadIdx.x] = 0; rank[threadIdx.x] = 0; }
         const u64 a0 = stage_tile(tile, rec, r0 * stride, (r0 + nr) * stride);
         __syncthreads();
-        for_each_window<W>(tile, a0, r0, nr, nullptr, stride, k, [&](Kmer<W> x) { atomicAdd(&hist[owner_of(x, k, P)], 1u); });
+        for_each_window<W>(tile, a0, r0, nr, nullptr, stride, k, 64, [&](Kmer<W> x) { atomicAdd(&hist[owner_of(x, k, P)], 1u); });
         __syncthreads();
         if (threadIdx.x < P && hist[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursors[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
         __syncthreads();
-        for_each_window<W>(tile, a0, r0, nr, nullptr, stride, k, [&](Kmer<W> x) {
+        for_each_window<W>(tile, a0, r0, nr, nullptr, stride, k, 64, [&](Kmer<W> x) {
             Kmer<W> y = canonical(x, k);                 // FreqFilter.scala:31-32, done by the sender
             int p = owner_of(x, k, P);                   // same owner for x and rc(x)
             u64 o = base[p] + atomicAdd(&rank[p], 1u);

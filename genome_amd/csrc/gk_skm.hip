@@ -1,0 +1,238 @@
+// gk_skm.hip — owner routing by SUPER-K-MERS for the PartitionedDNAMap path.
+//
+// Reference: PartitionedDNAMap.partition (S/ds/PartitionedDNAMap.scala:60-63) sends one Akka/Kryo
+// message per k-mer to `hashCode mod P`.  Here the owner of a k-mer is a strand-symmetric minimizer
+// hash (gk::owner_of), consecutive k-mers of a read almost always share their
+// minimizer, and a maximal run of same-owner k-mers is shipped as ONE record: the run's bases, 2
+// bits each, in the reference's own `.bin` framing [len:u8][bases] inside a fixed 16-B (k<=31) or
+// 32-B (k>=34) slot.  A run of r k-mers costs (r+k-1)/4+1 bytes instead of 8r..16r; the receiver
+// feeds the records to the ordinary read-counting pipeline (they ARE short reads: every k-mer of
+// a record is one of the sender's windows, no window is sent twice, none is lost), so the
+// all-to-all over xGMI moves ~8x fewer bytes and the receiver re-extracts and canonicalises.
+//
+// One kernel (k_skm_route) turns reads into records; owner p's records land in region p of the
+// output buffer (out_cap_records / P slots each), counted per owner.
+//
+// The minimizer of a window is the minimum of the per-POSITION m-mer scores over the window: the
+// scores are computed once per position (one lane each), parked in LDS, and each window lane
+// takes the min of its k-m+1 neighbours from LDS — 1 hash per k-mer instead of k-m+1.
+#include <algorithm>
+#include <string>
+
+#include "gk_internal.h"
+#include "gk_tile.h"
+
+using namespace gk;
+
+static constexpr int MAX_PARTS = 64;
+static constexpr int MAX_POS = 256;       // positions per read (len <= 255)
+
+__host__ __device__ static inline int skm_slot_bytes(int k) { return k <= 31 ? 16 : 32; }
+__host__ __device__ static inline int skm_max_bases(int k) { return (skm_slot_bytes(k) - 1) * 4; }
+__host__ __device__ static inline int skm_max_run(int k) { return skm_max_bases(k) - k + 1; }
+
+// score of the m-mer at bit position `bit` of the LDS tile: hash of its own canonical form
+__device__ __forceinline__ u32 mmer_score(const u32 *tile, u32 bit, int m) {
+    const u32 wi = bit >> 5, sh = bit & 31;
+    const u64 v = (u64)tile[wi] | ((u64)tile[wi + 1] << 32);
+    const u32 mm = (u32)((1ull << (2 * m)) - 1);
+    const u32 a = (u32)(v >> sh) & mm;
+    // reverse complement of a 2m-bit value: complement, reverse 2-bit groups of the 32-bit word, shift down
+    u32 r = __brev(~a);
+    r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+    r >>= (32 - 2 * m);
+    return hash32(a < r ? a : r);
+}
+
+// `nbases` bases starting at bit `bit` of the tile, as record bytes: byte 0 = nbases, then the
+// bases 2 bits each LSB first (the `.bin` framing), zero padded to the slot.  16- or 32-byte slot.
+template <int SLOT>
+__device__ __forceinline__ void write_record(const u32 *tile, u32 bit, int nbases, uint8_t *dst) {
+    constexpr int NW = SLOT / 4;                  // 32-bit words of the slot
+    const u32 wi = bit >> 5, sh = bit & 31;
+    u32 out[NW];
+    // payload word j (bits 32j..32j+31 of the base stream)
+    u32 prev = tile[wi];
+    u32 pay[NW];
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+        const u32 next = tile[wi + j + 1];
+        pay[j] = sh ? (prev >> sh) | (next << (32 - sh)) : prev;
+        prev = next;
+    }
+    // mask the payload to 2*nbases bits
+    const int nbits = 2 * nbases;
+#pragma unroll
+    for (int j = 0; j < NW; j++) {
+        const int lo = 32 * j;
+        if (nbits <= lo) pay[j] = 0;
+        else if (nbits < lo + 32) pay[j] &= (1u << (nbits - lo)) - 1u;
+    }
+    // shift the whole payload left by 8 bits and put the length byte in front
+    out[0] = (pay[0] << 8) | (u32)nbases;
+#pragma unroll
+    for (int j = 1; j < NW; j++) out[j] = (pay[j] << 8) | (pay[j - 1] >> 24);
+    uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+    d4[0] = make_uint4(out[0], out[1], out[2], out[3]);
+    if constexpr (SLOT == 32) d4[1] = make_uint4(out[4], out[5], out[6], out[7]);
+}
+
+// One pass: owners -> runs -> records.  Per tile of 64 reads:
+//   phase 1  each wave takes reads round-robin; per read the m-mer scores of its positions go to the
+//            wave's LDS strip, each window lane takes the minimum over its k-m+1 positions -> owner
+//            byte in LDS; run starts are found with a ballot (owner differs from the previous
+//            lane's; lane 0 of every 64-window block starts a record too, so that everything stays
+//            wave-local), run lengths with bit scans of the ballot — no loops; records per owner
+//            are counted in an LDS histogram
+//   reserve  one global atomic per (tile, owner) hands out a contiguous run of slots in the owner's
+//            region; a region that would overflow sets the overflow flag (the caller retries larger)
+//   phase 2  the same ballots, now on the owner bytes kept in LDS, and every run start lane writes
+//            its records: a 120-bit (or 248-bit) slice of the read, shifted behind a length byte,
+//            as one or two 16-B stores
+template <int SLOT>
+__global__ __launch_bounds__(BLOCK) void k_skm_route(const uint8_t *__restrict__ rec, u64 nreads, u32 stride, int k, int P,
+                                                     u64 region_cap /* records per owner region */, unsigned long long *cursors,
+                                                     unsigned long long *kmer_counts, u32 *overflow, uint8_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) u32 tile[TILE_WORDS];
+    __shared__ u32 strips[(BLOCK / 64) * MAX_POS];
+    __shared__ uint8_t own[TILE_READS * MAX_POS];
+    __shared__ u32 hist[MAX_PARTS], h_kmer[MAX_PARTS];
+    __shared__ unsigned long long base[MAX_PARTS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = k < 11 ? k : 11, w = k - m + 1, rmax = skm_max_run(k);
+    if (threadIdx.x < MAX_PARTS) h_kmer[threadIdx.x] = 0;
+    const u64 ntiles = (nreads + TILE_READS - 1) / TILE_READS;
+    for (u64 tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const u64 r0 = tl * TILE_READS;
+        const int nr = (int)min((u64)TILE_READS, nreads - r0);
+        __syncthreads();
+        if (threadIdx.x < MAX_PARTS) hist[threadIdx.x] = 0;
+        const u64 a0 = stage_tile(tile, rec, r0 * stride, (r0 + nr) * stride);
+        __syncthreads();
+        const uint8_t *tb = reinterpret_cast<const uint8_t *>(tile);
+        u32 *strip = strips + wave * MAX_POS;
+        // ---- phase 1
+        for (int r = wave; r < nr; r += BLOCK / 64) {
+            const u32 ro = (u32)((r0 + r) * stride - a0);
+            const int len = tb[ro], nk = len - k + 1, nm = len - m + 1;
+            const u32 bit0 = (ro + 1) * 8;
+            uint8_t *o_r = own + r * MAX_POS;
+            __builtin_amdgcn_wave_barrier();
+            for (int q = lane; q < nm; q += 64) strip[q] = mmer_score(tile, bit0 + 2 * q, m);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int pb = 0; pb < nk; pb += 64) {
+                const int p = pb + lane;
+                const bool valid = p < nk;
+                u32 best = 0xffffffffu;
+                if (valid) {
+                    best = strip[p];
+                    for (int j = 1; j < w; j++) best = min(best, strip[p + j]);
+                }
+                const int o = (int)(((u64)hash32(best ^ 0x5bd1e995u) * (u64)P) >> 32);      // == gk::owner_of
+                if (valid) o_r[p] = (uint8_t)o;
+                const int prev = __shfl_up(o, 1);
+                const bool start = valid && (lane == 0 || o != prev);
+                const unsigned long long S = __ballot(start), V = __ballot(valid);
+                if (start) {
+                    const unsigned long long nxt = lane == 63 ? 0ull : (S >> (lane + 1));
+                    const int rl = nxt ? __ffsll((long long)nxt) : (__popcll(V) - lane);
+                    atomicAdd(&hist[o], (u32)((rl + rmax - 1) / rmax));
+                    atomicAdd(&h_kmer[o], (u32)rl);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        __syncthreads();
+        // ---- reserve
+        if (threadIdx.x < P) {
+            const u32 c = hist[threadIdx.x];
+            unsigned long long b = ~0ull;
+            if (c) {
+                const unsigned long long at = atomicAdd(&cursors[threadIdx.x], (unsigned long long)c);
+                if (at + c <= region_cap) b = (unsigned long long)threadIdx.x * region_cap + at;
+                else *overflow = 1;
+            }
+            base[threadIdx.x] = b;
+            hist[threadIdx.x] = 0;      // becomes the rank counter
+        }
+        __syncthreads();
+        // ---- phase 2
+        for (int r = wave; r < nr; r += BLOCK / 64) {
+            const u32 ro = (u32)((r0 + r) * stride - a0);
+            const int nk = (int)tb[ro] - k + 1;
+            const uint8_t *o_r = own + r * MAX_POS;
+            for (int pb = 0; pb < nk; pb += 64) {
+                const int p = pb + lane;
+                const bool valid = p < nk;
+                const int o = valid ? o_r[p] : 0xff;
+                const int prev = __shfl_up(o, 1);
+                const bool start = valid && (lane == 0 || o != prev);
+                const unsigned long long S = __ballot(start), V = __ballot(valid);
+                if (start && base[o] != ~0ull) {
+                    const unsigned long long nxt = lane == 63 ? 0ull : (S >> (lane + 1));
+                    const int rl = nxt ? __ffsll((long long)nxt) : (__popcll(V) - lane);
+                    const int nrec = (rl + rmax - 1) / rmax;
+                    const u64 slot0 = base[o] + atomicAdd(&hist[o], (u32)nrec);
+                    for (int c = 0; c < nrec; c++) {
+                        const int ps = p + c * rmax;
+                        const int wl = min(rmax, rl - c * rmax);
+                        write_record<SLOT>(tile, (ro + 1) * 8 + 2 * ps, wl + k - 1, out + (slot0 + c) * SLOT);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < P && h_kmer[threadIdx.x]) atomicAdd(&kmer_counts[threadIdx.x], (unsigned long long)h_kmer[threadIdx.x]);
+}
+
+static thread_local unsigned long long *tls_counts = nullptr;   // [2 * MAX_PARTS + 1]: cursors, k-mer counts, overflow
+
+extern "C" {
+
+int gk_skm_slot_bytes(int k) { return k_supported(k) ? skm_slot_bytes(k) : 0; }
+
+int gk_shard_superkmers_dev(gk_ctx *ctx, int k, const void *dev_records, uint64_t nreads, int read_len, int P,
+                            void *dev_out, uint64_t out_cap_records, uint64_t *rec_counts_host, uint64_t *kmer_counts_host) {
+    if (!ctx) return fail(nullptr, GK_E_INVALID, "null ctx");
+    if (!k_supported(k)) return fail(ctx, GK_E_UNSUPPORTED_K, "k=" + std::to_string(k) + " unsupported");
+    if (P < 1 || P > MAX_PARTS) return fail(ctx, GK_E_INVALID, "P must be 1.." + std::to_string(MAX_PARTS));
+    if (!rec_counts_host || !kmer_counts_host || (!dev_records && nreads)) return fail(ctx, GK_E_INVALID, "null argument");
+    if (read_len < 0 || read_len > 255) return fail(ctx, GK_E_FORMAT, "read_len must be 0..255");
+    GK_HIP(ctx, hipSetDevice(ctx->device));
+    for (int p = 0; p < P; p++) { rec_counts_host[p] = 0; kmer_counts_host[p] = 0; }
+    const u64 nk = read_len >= k ? (u64)(read_len - k + 1) : 0;
+    if (nreads == 0 || nk == 0) return GK_OK;
+    if (!dev_out) return fail(ctx, GK_E_INVALID, "null record buffer");
+    const u64 region_cap = out_cap_records / (u64)P;
+    if (!tls_counts) GK_HIP(ctx, hipMalloc((void **)&tls_counts, (2 * MAX_PARTS + 1) * sizeof(unsigned long long)));
+    GK_HIP(ctx, hipMemsetAsync(tls_counts, 0, (2 * MAX_PARTS + 1) * sizeof(unsigned long long), ctx->stream));
+    const u32 stride = 1 + (read_len + 3) / 4;
+    const u64 ntiles = (nreads + TILE_READS - 1) / TILE_READS;
+    const int grid = (int)std::min<u64>(ntiles, (u64)ctx->cu_count * 6);
+    const uint8_t *rec = (const uint8_t *)dev_records;
+    u32 *d_overflow = reinterpret_cast<u32 *>(tls_counts + 2 * MAX_PARTS);
+    if (skm_slot_bytes(k) == 16)
+        hipLaunchKernelGGL(k_skm_route<16>, dim3(grid), dim3(BLOCK), 0, ctx->stream, rec, nreads, stride, k, P, region_cap, tls_counts,
+                           tls_counts + MAX_PARTS, d_overflow, (uint8_t *)dev_out);
+    else
+        hipLaunchKernelGGL(k_skm_route<32>, dim3(grid), dim3(BLOCK), 0, ctx->stream, rec, nreads, stride, k, P, region_cap, tls_counts,
+                           tls_counts + MAX_PARTS, d_overflow, (uint8_t *)dev_out);
+    GK_HIP(ctx, hipGetLastError());
+    unsigned long long h[2 * MAX_PARTS + 1];
+    GK_HIP(ctx, hipMemcpyAsync(h, tls_counts, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long worst = 0;
+    for (int p = 0; p < P; p++) {
+        rec_counts_host[p] = h[p];
+        kmer_counts_host[p] = h[MAX_PARTS + p];
+        worst = std::max(worst, h[p]);
+    }
+    if ((u32)h[2 * MAX_PARTS] || worst > region_cap)
+        return fail(ctx, GK_E_CAPACITY, "record buffer too small: the fullest owner region needs " + std::to_string(worst) +
+                                            " records, out_cap_records / P = " + std::to_string(region_cap));
+    return GK_OK;
+}
+
+}  // extern "C"

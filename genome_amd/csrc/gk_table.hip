@@ -64,12 +64,11 @@ template <int W> __global__ __launch_bounds__(BLOCK) void k_clear(Slot<W> *slots
 //   offsets != nullptr : offsets[r] = byte offset of record r, offsets[nreads] = end
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_count_reads(const uint8_t *__restrict__ rec, u64 nreads,
-                                                       const u32 *__restrict__ offsets, u32 stride, int k,
+                                                       const u32 *__restrict__ offsets, u32 stride, int k, int group,
                                                        Table<W> t, Counters *ctr) {
     __shared__ __attribute__((aligned(16))) u32 tile[TILE_WORDS];
     __shared__ u32 s_claimed, s_occ;
     if (threadIdx.x == 0) { s_claimed = 0; s_occ = 0; }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     u32 claimed = 0, occ = 0, err = 0;
     const u64 ntiles = (nreads + TILE_READS - 1) / TILE_READS;
     for (u64 tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
@@ -80,19 +79,11 @@ __global__ __launch_bounds__(BLOCK) void k_count_reads(const uint8_t *__restrict
         __syncthreads();                       // previous tile fully consumed
         const u64 a0 = stage_tile(tile, rec, gb, ge);
         __syncthreads();
-        const uint8_t *tb = reinterpret_cast<const uint8_t *>(tile);
-        for (int r = wave; r < nr; r += BLOCK / 64) {
-            const u32 ro = (u32)((offsets ? (u64)offsets[r0 + r] : (r0 + r) * stride) - a0);
-            const int len = tb[ro];                       // [len:u8] (PairedEndData.scala:25)
-            const int nk = len - k + 1;                   // reads shorter than k are skipped (FreqFilter.scala:29)
-            const u32 bit0 = (ro + 1) * 8;
-            for (int p = lane; p < nk; p += 64) {
-                Kmer<W> x = tile_kmer(tile, bit0 + 2 * p, k, (Kmer<W> *)nullptr);
-                Kmer<W> y = canonical(x, k);              // FreqFilter.scala:31-32
-                claimed += table_add(t, y, 1u, &err);     // kmersFreq.update(y, 1, _ + 1)  :33
-                occ++;
-            }
-        }
+        for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, group, [&](Kmer<W> x) {
+            Kmer<W> y = canonical(x, k);                  // FreqFilter.scala:31-32
+            claimed += table_add(t, y, 1u, &err);         // kmersFreq.update(y, 1, _ + 1)  :33
+            occ++;
+        });
     }
     atomicAdd(&s_claimed, claimed);
     atomicAdd(&s_occ, occ);
@@ -464,16 +455,16 @@ int gk_map_slots(gk_map *m, uint64_t *slots) {
 }
 
 // launch k_count_reads over device-resident records; accumulates event time into last_count_ms
-static int launch_count(gk_map *m, const uint8_t *d_rec, u64 nreads, const u32 *d_off, u32 stride) {
+static int launch_count(gk_map *m, const uint8_t *d_rec, u64 nreads, const u32 *d_off, u32 stride, int group = 64) {
     gk_ctx *ctx = m->ctx;
     u64 ntiles = (nreads + TILE_READS - 1) / TILE_READS;
     int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)ctx->cu_count * 8);
     GK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     if (m->W == 1)
-        hipLaunchKernelGGL(k_count_reads<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k,
+        hipLaunchKernelGGL(k_count_reads<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k, group,
                            table_of<1>(m), m->d_ctr);
     else
-        hipLaunchKernelGGL(k_count_reads<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k,
+        hipLaunchKernelGGL(k_count_reads<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k, group,
                            table_of<2>(m), m->d_ctr);
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -512,12 +503,12 @@ static bool use_partitioned(const gk_map *m, u64 occ) {
 
 // partitioned launch over device records or device keys, timed with the same events as launch_count
 static int launch_partitioned(gk_map *m, const uint8_t *d_rec, u64 nreads, const u32 *d_off, u32 stride, const u64 *d_keys,
-                              u64 nkeys_in, u64 bound) {
+                              u64 nkeys_in, u64 bound, int group = 64) {
     gk_ctx *ctx = m->ctx;
     GK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     const bool from_empty = m->pending_clear;
     m->pending_clear = false;
-    if (int rc = part_count(m, &m->part, d_rec, nreads, d_off, stride, d_keys, nkeys_in, bound, from_empty)) return rc;
+    if (int rc = part_count(m, &m->part, d_rec, nreads, d_off, stride, group, d_keys, nkeys_in, bound, from_empty)) return rc;
     GK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     GK_HIP(ctx, hipEventSynchronize(ctx->ev1));
     float ms = 0.f;
@@ -573,6 +564,42 @@ int gk_map_count_reads_dev(gk_map *m, const void *dev_records, uint64_t nreads, 
     m->last_count_occ = occ;
     m->total_occurrences += occ;
     if (occurrences) *occurrences = occ;
+    return GK_OK;
+}
+
+// Owner side of the super-k-mer exchange (gk_skm.hip): the records are short reads in fixed slots;
+// kmers_total (exchanged next to the record counts) is the exact number of windows they hold.
+int gk_map_count_superkmers_dev(gk_map *m, const void *dev_records, uint64_t nrecords, uint64_t kmers_total, uint64_t *occurrences) {
+    if (int rc = check_map_lazy(m)) return rc;
+    gk_ctx *ctx = m->ctx;
+    if (occurrences) *occurrences = 0;
+    if (!dev_records && nrecords) return fail(ctx, GK_E_INVALID, "gk_map_count_superkmers_dev: null records");
+    m->last_count_ms = 0.f;
+    m->last_count_occ = 0;
+    for (float &x : m->phase_ms) x = 0.f;
+    if (nrecords == 0) return GK_OK;
+    const u32 stride = m->k <= 31 ? 16u : 32u;
+    const u64 max_run = (u64)((stride - 1) * 4 - m->k + 1);
+    if (kmers_total > nrecords * max_run) return fail(ctx, GK_E_INVALID, "kmers_total exceeds what the records can hold");
+    if (int rc = reset_occ_counter(m)) return rc;
+    const uint8_t *rec = (const uint8_t *)dev_records;
+    // a record holds <= max_run windows but typically a minimizer's reach, ~(k-m+2)/2: pick the lane
+    // group that keeps the wave full
+    const int group = lanes_per_read(std::min<int>((int)max_run, std::max(8, (m->k - 9) * 3 / 4)));
+    if (use_partitioned(m, kmers_total)) {
+        if (!m->pending_clear) { if (int rc = map_reserve(m, kmers_total)) return rc; }
+        if (int rc = launch_partitioned(m, rec, nrecords, nullptr, stride, nullptr, 0, kmers_total, group)) return rc;
+    } else {
+        if (int rc = map_materialize(m)) return rc;
+        if (int rc = map_reserve(m, kmers_total)) return rc;
+        if (int rc = launch_count(m, rec, nrecords, nullptr, stride, group)) return rc;
+    }
+    uint64_t occ = 0;
+    if (int rc = read_occ_counter(m, &occ)) return rc;
+    m->last_count_occ = occ;
+    m->total_occurrences += occ;
+    if (occurrences) *occurrences = occ;
+    if (occ != kmers_total) return fail(ctx, GK_E_FORMAT, "records held " + std::to_string(occ) + " k-mers, caller announced " + std::to_string(kmers_total));
     return GK_OK;
 }
 

@@ -45,17 +45,21 @@ __device__ __forceinline__ u64 stage_tile(u32 *tile, const uint8_t *rec, u64 gb,
 }
 
 
-// Walk every window of a staged tile: f(kmer) is called once per window by the lane that owns it
-// (waves take reads round-robin, lanes take window positions).  offsets == nullptr: fixed stride.
+// Walk every window of a staged tile: f(kmer) is called once per window by the lane that owns it.
+// A wave is cut into 64/G groups of G lanes (G = 64, 32 or 16); each group takes one read and its
+// lanes take window positions, so short records (super-k-mers hold ~10 windows) still fill the wave.
+// offsets == nullptr: fixed stride.
 template <int W, class F>
-__device__ __forceinline__ void for_each_window(const u32 *tile, u64 a0, u64 r0, int nr, const u32 *offsets, u32 stride, int k, F f) {
+__device__ __forceinline__ void for_each_window(const u32 *tile, u64 a0, u64 r0, int nr, const u32 *offsets, u32 stride, int k,
+                                                int G, F f) {
     const uint8_t *tb = reinterpret_cast<const uint8_t *>(tile);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    for (int r = wave; r < nr; r += nwaves) {
+    const int per_wave = 64 / G, sub = lane / G, gl = lane & (G - 1);
+    for (int r = wave * per_wave + sub; r < nr; r += nwaves * per_wave) {
         const u32 ro = (u32)((offsets ? (u64)offsets[r0 + r] : (r0 + r) * stride) - a0);
         const int nk = (int)tb[ro] - k + 1;           // [len:u8]; reads shorter than k are skipped
         const u32 bit0 = (ro + 1) * 8;
-        for (int p = lane; p < nk; p += 64) f(tile_kmer(tile, bit0 + 2 * p, k, (Kmer<W> *)nullptr));
+        for (int p = gl; p < nk; p += G) f(tile_kmer(tile, bit0 + 2 * p, k, (Kmer<W> *)nullptr));
     }
 }
 

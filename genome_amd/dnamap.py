@@ -56,11 +56,23 @@ class Context:
         L.check(L.lib().gk_synth_reads_dev(self.h, dptr, nreads, read_len, 0 if mode == "U" else 1, config_id,
                                            first_read, genome_len, int(err * (1 << 24))), self.h)
 
+    def shard_superkmers(self, k: int, d_records: int, nreads: int, read_len: int, P: int, d_out: int, out_cap_records: int):
+        """-> (records per owner, k-mers per owner); raises GkError(GK_E_CAPACITY) if d_out is too small
+        (the error message carries the number of records needed)."""
+        rc_, kc = np.zeros(P, np.uint64), np.zeros(P, np.uint64)
+        L.check(L.lib().gk_shard_superkmers_dev(self.h, k, d_records, nreads, read_len, P, d_out, out_cap_records,
+                                                L.ptr(rc_, C.c_uint64), L.ptr(kc, C.c_uint64)), self.h)
+        return rc_, kc
+
     def shard_reads(self, k: int, d_records: int, nreads: int, read_len: int, P: int, d_keys_out: int, keys_cap: int):
         counts = np.zeros(P, np.uint64)
         L.check(L.lib().gk_shard_reads_dev(self.h, k, d_records, nreads, read_len, P, d_keys_out, keys_cap,
                                            L.ptr(counts, C.c_uint64)), self.h)
         return counts
+
+
+def skm_slot_bytes(k: int) -> int:
+    return L.lib().gk_skm_slot_bytes(k)
 
 
 def _keys(k: int, keys):
@@ -167,6 +179,11 @@ class HipDNAMap:
     def count_reads_dev(self, d_records: int, nreads: int, read_len: int) -> int:
         occ = C.c_uint64()
         L.check(L.lib().gk_map_count_reads_dev(self.h, d_records, nreads, read_len, C.byref(occ)), self.ctx.h)
+        return occ.value
+
+    def count_superkmers_dev(self, d_records: int, nrecords: int, kmers_total: int) -> int:
+        occ = C.c_uint64()
+        L.check(L.lib().gk_map_count_superkmers_dev(self.h, d_records, nrecords, kmers_total, C.byref(occ)), self.ctx.h)
         return occ.value
 
     def clear(self):

@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib as L
-from .dnamap import Context, HipDNAMap, _keys
+from .dnamap import Context, HipDNAMap, _keys, skm_slot_bytes
 
 
 def owner_of(k: int, lo: int, hi: int, P: int) -> int:
@@ -67,7 +67,35 @@ class PartitionedDNAMap:
             p.deleteAll_lt(rounds)
 
     def count_reads_dev(self, d_records: int, nreads: int, read_len: int) -> int:
-        """extract + canonicalise + bucket by owner on the device, then owner-side inserts."""
+        """Route by super-k-mers (gk_shard_superkmers_dev), then every owner counts the records it got
+        with the ordinary read pipeline — the single-device rehearsal of the RCCL exchange."""
+        nk = max(0, read_len - self.k + 1)
+        if nreads * nk == 0:
+            return 0
+        slot = skm_slot_bytes(self.k)
+        cap = max(1024 * self.P, nreads * 16)
+        while True:
+            d_out = self.ctx.alloc(cap * slot)
+            try:
+                recs, kmers = self.ctx.shard_superkmers(self.k, d_records, nreads, read_len, self.P, d_out, cap)
+            except L.GkError as e:
+                self.ctx.free(d_out)
+                if e.code != L.GK_E_CAPACITY:
+                    raise
+                cap = cap * 4
+                continue
+            break
+        try:
+            region = cap // self.P                        # owner p's records start at slot p * region
+            for p in range(self.P):
+                if recs[p]:
+                    self.parts[p].count_superkmers_dev(d_out + p * region * slot, int(recs[p]), int(kmers[p]))
+        finally:
+            self.ctx.free(d_out)
+        return int(kmers.sum())
+
+    def count_reads_dev_keys(self, d_records: int, nreads: int, read_len: int) -> int:
+        """extract + canonicalise + bucket 8/16-B keys by owner on the device, then owner-side inserts."""
         nk = max(0, read_len - self.k + 1)
         total = nreads * nk
         if total == 0:
@@ -153,3 +181,26 @@ def exchange_keys(dist, send, send_counts, W: int, recv=None, group=None):
                            output_split_sizes=[int(c) * W for c in recv_counts],
                            input_split_sizes=[int(c) * W for c in send_counts], group=group)
     return recv, recv_counts
+
+
+def exchange_records(dist, send, rec_counts, kmer_counts, slot: int, region_records: int, recv=None, group=None):
+    """The exchange step for super-k-mer records (gk_shard_superkmers_dev): `send` is a uint8 tensor
+    cut into P regions of `region_records` slots, region p holding rec_counts[p] records for rank p.
+    One all-to-all of (records, k-mers) per peer, one of the record bytes (RCCL over xGMI on GPU
+    tensors, gloo on CPU tensors).  Returns (recv uint8 tensor with the records packed back to back,
+    records received, k-mers received)."""
+    import torch
+    P = len(rec_counts)
+    sc = torch.as_tensor(np.stack([np.asarray(rec_counts, np.int64), np.asarray(kmer_counts, np.int64)], axis=1).reshape(-1),
+                         device=send.device)
+    rc = torch.empty_like(sc)
+    dist.all_to_all_single(rc, sc, group=group)
+    rcn = rc.cpu().numpy().reshape(P, 2)
+    nrec, nkm = int(rcn[:, 0].sum()), int(rcn[:, 1].sum())
+    if recv is None or recv.numel() < nrec * slot:
+        recv = torch.empty(max(nrec * slot, slot), dtype=torch.uint8, device=send.device)
+    ins = [send[p * region_records * slot: (p * region_records + int(rec_counts[p])) * slot] for p in range(P)]
+    off = np.concatenate([[0], np.cumsum(rcn[:, 0])]).astype(np.int64)
+    outs = [recv[int(off[p]) * slot: int(off[p + 1]) * slot] for p in range(P)]
+    dist.all_to_all(outs, ins, group=group)
+    return recv, nrec, nkm

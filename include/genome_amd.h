@@ -128,6 +128,19 @@ int gk_map_last_phase_ms(gk_map *m, float *ms5);
  * (RCCL all-to-all) and feed what a rank receives to gk_map_update_inc_dev. */
 int gk_shard_reads_dev(gk_ctx *ctx, int k, const void *dev_records, uint64_t nreads, int read_len, int P,
                        void *dev_keys_out, uint64_t keys_cap, uint64_t *counts_host);
+/* The same routing, shipped as SUPER-K-MERS: every maximal run of consecutive same-owner windows of
+ * a read becomes one record — the run's bases in the `.bin` framing [len:u8][2-bit bases] inside a
+ * fixed slot of gk_skm_slot_bytes(k) bytes (16 for k<=31, 32 for k>=34; longer runs are split).
+ * ~8x fewer bytes than 8/16-B keys cross xGMI; the owner re-extracts and canonicalises, exactly as
+ * FreqFilter.add does on the original reads: feed what a rank receives to
+ * gk_map_count_superkmers_dev.  dev_out is cut into P regions of out_cap_records / P slots; owner p's
+ * records fill the start of region p; rec_counts_host[p] / kmer_counts_host[p] = records / windows
+ * for owner p.  If a region is too small the call fails with GK_E_CAPACITY after filling the counts
+ * (max of rec_counts_host = slots a region needs); retry with a larger buffer. */
+int gk_skm_slot_bytes(int k);
+int gk_shard_superkmers_dev(gk_ctx *ctx, int k, const void *dev_records, uint64_t nreads, int read_len, int P,
+                            void *dev_out, uint64_t out_cap_records, uint64_t *rec_counts_host, uint64_t *kmer_counts_host);
+int gk_map_count_superkmers_dev(gk_map *m, const void *dev_records, uint64_t nrecords, uint64_t kmers_total, uint64_t *occurrences);
 /* owner of one key under the same function (host-side, for tests and for routing point queries) */
 int gk_owner_of(int k, uint64_t lo, uint64_t hi, int P);
 

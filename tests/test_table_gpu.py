@@ -303,3 +303,65 @@ def test_partitioned_path_heavy_hitters_and_tiny_batches(ctx):
     m.count_reads(one, 1); ref.count_reads(one, 1)
     assert_same_table(m.sorted_items(), ref.export_sorted())
     m.close()
+
+
+@pytest.mark.parametrize("k,L_,P", [(31, 150, 8), (21, 100, 3), (11, 60, 2), (55, 150, 8), (63, 200, 4), (34, 255, 5)])
+def test_superkmer_records(ctx, k, L_, P):
+    """gk_shard_superkmers_dev: every record is a run of same-owner windows of one read, in the `.bin`
+    framing; together the records hold every window exactly once (multiset of canonical k-mers ==
+    the oracle's table) and every window sits with the owner gk_owner_of names."""
+    from genome_amd.dnamap import skm_slot_bytes
+    n = 1500
+    rec = synth.reads_mode_g(n, L_, 20000, 0.02, config_id=k * 7 + P)
+    d = ctx.alloc(rec.size + 64)
+    ctx.upload(d, rec)
+    slot = skm_slot_bytes(k)
+    assert slot == (16 if k <= 31 else 32)
+    with pytest.raises(L.GkError) as e:                       # too small: counts are still reported
+        ctx.shard_superkmers(k, d, n, L_, P, ctx.alloc(64), 2)
+    assert e.value.code == L.GK_E_CAPACITY
+    cap = n * (L_ - k + 1) * P
+    region = cap // P
+    d_out = ctx.alloc(cap * slot)
+    recs, kmers = ctx.shard_superkmers(k, d, n, L_, P, d_out, cap)
+    assert int(kmers.sum()) == n * (L_ - k + 1)
+    if k >= 21:
+        assert int(recs.sum()) < int(kmers.sum()) / 3         # runs, not single windows (k == m has no shared minimizers)
+    ref = O.PMap(k, 1)
+    ref.count_reads(rec.tobytes(), n)
+    got = O.PMap(k, 1)
+    max_bases = (slot - 1) * 4
+    packed = []
+    for p in range(P):
+        part = ctx.download(d_out + p * region * slot, int(recs[p]) * slot).reshape(-1, slot)   # owner p's region
+        packed.append(part)
+        lens = part[:, 0].astype(int)
+        assert (lens >= k).all() and (lens <= max_bases).all()
+        assert int((lens - k + 1).sum()) == int(kmers[p])
+        # padding after the last base is zero; the record parses as a `.bin` record of its own
+        for row in part[:: max(1, len(part) // 60)]:
+            ln = int(row[0]); nb = (ln + 3) // 4
+            assert not row[1 + nb:].any()
+            if ln % 4:
+                assert int(row[nb]) >> (2 * (ln % 4)) == 0
+            s = R.reads_from_bin(bytes(row[:1 + nb]), 1)[0]
+            for i in range(0, ln - k + 1, 7):
+                lo, hi = dna.pack(s[i:i + k])
+                assert owner_of(k, lo, hi, P) == p
+        # the `.bin` framing lets the oracle count the records directly (strip the slot padding)
+        stream = b"".join(bytes(row[:1 + (int(row[0]) + 3) // 4]) for row in part)
+        got.count_reads(stream, len(part))
+    assert_same_table(got.export_sorted(), ref.export_sorted())
+    # and the GPU owner-side count of the records gives the same table through both insert paths
+    allrec = np.concatenate(packed)
+    d_all = ctx.alloc(allrec.size + 64)
+    ctx.upload(d_all, allrec)
+    for path in ("direct", "partitioned"):
+        m = HipDNAMap(ctx, k)
+        m.set_insert_path(path)
+        assert m.count_superkmers_dev(d_all, int(recs.sum()), int(kmers.sum())) == int(kmers.sum())
+        assert_same_table(m.sorted_items(), ref.export_sorted())
+        with pytest.raises(L.GkError):
+            m.count_superkmers_dev(d_all, int(recs.sum()), int(kmers.sum()) - 1)   # announced count must match
+        m.close()
+    ctx.free(d_out); ctx.free(d); ctx.free(d_all)
