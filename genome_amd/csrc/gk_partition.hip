@@ -36,11 +36,11 @@
 using namespace gk;
 
 static constexpr int PBLOCK = 512;          // threads of the key-streaming kernels
-static constexpr int KEYS_PER_THREAD = 16;
+static constexpr int KEYS_PER_THREAD = 8;
 static constexpr int PTILE_READS = 256;     // reads per LDS tile in P1/P2 (runs of ~120 keys per bucket)
 static constexpr int PTILE_WORDS = PTILE_READS * 65 / 4 + 64;
 static constexpr int TILE2 = PBLOCK * KEYS_PER_THREAD;   // keys per chunk in P3/P4
-static constexpr u32 MAX_NB2 = 4096;        // LDS bound in P3/P4 (12 B per fine bucket, 48 KiB)
+static constexpr u32 MAX_NB2 = 4096;        // LDS bound in P3/P4 (12 B per fine bucket on top of the sorted chunk)
 
 struct PartArrays {
     unsigned long long *hist1;      // [256]
@@ -61,6 +61,25 @@ template <int W> __device__ __forceinline__ Kmer<W> load_key(const u64 *keys, u6
 template <int W> __device__ __forceinline__ void store_key(u64 *keys, u64 i, Kmer<W> x) {
     if constexpr (W == 1) keys[i] = x.lo;
     else { keys[2 * i] = x.lo; keys[2 * i + 1] = x.hi; }
+}
+
+// block-wide (PBLOCK threads) in-place exclusive scan of arr[0..n) in LDS; returns nothing, arr[i]
+// becomes the sum of the elements before i.  wsum: PBLOCK/64 scratch words.
+__device__ __forceinline__ void block_scan_inplace(u32 *arr, u32 n, u32 *wsum) {
+    const u32 per = (n + PBLOCK - 1) / PBLOCK;
+    const u32 b0 = threadIdx.x * per, b1 = min(b0 + per, n);
+    u32 sum = 0;
+    for (u32 b = b0; b < b1; b++) sum += arr[b];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 inc = sum;
+    for (int d = 1; d < 64; d <<= 1) { u32 tt = __shfl_up(inc, d); if (lane >= d) inc += tt; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    u32 pre = 0;
+    for (int w = 0; w < wave; w++) pre += wsum[w];
+    u32 run = pre + inc - sum;
+    for (u32 b = b0; b < b1; b++) { const u32 c = arr[b]; arr[b] = run; run += c; }
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -146,15 +165,21 @@ __global__ __launch_bounds__(BLOCK) void k_part_hist1_keys(const u64 *__restrict
     if (hist[threadIdx.x]) atomicAdd(&hist1[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
 }
 
-// generic chunked scatter of a key range into `nbins` bins: used for P2 (keys source, bin = L1
-// bucket) and P4 (bin = fine bucket inside one L1 bucket).  LDS: nbins u32.
+// Chunked scatter of a key range into `nbins` bins, used for P2 from keys (bin = L1 bucket) and P4
+// (bin = fine bucket inside one L1 bucket).  The chunk is SORTED BY BIN IN LDS first and then
+// written out linearly, so that consecutive lanes store consecutive addresses: a store instruction
+// whose 64 lanes hit 64 different lines is issued one line at a time (the scattered form of this
+// kernel was bound by exactly that, whatever the run length), while a sorted write-out touches a
+// handful of lines per instruction.  LDS (dynamic): sorted keys [TILE2 * W], bin of each sorted
+// position [TILE2] u16, per-bin offset [nbins] u32, per-bin destination [nbins] u64.
 template <int W, int LEVEL>
 __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u64 begin, u32 cnt, const Table<W> &t, u32 nbins,
-                                              u32 *lds_hist, unsigned long long *lds_base, const unsigned long long *bin_base,
-                                              unsigned long long *cursor64, u32 *cursor32, u64 bin0, u64 *__restrict__ out) {
+                                              u64 *sorted, uint16_t *binof, u32 *off, unsigned long long *gb, u32 *wsum,
+                                              const unsigned long long *bin_base, unsigned long long *cursor64, u32 *cursor32,
+                                              u64 bin0, u64 *__restrict__ out) {
     Kmer<W> key[KEYS_PER_THREAD];
-    u32 bin[KEYS_PER_THREAD];
-    for (u32 b = threadIdx.x; b < nbins; b += PBLOCK) lds_hist[b] = 0;
+    u32 bin[KEYS_PER_THREAD], rank[KEYS_PER_THREAD];
+    for (u32 b = threadIdx.x; b < nbins; b += PBLOCK) off[b] = 0;
     __syncthreads();
     // all loads first, unconditionally (index clamped): one memory round trip per chunk instead of
     // one per key — a load inside `if (i < cnt)` is sunk next to its use and serialises
@@ -170,36 +195,58 @@ __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u64 be
         if (i < cnt) {
             const u64 h = slot_hash(key[j]);
             bin[j] = LEVEL == 1 ? seg_l1(t, h) : seg_fine(t, h);
-            atomicAdd(&lds_hist[bin[j]], 1u);
+            rank[j] = atomicAdd(&off[bin[j]], 1u);             // rank inside its bin
         }
     }
     __syncthreads();
-    for (u32 b = threadIdx.x; b < nbins; b += PBLOCK) {
-        const u32 c = lds_hist[b];
+    for (u32 b = threadIdx.x; b < nbins; b += PBLOCK) {        // reserve the bin's run in the output
+        const u32 c = off[b];
         if (c) {
-            if (LEVEL == 1) lds_base[b] = bin_base[b] + atomicAdd(&cursor64[b], (unsigned long long)c);
-            else lds_base[b] = bin_base[bin0 + b] + atomicAdd(&cursor32[bin0 + b], c);
+            if (LEVEL == 1) gb[b] = bin_base[b] + atomicAdd(&cursor64[b], (unsigned long long)c);
+            else gb[b] = bin_base[bin0 + b] + atomicAdd(&cursor32[bin0 + b], c);
         }
-        lds_hist[b] = 0;
     }
     __syncthreads();
+    block_scan_inplace(off, nbins, wsum);                      // counts -> offsets in the sorted chunk
 #pragma unroll
     for (int j = 0; j < KEYS_PER_THREAD; j++)
-        if (bin[j] != 0xffffffffu) store_key<W>(out, lds_base[bin[j]] + atomicAdd(&lds_hist[bin[j]], 1u), key[j]);
+        if (bin[j] != 0xffffffffu) {
+            const u32 pos = off[bin[j]] + rank[j];
+            store_key<W>(sorted, pos, key[j]);
+            binof[pos] = (uint16_t)bin[j];
+        }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < cnt; i += PBLOCK) {          // linear, coalesced write-out
+        const u32 b = binof[i];
+        store_key<W>(out, gb[b] + (i - off[b]), load_key<W>(sorted, i));
+    }
     __syncthreads();
 }
+
+// dynamic LDS carve for scatter_chunk
+template <int W> struct ScatterLds {
+    u64 *sorted; uint16_t *binof; u32 *off; unsigned long long *gb; u32 *wsum;
+    __device__ __forceinline__ ScatterLds(unsigned long long *base, u32 nbins) {
+        gb = base;                                                       // [nbins] u64
+        sorted = reinterpret_cast<u64 *>(base + nbins);                  // [TILE2 * W] u64
+        off = reinterpret_cast<u32 *>(sorted + (size_t)TILE2 * W);       // [nbins] u32
+        wsum = off + nbins;                                              // [PBLOCK / 64]
+        binof = reinterpret_cast<uint16_t *>(wsum + PBLOCK / 64);        // [TILE2] u16
+    }
+    static size_t bytes(u32 nbins) { return (size_t)nbins * 12 + (size_t)TILE2 * W * 8 + (PBLOCK / 64) * 4 + (size_t)TILE2 * 2 + 16; }
+};
 
 template <int W>
 __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_keys(const u64 *__restrict__ keys, u64 n, Table<W> t,
                                                                const unsigned long long *l1_base, unsigned long long *cursor1,
                                                                u64 *__restrict__ out) {
-    __shared__ u32 lds_hist[256];
-    __shared__ unsigned long long lds_base[256];
+    extern __shared__ unsigned long long lds_dyn1[];
+    ScatterLds<W> L(lds_dyn1, 256u);
     const u64 nchunks = (n + TILE2 - 1) / TILE2;
     for (u64 c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const u64 begin = c * TILE2;
         const u32 cnt = (u32)min((u64)TILE2, n - begin);
-        scatter_chunk<W, 1>(keys, begin, cnt, t, 256u, lds_hist, lds_base, l1_base, cursor1, nullptr, 0, out);
+        scatter_chunk<W, 1>(keys, begin, cnt, t, 256u, L.sorted, L.binof, L.off, L.gb, L.wsum, l1_base, cursor1, nullptr, 0, out);
     }
 }
 
@@ -291,16 +338,15 @@ template <int W>
 __global__ __launch_bounds__(PBLOCK) void k_part_scatter2(const u64 *__restrict__ bufA, Table<W> t, PartArrays a, u64 max_chunks,
                                                           u64 *__restrict__ bufB) {
     extern __shared__ unsigned long long lds_dyn[];
-    unsigned long long *lds_base = lds_dyn;                       // [nb2]
-    u32 *lds_hist = reinterpret_cast<u32 *>(lds_dyn + t.nb2);     // [nb2]
+    ScatterLds<W> L(lds_dyn, t.nb2);
     const u64 total_chunks = a.cbase[256];
     for (u64 c = blockIdx.x; c < total_chunks && c < max_chunks; c += gridDim.x) {
         const u32 b1 = chunk_bucket(a.cbase, c);
         const u64 bsize = a.l1_base[b1 + 1] - a.l1_base[b1];
         const u64 begin = (c - a.cbase[b1]) * TILE2;
         const u32 cnt = (u32)min((u64)TILE2, bsize - begin);
-        scatter_chunk<W, 2>(bufA, a.l1_base[b1] + begin, cnt, t, t.nb2, lds_hist, lds_base, a.fine_base, nullptr, a.cursor2,
-                            (u64)b1 * t.nb2, bufB);
+        scatter_chunk<W, 2>(bufA, a.l1_base[b1] + begin, cnt, t, t.nb2, L.sorted, L.binof, L.off, L.gb, L.wsum, a.fine_base, nullptr,
+                            a.cursor2, (u64)b1 * t.nb2, bufB);
     }
 }
 
@@ -462,6 +508,15 @@ static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads
     const u32 nb1 = 1u << m->lnb1;
     const u64 nseg = t.nseg();
     const int cu8 = ctx->cu_count * 8;
+    const size_t lds = ((size_t)1 << SegBits<W>::value) * sizeof(Slot<W>) + 16;
+    if (!ps->lds_attr_set) {
+        GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<W>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)ScatterLds<W>::bytes(MAX_NB2)));
+        GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter1_keys<W>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)ScatterLds<W>::bytes(256u)));
+        GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_seg_insert<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ps->lds_attr_set = true;
+    }
     // P1 + prefix + P2
     GK_HIP(ctx, hipEventRecord(ctx->pev[0], ctx->stream));
     if (d_rec) {
@@ -470,6 +525,8 @@ static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads
         hipLaunchKernelGGL(k_part_hist1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k, group, t, a.hist1, m->d_ctr);
         hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(256), 0, ctx->stream, a, nb1);
         GK_HIP(ctx, hipEventRecord(ctx->pev[1], ctx->stream));
+        // (A variant that also sorts THIS kernel's keys in LDS before writing was measured slower,
+        //  0.76 vs 0.68 ms at C2: P2 is bound by the two window-extraction passes, not by its stores.)
         hipLaunchKernelGGL(k_part_scatter1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k, group, t,
                            a.l1_base, a.cursor1, ps->bufA);
     } else {
@@ -478,7 +535,7 @@ static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads
         hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(256), 0, ctx->stream, a, nb1);
         GK_HIP(ctx, hipEventRecord(ctx->pev[1], ctx->stream));
         const int g2 = (int)std::min<u64>(std::max<u64>((nkeys_in + TILE2 - 1) / TILE2, 1), (u64)ctx->cu_count * 4);
-        hipLaunchKernelGGL(k_part_scatter1_keys<W>, dim3(g2), dim3(PBLOCK), 0, ctx->stream, d_keys, nkeys_in, t, a.l1_base, a.cursor1, ps->bufA);
+        hipLaunchKernelGGL(k_part_scatter1_keys<W>, dim3(g2), dim3(PBLOCK), ScatterLds<W>::bytes(256u), ctx->stream, d_keys, nkeys_in, t, a.l1_base, a.cursor1, ps->bufA);
     }
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipEventRecord(ctx->pev[2], ctx->stream));
@@ -489,15 +546,10 @@ static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads
     hipLaunchKernelGGL(k_part_hist2<W>, dim3(gchunks), dim3(PBLOCK), m->nb2 * 4, ctx->stream, ps->bufA, t, a, max_chunks);
     hipLaunchKernelGGL(k_part_prefix2, dim3(nb1), dim3(256), 0, ctx->stream, a, nb1, m->nb2);
     GK_HIP(ctx, hipEventRecord(ctx->pev[3], ctx->stream));
-    hipLaunchKernelGGL(k_part_scatter2<W>, dim3(gchunks), dim3(PBLOCK), m->nb2 * 12, ctx->stream, ps->bufA, t, a, max_chunks, ps->bufB);
+    hipLaunchKernelGGL(k_part_scatter2<W>, dim3(gchunks), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2), ctx->stream, ps->bufA, t, a, max_chunks, ps->bufB);
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipEventRecord(ctx->pev[4], ctx->stream));
     // P5
-    const size_t lds = ((size_t)1 << SegBits<W>::value) * sizeof(Slot<W>) + 16;
-    if (!ps->lds_attr_set) {
-        GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_seg_insert<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        ps->lds_attr_set = true;
-    }
     const int gseg = (int)std::min<u64>(nseg, (u64)ctx->cu_count * 24);
     hipLaunchKernelGGL(k_seg_insert<W>, dim3(gseg), dim3(SBLOCK), lds, ctx->stream, t, fine_keys, a, from_empty ? 1 : 0, m->d_ctr);
     GK_HIP(ctx, hipGetLastError());

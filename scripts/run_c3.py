@@ -1,0 +1,42 @@
+"""BASELINE.json configs[2] rehearsal: N x 150 bp reads over an E. coli-scale genome, k=31, one GPU:
+count (chunked) -> deleteAll(<3) -> buildGraph -> removeBubbles -> simplifyGraph -> retainLargest, timed.
+usage: python scripts/run_c3.py [reads=5000000] [genome=4600000] [err=0.005]"""
+import sys, time, json
+sys.path.insert(0, '.')
+import numpy as np
+from genome_amd import synth
+from genome_amd.dnamap import Context, HipDNAMap
+from genome_amd.graph import buildGraph
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 4_600_000
+err = float(sys.argv[3]) if len(sys.argv) > 3 else 0.005
+L, k, chunk = 150, 31, 2_000_000
+ctx = Context(0)
+stride = synth.record_stride(L)
+d = ctx.alloc(chunk * stride + 64)
+m = HipDNAMap(ctx, k, 0)
+t = {}
+t0 = time.perf_counter(); occ = 0; tgen = 0.0
+for first in range(0, n, chunk):
+    c = min(chunk, n - first)
+    g0 = time.perf_counter()
+    ctx.synth_reads(d, c, L, "G", 3, first, G, err)
+    tgen += time.perf_counter() - g0
+    occ += m.count_reads_dev(d, c, L)
+t["count_s"] = time.perf_counter() - t0 - tgen
+distinct = m.size(); st = m.stats()
+t0 = time.perf_counter(); m.deleteAll_lt(3); t["filter_s"] = time.perf_counter() - t0
+good = m.size()
+t0 = time.perf_counter(); g = buildGraph(k, m); t["build_s"] = time.perf_counter() - t0
+c0 = g.counts()
+t0 = time.perf_counter(); g.removeBubbles(); t["bubbles_s"] = time.perf_counter() - t0
+c1 = g.counts()
+t0 = time.perf_counter(); g.simplifyGraph(); t["simplify_s"] = time.perf_counter() - t0
+c2 = g.counts()
+t0 = time.perf_counter(); kept, comps = g.retainLargest(); t["retain_s"] = time.perf_counter() - t0
+c3 = g.counts()
+print(json.dumps({"reads": n, "genome": G, "err": err, "occurrences": occ, "distinct": distinct, "good_kmers": good,
+                  "table": {k_: st[k_] for k_ in ("slots", "grows", "partitioned_launches", "direct_launches")},
+                  "occ_per_s_count": occ / t["count_s"], "graph_built": c0, "after_bubbles": c1, "after_simplify": c2,
+                  "components": comps, "largest": c3, "times": {k_: round(v, 4) for k_, v in t.items()}}))
