@@ -32,6 +32,8 @@ template <int W> struct Kmer;
 template <> struct Kmer<1> { u64 lo; };
 template <> struct Kmer<2> { u64 lo, hi; };
 
+GK_HD u64 low_mask(int nbits) { return nbits >= 64 ? ~0ULL : ((1ULL << nbits) - 1ULL); }
+
 GK_HD bool operator==(Kmer<1> a, Kmer<1> b) { return a.lo == b.lo; }
 GK_HD bool operator==(Kmer<2> a, Kmer<2> b) { return a.lo == b.lo && a.hi == b.hi; }
 GK_HD bool kmer_less(Kmer<1> a, Kmer<1> b) { return a.lo < b.lo; }
@@ -61,10 +63,11 @@ GK_HD Kmer<1> revcomp(Kmer<1> x, int k) {
     r.lo = rev_groups(~x.lo) >> (64 - 2 * k);
     return r;
 }
-GK_HD Kmer<2> revcomp(Kmer<2> x, int k) {   // 34 <= k <= 63  =>  shift s in [2, 60]
+GK_HD Kmer<2> revcomp(Kmer<2> x, int k) {   // 34 <= k <= 64  =>  shift s in [0, 60]
     u64 nlo = rev_groups(~x.hi), nhi = rev_groups(~x.lo);
     int s = 128 - 2 * k;
     Kmer<2> r;
+    if (s == 0) { r.lo = nlo; r.hi = nhi; return r; }
     r.lo = (nlo >> s) | (nhi << (64 - s));
     r.hi = nhi >> s;
     return r;
@@ -109,7 +112,7 @@ GK_HD Kmer<1> prepend_base(int b, Kmer<1> x, int k) {
 }
 GK_HD Kmer<2> prepend_base(int b, Kmer<2> x, int k) {
     Kmer<2> r;
-    r.hi = ((x.hi << 2) | (x.lo >> 62)) & ((1ULL << (2 * (k - 32))) - 1);
+    r.hi = ((x.hi << 2) | (x.lo >> 62)) & low_mask(2 * (k - 32));
     r.lo = (x.lo << 2) | (u64)b;
     return r;
 }
@@ -182,14 +185,19 @@ template <> struct __attribute__((aligned(32))) Slot<2> { u64 w0; u64 w1; u32 ex
 
 // Stored form.  W=1: the key itself (k<=31 leaves the two top bits clear).  W=2: two 63-bit
 // halves, bits 0..62 and 63..125 of the 128-bit k-mer, so each word has a spare top bit and each
-// can be claimed by its own 64-bit CAS (there is no 128-bit CAS).
+// can be claimed by its own 64-bit CAS (there is no 128-bit CAS).  k=64 has two bits more than
+// that (its last base, bits 126..127): the TAG.  A tagged table keeps them in the slot ADDRESS:
+// a key may only sit in slots whose index is = tag (mod 4), probing steps by 4, so the stored 126
+// bits plus the slot index give the key back.
 template <int W> struct Stored;
 template <> struct Stored<1> { u64 w0; };
 template <> struct Stored<2> { u64 w0, w1; };
 GK_HD Stored<1> to_stored(Kmer<1> x) { return Stored<1>{x.lo}; }
-GK_HD Stored<2> to_stored(Kmer<2> x) { return Stored<2>{x.lo & 0x7fffffffffffffffULL, (x.lo >> 63) | (x.hi << 1)}; }
-GK_HD Kmer<1> from_stored(Stored<1> s) { return Kmer<1>{s.w0}; }
-GK_HD Kmer<2> from_stored(Stored<2> s) { return Kmer<2>{s.w0 | (s.w1 << 63), s.w1 >> 1}; }
+GK_HD Stored<2> to_stored(Kmer<2> x) { return Stored<2>{x.lo & 0x7fffffffffffffffULL, (x.lo >> 63) | ((x.hi << 1) & 0x7fffffffffffffffULL)}; }
+GK_HD u32 key_tag(Kmer<1>) { return 0u; }
+GK_HD u32 key_tag(Kmer<2> x) { return (u32)(x.hi >> 62); }
+GK_HD Kmer<1> from_stored(Stored<1> s, u32 = 0u) { return Kmer<1>{s.w0}; }
+GK_HD Kmer<2> from_stored(Stored<2> s, u32 tag = 0u) { return Kmer<2>{s.w0 | (s.w1 << 63), (s.w1 >> 1) | ((u64)tag << 62)}; }
 GK_D Stored<1> load_stored(const Slot<1> *s) { return Stored<1>{s->w0}; }
 GK_D Stored<2> load_stored(const Slot<2> *s) { return Stored<2>{s->w0, s->w1}; }
 
@@ -211,6 +219,7 @@ template <int W> struct Table {
     Slot<W> *slots;
     u32 nb2;           // fine buckets per L1 bucket
     u32 lnb1;          // log2(L1 buckets), 0..8
+    u32 tagged;        // 1 for k = 64: slot index mod 4 carries the key's last base
     GK_HD u64 nseg() const { return (u64)nb2 << lnb1; }
     GK_HD u64 capacity() const { return nseg() << SegBits<W>::value; }
 };
@@ -238,7 +247,7 @@ GK_D void add32_noret(u32 *p, u32 v) { (void)__hip_atomic_fetch_add(p, v, __ATOM
 // words are write-once during an insert phase); the CAS decides.  Returns 1 if this call claimed
 // a new slot, 0 if the key was there, -1 if the probe wrapped the whole segment (full).
 template <class CAS, class ADD>
-GK_D int seg_add(Slot<1> *seg, u32 pos, Kmer<1> key, u32 add, CAS cas, ADD addf) {
+GK_D int seg_add(Slot<1> *seg, u32 pos, Kmer<1> key, u32 add, CAS cas, ADD addf, u32 = 0u) {
     constexpr u32 smask = (1u << SegBits<1>::value) - 1u;
     u32 i = pos;
     for (u32 n = 0; n <= smask; ++n) {
@@ -262,11 +271,12 @@ GK_D int seg_add(Slot<1> *seg, u32 pos, Kmer<1> key, u32 add, CAS cas, ADD addf)
 // loser simply moves on to the next slot, and every later probe of that key makes the same
 // decision from the (now immutable) slot contents, so a key never lands in two slots.
 template <class CAS, class ADD>
-GK_D int seg_add(Slot<2> *seg, u32 pos, Kmer<2> key, u32 add, CAS cas, ADD addf) {
+GK_D int seg_add(Slot<2> *seg, u32 pos, Kmer<2> key, u32 add, CAS cas, ADD addf, u32 tagged = 0u) {
     constexpr u32 smask = (1u << SegBits<2>::value) - 1u;
     const Stored<2> k = to_stored(key);
-    u32 i = pos;
-    for (u32 n = 0; n <= smask; ++n) {
+    const u32 step = tagged ? 4u : 1u;
+    u32 i = tagged ? ((pos & ~3u) | key_tag(key)) : pos;
+    for (u32 n = 0; n <= smask; n += step) {
         Slot<2> *s = &seg[i];
         u64 c0 = s->w0;
         int claimed = 0;
@@ -286,7 +296,7 @@ GK_D int seg_add(Slot<2> *seg, u32 pos, Kmer<2> key, u32 add, CAS cas, ADD addf)
                 return claimed;
             }
         }
-        i = (i + 1) & smask;
+        i = (i + step) & smask;
     }
     return -1;
 }
@@ -297,13 +307,13 @@ struct GlobalAdd { GK_D void operator()(u32 *p, u32 v) const { add32_noret(p, v)
 template <int W> GK_D int table_add(const Table<W> &t, Kmer<W> key, u32 add, u32 *err) {
     const u64 h = slot_hash(key);
     Slot<W> *seg = t.slots + ((u64)seg_of(t, h) << SegBits<W>::value);
-    int r = seg_add(seg, seg_pos<W>(h), key, add, GlobalCas(), GlobalAdd());
+    int r = seg_add(seg, seg_pos<W>(h), key, add, GlobalCas(), GlobalAdd(), t.tagged);
     if (r < 0) { *err = 1; return 0; }
     return r;
 }
 
 // Container.apply (ArrayDNAMap.scala:90-101) on a quiescent table: global slot index or -1.
-GK_D i64 seg_find(const Slot<1> *seg, u32 pos, Kmer<1> key) {
+GK_D i64 seg_find(const Slot<1> *seg, u32 pos, Kmer<1> key, u32 = 0u) {
     constexpr u32 smask = (1u << SegBits<1>::value) - 1u;
     u32 i = pos;
     for (u32 n = 0; n <= smask; ++n) {
@@ -314,26 +324,31 @@ GK_D i64 seg_find(const Slot<1> *seg, u32 pos, Kmer<1> key) {
     }
     return -1;
 }
-GK_D i64 seg_find(const Slot<2> *seg, u32 pos, Kmer<2> key) {
+GK_D i64 seg_find(const Slot<2> *seg, u32 pos, Kmer<2> key, u32 tagged = 0u) {
     constexpr u32 smask = (1u << SegBits<2>::value) - 1u;
     const Stored<2> k = to_stored(key);
-    u32 i = pos;
-    for (u32 n = 0; n <= smask; ++n) {
+    const u32 step = tagged ? 4u : 1u;
+    u32 i = tagged ? ((pos & ~3u) | key_tag(key)) : pos;
+    for (u32 n = 0; n <= smask; n += step) {
         u64 c0 = seg[i].w0;
         if (c0 == k.w0 && seg[i].w1 == k.w1) return (i64)i;
         if (c0 == KEY_EMPTY) return -1;
-        i = (i + 1) & smask;
+        i = (i + step) & smask;
     }
     return -1;
 }
 template <int W> GK_D i64 table_find(const Table<W> &t, Kmer<W> key) {
     const u64 h = slot_hash(key);
     const u64 base = (u64)seg_of(t, h) << SegBits<W>::value;
-    i64 r = seg_find(t.slots + base, seg_pos<W>(h), key);
+    i64 r = seg_find(t.slots + base, seg_pos<W>(h), key, t.tagged);
     return r < 0 ? -1 : (i64)base + r;
 }
 template <int W> GK_D bool slot_live(const Slot<W> *s) { return s->w0 != KEY_EMPTY && s->w0 != KEY_TOMB; }
 template <int W> GK_D u32 slot_count(const Slot<W> *s) { return s->extra + 1u; }
+// the key held by slot i of a table (i = global slot index; segments are multiples of 4 slots)
+template <int W> GK_D Kmer<W> slot_key(const Slot<W> *slots, u64 i, u32 tagged) {
+    return from_stored(load_stored(&slots[i]), tagged ? (u32)(i & 3u) : 0u);
+}
 
 // Graph.buildGraph `contains` (Graph.scala:270): either strand.  Only the hash-rule canonical
 // orientation can be a stored key, except in the tie h(x) == h(rc x) where occurrences seen as x

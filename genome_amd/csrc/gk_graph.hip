@@ -133,7 +133,7 @@ __global__ __launch_bounds__(BLOCK) void k_classify(Table<W> t, int k, unsigned 
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < ncap; i += (u64)gridDim.x * BLOCK) {
         Slot<W> *s = &t.slots[i];
         if (!slot_live(s)) continue;
-        Kmer<W> y = from_stored(load_stored(s));
+        Kmer<W> y = slot_key(t.slots, i, t.tagged);
         u32 in = 0, out = 0;
         bool f;
         for (int b = 0; b < 4; b++) {
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(BLOCK) void k_collect_terminals(Table<W> t, int k, 
             sel = (aux & AUX_TERMINAL) && !(aux & AUX_SECONDARY);
             if (sel) {
                 // out(y) + out(rc y) = popc(out) + popc(in); a palindrome (y == rc y, even k) is ONE node
-                Kmer<W> y = from_stored(load_stored(&t.slots[i]));
+                Kmer<W> y = slot_key(t.slots, i, t.tagged);
                 edges += (y == revcomp(y, k)) ? __popc((aux >> 4) & 15u) : __popc(aux & 0xffu);
             }
         }
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(BLOCK) void k_make_nodes(Table<W> t, int k, const u
         if (j < nT) {
             const u64 slot = tslots[j];
             const u32 aux = t.slots[slot].aux;
-            y = from_stored(load_stored(&t.slots[slot]));
+            y = slot_key(t.slots, slot, t.tagged);
             rc = revcomp(y, k);
             pal = (y == rc);
             m0 = (aux >> 4) & 15u;                  // outcoming(y)
@@ -718,7 +718,7 @@ static int graph_build_index(gk_graph *g) {
 
 template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
     gk_ctx *ctx = m->ctx;
-    Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1};
+    Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u};
     const int k = m->k;
     unsigned long long *d_cnt = nullptr;     // [0] terminals [1] cursor [2] edges [3] ecursor [4] pool cursor
     u32 *d_err = nullptr, *slot_node = nullptr;

@@ -58,7 +58,7 @@ int hip_fail(const gk_ctx *ctx, hipError_t e, const char *what);
         if (e__ != hipSuccess) return gk::hip_fail((ctx), e__, #call);      \
     } while (0)
 
-inline bool k_supported(int k) { return (k >= 2 && k <= 31) || (k >= 34 && k <= 63); }
+inline bool k_supported(int k) { return (k >= 2 && k <= 31) || (k >= 34 && k <= 64); }
 inline int words_for_k(int k) { return k <= 32 ? 1 : 2; }
 inline size_t slot_bytes(int W) { return W == 1 ? 16 : 32; }
 inline uint32_t seg_bits_for(int W) { return W == 1 ? gk::SegBits<1>::value : gk::SegBits<2>::value; }

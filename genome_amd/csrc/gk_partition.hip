@@ -411,13 +411,13 @@ __global__ __launch_bounds__(SBLOCK) void k_seg_insert(Table<W> t, const u64 *__
 #pragma unroll
         for (int j = 0; j < SEG_KPT; j++) {
             if (threadIdx.x + j * SBLOCK < nk) {
-                const int r = seg_add(seg, seg_pos<W>(slot_hash(key[j])), key[j], 1u, LdsCas(), LdsAdd());
+                const int r = seg_add(seg, seg_pos<W>(slot_hash(key[j])), key[j], 1u, LdsCas(), LdsAdd(), t.tagged);
                 if (r < 0) overflow = true; else claims += (u32)r;
             }
         }
         for (u64 i = kb + (u64)SBLOCK * SEG_KPT + threadIdx.x; i < ke; i += SBLOCK) {   // heavy buckets (repeats)
             const Kmer<W> kx = load_key<W>(keys, i);
-            const int r = seg_add(seg, seg_pos<W>(slot_hash(kx)), kx, 1u, LdsCas(), LdsAdd());
+            const int r = seg_add(seg, seg_pos<W>(slot_hash(kx)), kx, 1u, LdsCas(), LdsAdd(), t.tagged);
             if (r < 0) overflow = true; else claims += (u32)r;
         }
         for (int d = 32; d; d >>= 1) claims += __shfl_down(claims, d);
@@ -502,7 +502,7 @@ template <int W>
 static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads, const u32 *d_off, u32 stride, int group,
                     const u64 *d_keys, u64 nkeys_in, u64 nkeys_bound, bool from_empty) {
     gk_ctx *ctx = m->ctx;
-    Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1};
+    Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u};
     PartArrays a;
     if (int rc = part_prepare(m, ps, nkeys_bound, &a, true)) return rc;
     const u32 nb1 = 1u << m->lnb1;

@@ -118,11 +118,11 @@ __global__ __launch_bounds__(BLOCK) void k_add_keys(const u64 *__restrict__ keys
 
 // ArrayDNAMap.rescale (ArrayDNAMap.scala:217-230): move every live (key, count) into a new table.
 template <int W>
-__global__ __launch_bounds__(BLOCK) void k_rehash(const Slot<W> *__restrict__ old, u64 ncap, Table<W> t, Counters *ctr) {
+__global__ __launch_bounds__(BLOCK) void k_rehash(const Slot<W> *__restrict__ old, u64 ncap, Table<W> t, Counters *ctr) {   // old and new share t.tagged
     u32 err = 0;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < ncap; i += (u64)gridDim.x * BLOCK) {
         if (!slot_live(&old[i])) continue;
-        Kmer<W> key = from_stored(load_stored(&old[i]));
+        Kmer<W> key = slot_key(old, i, t.tagged);
         table_add(t, key, slot_count(&old[i]), &err);
     }
     if (err) ctr->error = 1;
@@ -181,7 +181,7 @@ __device__ __forceinline__ u32 block_scan_flag(bool flag, u32 *total, u32 *lds4)
 // Container.iterator (ArrayDNAMap.scala:175-178): compact every live (key, count) to dense arrays.
 // One atomic per 256-slot group reserves the output range; order within a group is slot order.
 template <int W>
-__global__ __launch_bounds__(BLOCK) void k_export(const Slot<W> *__restrict__ slots, u64 ncap, u64 *lo, u64 *hi, i32 *cnt,
+__global__ __launch_bounds__(BLOCK) void k_export(const Slot<W> *__restrict__ slots, u64 ncap, u32 tagged, u64 *lo, u64 *hi, i32 *cnt,
                                                   unsigned long long *cursor) {
     __shared__ u32 lds4[BLOCK / 64];
     __shared__ unsigned long long s_base;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(BLOCK) void k_export(const Slot<W> *__restrict__ sl
         if (threadIdx.x == 0 && tot) s_base = atomicAdd(cursor, (unsigned long long)tot);
         __syncthreads();
         if (live) {
-            Kmer<W> key = from_stored(load_stored(&slots[i]));
+            Kmer<W> key = slot_key(slots, i, tagged);
             u64 o = s_base + pos;
             lo[o] = key.lo;
             if constexpr (W == 2) { if (hi) hi[o] = key.hi; }
@@ -216,7 +216,7 @@ static inline int grid_for(const gk_ctx *ctx, u64 work_items, int per_block) {
 }
 
 template <int W> static Table<W> table_of(const gk_map *m) {
-    return Table<W>{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1};
+    return Table<W>{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u};
 }
 
 static int alloc_table(gk_ctx *ctx, int W, uint64_t cap, void **out) {
@@ -242,16 +242,18 @@ int map_sync_counters(gk_map *m) {
     return GK_OK;
 }
 
-static constexpr double MAX_LOAD = 0.8;     // grow before a batch could exceed this
-static constexpr double TARGET_LOAD = 0.65; // load right after sizing / a grow
+// Load limits: grow before a batch could exceed max_load; size for target_load.  A tagged table
+// (k = 64) is four interleaved sub-tables of a quarter segment each, so it runs emptier.
+static inline double max_load(const gk_map *m) { return m->k == 64 ? 0.6 : 0.8; }
+static inline double target_load(const gk_map *m) { return m->k == 64 ? 0.45 : 0.65; }
 
 // ArrayDNAMap.rescale analogue: make room for `extra_keys` more distinct keys.
 int map_reserve(gk_map *m, uint64_t extra_keys) {
     uint64_t need = m->size + m->tombstones + extra_keys;
-    if ((double)need <= MAX_LOAD * (double)m->capacity) return GK_OK;
+    if ((double)need <= max_load(m) * (double)m->capacity) return GK_OK;
     uint32_t nnb2, nlnb1;
     uint64_t ncap;
-    plan_segments(m->W, std::max<uint64_t>((uint64_t)((double)(m->size + extra_keys) / TARGET_LOAD) + 1, m->capacity + m->capacity / 2), &nnb2, &nlnb1, &ncap);
+    plan_segments(m->W, std::max<uint64_t>((uint64_t)((double)(m->size + extra_keys) / target_load(m)) + 1, m->capacity + m->capacity / 2), &nnb2, &nlnb1, &ncap);
     gk_ctx *ctx = m->ctx;
     void *nslots = nullptr;
     int rc = alloc_table(ctx, m->W, ncap, &nslots);
@@ -259,10 +261,10 @@ int map_reserve(gk_map *m, uint64_t extra_keys) {
     int grid = grid_for(ctx, m->capacity, BLOCK);
     if (m->W == 1)
         hipLaunchKernelGGL(k_rehash<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, m->capacity,
-                           Table<1>{(Slot<1> *)nslots, nnb2, nlnb1}, m->d_ctr);
+                           Table<1>{(Slot<1> *)nslots, nnb2, nlnb1, 0u}, m->d_ctr);
     else
         hipLaunchKernelGGL(k_rehash<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots, m->capacity,
-                           Table<2>{(Slot<2> *)nslots, nnb2, nlnb1}, m->d_ctr);
+                           Table<2>{(Slot<2> *)nslots, nnb2, nlnb1, m->k == 64 ? 1u : 0u}, m->d_ctr);
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     GK_HIP(ctx, hipFree(m->slots));
@@ -379,14 +381,14 @@ int gk_map_create(gk_ctx *ctx, int k, uint64_t capacity_hint, gk_map **out) {
     *out = nullptr;
     if (!k_supported(k))
         return fail(ctx, GK_E_UNSUPPORTED_K,
-                    "k=" + std::to_string(k) + " unsupported (2..31 and 34..63; k=32,33 are broken in the reference)");
+                    "k=" + std::to_string(k) + " unsupported (2..31 and 34..64; k=32,33 are broken in the reference)");
     GK_HIP(ctx, hipSetDevice(ctx->device));
     gk_map *m = new gk_map();
     m->ctx = ctx;
     m->k = k;
     m->W = words_for_k(k);
     uint64_t want = capacity_hint ? capacity_hint : 1024;
-    plan_segments(m->W, (uint64_t)((double)want / TARGET_LOAD) + 1, &m->nb2, &m->lnb1, &m->capacity);
+    plan_segments(m->W, (uint64_t)((double)want / target_load(m)) + 1, &m->nb2, &m->lnb1, &m->capacity);
     int rc = alloc_table(ctx, m->W, m->capacity, &m->slots);
     if (rc == GK_OK) {
         hipError_t e = hipMalloc((void **)&m->d_ctr, sizeof(Counters));
@@ -526,7 +528,7 @@ static int launch_partitioned(gk_map *m, const uint8_t *d_rec, u64 nreads, const
 // how many reads (of nk windows each) may go into one launch without risking the load limit
 static u64 reads_per_launch(gk_map *m, u64 nk) {
     if (nk == 0) return ~0ull;
-    double room = MAX_LOAD * (double)m->capacity - (double)(m->size + m->tombstones);
+    double room = max_load(m) * (double)m->capacity - (double)(m->size + m->tombstones);
     u64 floor_occ = std::max<u64>(1ull << 24, m->capacity / 4);
     u64 occ = room > (double)floor_occ ? (u64)room : floor_occ;
     return std::max<u64>(1, occ / nk);
@@ -737,7 +739,7 @@ static int check_key_bits(const gk_map *m, const uint64_t *lo, const uint64_t *h
     for (uint64_t i = 0; i < n; i++) {
         bool bad;
         if (m->W == 1) bad = (lo[i] >> (2 * k)) != 0 || (hi && hi[i] != 0);
-        else bad = (hi[i] >> (2 * (k - 32))) != 0;
+        else bad = k < 64 && (hi[i] >> (2 * (k - 32))) != 0;
         if (bad) return fail(m->ctx, GK_E_KLEN, "key " + std::to_string(i) + " is not a " + std::to_string(k) + "-mer (bits set above 2k)");
     }
     return GK_OK;
@@ -806,17 +808,17 @@ int gk_map_filter_lt(gk_map *m, int32_t rounds) {
     if (m->tombstones) {
         uint32_t nnb2, nlnb1;
         uint64_t ncap;
-        plan_segments(m->W, (uint64_t)((double)m->size / TARGET_LOAD) + 1, &nnb2, &nlnb1, &ncap);
+        plan_segments(m->W, (uint64_t)((double)m->size / target_load(m)) + 1, &nnb2, &nlnb1, &ncap);
         if (ncap > m->capacity) { nnb2 = m->nb2; nlnb1 = m->lnb1; ncap = m->capacity; }
         void *nslots = nullptr;
         if (alloc_table(ctx, m->W, ncap, &nslots) != GK_OK) return GK_OK;   // keep tombstones if memory is short
         int g2 = grid_for(ctx, m->capacity, BLOCK);
         if (m->W == 1)
             hipLaunchKernelGGL(k_rehash<1>, dim3(g2), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, m->capacity,
-                               Table<1>{(Slot<1> *)nslots, nnb2, nlnb1}, m->d_ctr);
+                               Table<1>{(Slot<1> *)nslots, nnb2, nlnb1, 0u}, m->d_ctr);
         else
             hipLaunchKernelGGL(k_rehash<2>, dim3(g2), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots, m->capacity,
-                               Table<2>{(Slot<2> *)nslots, nnb2, nlnb1}, m->d_ctr);
+                               Table<2>{(Slot<2> *)nslots, nnb2, nlnb1, m->k == 64 ? 1u : 0u}, m->d_ctr);
         GK_HIP(ctx, hipGetLastError());
         GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         GK_HIP(ctx, hipFree(m->slots));
@@ -879,8 +881,8 @@ int gk_map_export(gk_map *m, uint64_t *lo, uint64_t *hi, int32_t *counts, uint64
     if (e == hipSuccess) e = hipMemsetAsync(d_cursor, 0, 8, ctx->stream);
     if (e == hipSuccess) {
         int grid = grid_for(ctx, m->capacity, BLOCK);
-        if (m->W == 1) hipLaunchKernelGGL(k_export<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, m->capacity, d_lo, d_hi, d_cnt, d_cursor);
-        else hipLaunchKernelGGL(k_export<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots, m->capacity, d_lo, d_hi, d_cnt, d_cursor);
+        if (m->W == 1) hipLaunchKernelGGL(k_export<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, m->capacity, 0u, d_lo, d_hi, d_cnt, d_cursor);
+        else hipLaunchKernelGGL(k_export<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots, m->capacity, m->k == 64 ? 1u : 0u, d_lo, d_hi, d_cnt, d_cursor);
         e = hipGetLastError();
     }
     unsigned long long written = 0;

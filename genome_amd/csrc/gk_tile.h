@@ -26,7 +26,7 @@ __device__ __forceinline__ Kmer<2> tile_kmer(const u32 *tile, u32 bitpos, int k,
     u64 v2 = tile[wi + 4];
     u64 lo = (v0 >> sh) | (sh ? (v1 << (64 - sh)) : 0ull);
     u64 hi = (v1 >> sh) | (sh ? (v2 << (64 - sh)) : 0ull);
-    return Kmer<2>{lo, hi & ((1ull << (2 * (k - 32))) - 1)};
+    return Kmer<2>{lo, hi & low_mask(2 * (k - 32))};
 }
 
 // Stage the records of reads [r0, r0+nr) into LDS with 16-byte coalesced loads.  The byte range

@@ -20,8 +20,8 @@
  *     bits 2i of lo (i<32) / 2(i-32) of hi, codes A=0 G=1 C=2 T=3, unused high bits zero
  *     (S/dna/DNASeq.scala:74-215, S/dna/Base.scala:13-19).  `hi` arrays may be NULL when k<=32.
  *     Counts are int32 (the reference's DNAMap[Int]).
- *   - Supported k: 2..31 and 34..63.  k=32/33 are broken in the reference itself
- *     and k=64 / k>64 are not implemented here: GK_E_UNSUPPORTED_K.
+ *   - Supported k: 2..31 and 34..64, as in the reference: k=32/33 are broken in the reference itself
+ *      and k>64 takes its un-specialised ArrayDNASeq path: GK_E_UNSUPPORTED_K.
  *   - There is no CPU fallback: without a gfx950 device every compute call fails with
  *     GK_E_NODEVICE / GK_E_HIP.
  */
@@ -39,7 +39,7 @@ typedef enum {
     GK_OK = 0,
     GK_E_INVALID = -1,        /* bad argument (NULL handle, negative size, ...) */
     GK_E_KLEN = -2,           /* key length != the map's k  (ArrayDNAMap.scala:182,187,192,199,206) */
-    GK_E_UNSUPPORTED_K = -3,  /* k outside 2..31, 34..63 */
+    GK_E_UNSUPPORTED_K = -3,  /* k outside 2..31, 34..64 */
     GK_E_CAPACITY = -4,       /* table could not grow / export buffer too small */
     GK_E_HIP = -5,            /* HIP runtime error (message has the hipError string) */
     GK_E_NODEVICE = -6,       /* no usable gfx950 device */

@@ -48,7 +48,7 @@ def test_null_handles_are_errors_not_crashes():
     lib.gk_graph_destroy(None)
 
 
-@pytest.mark.parametrize("k", [5, 11, 21, 31, 34, 47, 55, 63])
+@pytest.mark.parametrize("k", [5, 11, 21, 31, 34, 47, 55, 63, 64])
 def test_owner_is_strand_symmetric(k):
     """The owner function must send x and rc(x) — hence both hash-rule candidates, incl. the tie
     case (FreqFilter.scala:31-32) — to the same partition."""

@@ -79,7 +79,7 @@ def _reads(rnd, n, lmin, lmax, glen, err, haplotypes=1):
     return out
 
 
-@pytest.mark.parametrize("k,seed,hap", [(7, 1, 1), (11, 2, 2), (15, 3, 2), (21, 4, 1), (31, 5, 2), (35, 6, 2), (47, 7, 1), (63, 8, 2)])
+@pytest.mark.parametrize("k,seed,hap", [(7, 1, 1), (11, 2, 2), (15, 3, 2), (21, 4, 1), (31, 5, 2), (35, 6, 2), (47, 7, 1), (63, 8, 2), (64, 9, 2)])
 def test_build_bubbles_simplify_remove_retain_vs_oracle(ctx, k, seed, hap):
     rnd = random.Random(seed)
     reads = _reads(rnd, 900, k + 5, min(255, k + 90), 1500, 0.01, hap)

@@ -66,7 +66,7 @@ def _random_reads(rnd, n, lmin, lmax, genome_len, err):
     return reads
 
 
-@pytest.mark.parametrize("k", [2, 5, 11, 21, 30, 31, 34, 35, 47, 55, 62, 63])
+@pytest.mark.parametrize("k", [2, 5, 11, 21, 30, 31, 34, 35, 47, 55, 62, 63, 64])
 def test_ragged_reads_vs_oracle(ctx, k):
     """Ragged / empty / shorter-than-k records (FreqFilter.scala:29), every supported key width."""
     rnd = random.Random(k)
@@ -108,7 +108,7 @@ def test_truncated_stream_is_a_format_error(ctx):
 
 
 def test_key_length_and_k_errors(ctx):
-    """`assert(key.length == k)` (ArrayDNAMap.scala:182,199) -> GK_E_KLEN; k=32/33/64 unsupported."""
+    """`assert(key.length == k)` (ArrayDNAMap.scala:182,199) -> GK_E_KLEN; k=32/33/>64 unsupported."""
     m = HipDNAMap(ctx, 11)
     with pytest.raises(AssertionError):
         m.apply("AGCT")
@@ -117,13 +117,13 @@ def test_key_length_and_k_errors(ctx):
     with pytest.raises(L.KeyLengthError):
         m.apply_batch([(1, 1)])
     m.close()
-    for k in (0, 1, 32, 33, 64, 65, 100):
+    for k in (0, 1, 32, 33, 65, 100):
         with pytest.raises(L.GkError) as e:
             HipDNAMap(ctx, k)
         assert e.value.code == L.GK_E_UNSUPPORTED_K
 
 
-@pytest.mark.parametrize("k", [21, 55])
+@pytest.mark.parametrize("k", [21, 55, 64])
 def test_apply_contains_update(ctx, k):
     rnd = random.Random(k)
     keys = ["".join(rnd.choice("AGCT") for _ in range(k)) for _ in range(500)]
@@ -147,7 +147,7 @@ def test_apply_contains_update(ctx, k):
     m.close()
 
 
-@pytest.mark.parametrize("k,L_,mode", [(21, 100, "G"), (31, 150, "U"), (31, 150, "G"), (55, 150, "G"), (63, 150, "U")])
+@pytest.mark.parametrize("k,L_,mode", [(21, 100, "G"), (31, 150, "U"), (31, 150, "G"), (55, 150, "G"), (63, 150, "U"), (64, 150, "G")])
 def test_device_resident_reads_and_device_synth(ctx, k, L_, mode):
     """count_reads_dev on records generated on the device == oracle on the numpy generator's bytes."""
     n, G, e, cid = 3000, 20000, 0.01, 7
@@ -170,7 +170,7 @@ def test_device_resident_reads_and_device_synth(ctx, k, L_, mode):
     ctx.free(d)
 
 
-@pytest.mark.parametrize("k,P", [(21, 2), (31, 4), (31, 8), (55, 8), (63, 3)])
+@pytest.mark.parametrize("k,P", [(21, 2), (31, 4), (31, 8), (55, 8), (63, 3), (64, 4)])
 def test_logical_partitions_vs_oracle(ctx, k, P):
     """PartitionedDNAMap: sorted content is independent of P and of the partition function."""
     n, L_ = 2000, 120
@@ -238,7 +238,7 @@ def test_full_size_c2_properties(ctx):
 
 
 @pytest.mark.parametrize("k,L_,n,hint", [(31, 150, 40000, 0), (31, 150, 40000, 6_000_000), (21, 100, 30000, 100), (55, 150, 30000, 0),
-                                          (63, 120, 20000, 3_000_000), (11, 60, 50000, 0)])
+                                          (63, 120, 20000, 3_000_000), (11, 60, 50000, 0), (64, 150, 20000, 0)])
 def test_partitioned_path_equals_direct_and_oracle(ctx, k, L_, n, hint):
     """The LDS segment-build path (gk_partition.hip) and the global-atomic path must produce the
     same table as the oracle: from empty, on top of existing content, after a deferred clear, and
@@ -305,7 +305,7 @@ def test_partitioned_path_heavy_hitters_and_tiny_batches(ctx):
     m.close()
 
 
-@pytest.mark.parametrize("k,L_,P", [(31, 150, 8), (21, 100, 3), (11, 60, 2), (55, 150, 8), (63, 200, 4), (34, 255, 5)])
+@pytest.mark.parametrize("k,L_,P", [(31, 150, 8), (21, 100, 3), (11, 60, 2), (55, 150, 8), (63, 200, 4), (34, 255, 5), (64, 150, 8)])
 def test_superkmer_records(ctx, k, L_, P):
     """gk_shard_superkmers_dev: every record is a run of same-owner windows of one read, in the `.bin`
     framing; together the records hold every window exactly once (multiset of canonical k-mers ==
