@@ -9,6 +9,7 @@
  */
 #include "gk_oracle.h"
 
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -414,6 +415,76 @@ long gko_count_reads(gko_pmap *pm, const uint8_t *bin, size_t nbytes, uint64_t n
             }
         }
     }
+    return occ;
+}
+
+/* PartitionedDNAMap on P host threads, without the network (BASELINE.md variant BP): phase 1, T
+ * reader threads split the records and route every canonical k-mer to a per-(reader, owner) buffer
+ * (owner = hashCode mod P, PartitionedDNAMap.scala:60-63 — the driver side of :41-43); phase 2, one
+ * thread per partition applies its messages in reader order (the actor side, ArrayDNAMap.scala:39,
+ * 198-203).  Per-partition content equals the sequential result (insertion order inside a partition
+ * only changes slot order). */
+typedef struct { gko_kmer *v; size_t n, cap; } keybuf;
+typedef struct {
+    gko_pmap *pm; const uint8_t *bin; const size_t *rec_off; uint64_t r0, r1; keybuf *out /* [P] */; long occ;
+} mt_reader;
+typedef struct { gko_pmap *pm; int p, T; keybuf *bufs /* [T][P] */; } mt_owner;
+
+static void *mt_read_fn(void *arg) {
+    mt_reader *a = (mt_reader *)arg;
+    const int k = a->pm->k, P = a->pm->P;
+    for (uint64_t r = a->r0; r < a->r1; r++) {
+        const uint8_t *recp = a->bin + a->rec_off[r];
+        const int len = recp[0];
+        for (int p = 0; p + k <= len; p++) {
+            gko_kmer y = gko_canon(gko_kmer_from_packed(recp + 1, p, k), k);
+            keybuf *b = &a->out[gko_partition(y, k, P)];
+            if (b->n == b->cap) { b->cap = b->cap ? b->cap * 2 : 4096; b->v = (gko_kmer *)realloc(b->v, b->cap * sizeof(gko_kmer)); }
+            b->v[b->n++] = y;
+            a->occ++;
+        }
+    }
+    return NULL;
+}
+static void *mt_own_fn(void *arg) {
+    mt_owner *a = (mt_owner *)arg;
+    const int P = a->pm->P;
+    for (int t = 0; t < a->T; t++) {
+        keybuf *b = &a->bufs[(size_t)t * P + a->p];
+        for (size_t i = 0; i < b->n; i++) gko_map_update_inc(a->pm->parts[a->p], b->v[i]);
+    }
+    return NULL;
+}
+
+long gko_count_reads_mt(gko_pmap *pm, const uint8_t *bin, size_t nbytes, uint64_t nreads, int nthreads) {
+    const int P = pm->P, T = nthreads < 1 ? 1 : nthreads;
+    size_t *rec_off = (size_t *)malloc((nreads + 1) * sizeof(size_t));
+    size_t pos = 0;
+    for (uint64_t r = 0; r < nreads; r++) {
+        if (pos >= nbytes) { free(rec_off); return -1; }
+        rec_off[r] = pos;
+        pos += 1 + (size_t)(bin[pos] + 3) / 4;
+        if (pos > nbytes) { free(rec_off); return -1; }
+    }
+    keybuf *bufs = (keybuf *)calloc((size_t)T * P, sizeof(keybuf));
+    mt_reader *rd = (mt_reader *)calloc((size_t)T, sizeof(mt_reader));
+    pthread_t *th = (pthread_t *)malloc((size_t)(T > P ? T : P) * sizeof(pthread_t));
+    for (int t = 0; t < T; t++) {
+        rd[t].pm = pm; rd[t].bin = bin; rd[t].rec_off = rec_off;
+        rd[t].r0 = nreads * (uint64_t)t / T; rd[t].r1 = nreads * (uint64_t)(t + 1) / T;
+        rd[t].out = bufs + (size_t)t * P;
+        pthread_create(&th[t], NULL, mt_read_fn, &rd[t]);
+    }
+    long occ = 0;
+    for (int t = 0; t < T; t++) { pthread_join(th[t], NULL); occ += rd[t].occ; }
+    mt_owner *ow = (mt_owner *)calloc((size_t)P, sizeof(mt_owner));
+    for (int p = 0; p < P; p++) {
+        ow[p].pm = pm; ow[p].p = p; ow[p].T = T; ow[p].bufs = bufs;
+        pthread_create(&th[p], NULL, mt_own_fn, &ow[p]);
+    }
+    for (int p = 0; p < P; p++) pthread_join(th[p], NULL);
+    for (size_t i = 0; i < (size_t)T * P; i++) free(bufs[i].v);
+    free(bufs); free(rd); free(ow); free(th); free(rec_off);
     return occ;
 }
 

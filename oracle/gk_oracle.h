@@ -84,6 +84,9 @@ size_t gko_pmap_export_sorted(const gko_pmap *pm, uint64_t *lo, uint64_t *hi, in
  * consumed (2 per pair).  Returns the number of k-mer occurrences processed, or -1 if the stream
  * is truncated. */
 long gko_count_reads(gko_pmap *pm, const uint8_t *bin, size_t nbytes, uint64_t nreads);
+/* the same on host threads: `nthreads` readers route k-mers to the P partitions of pm, then one thread
+ * per partition inserts (PartitionedDNAMap without the network; the CPU baseline's multi-core form) */
+long gko_count_reads_mt(gko_pmap *pm, const uint8_t *bin, size_t nbytes, uint64_t nreads, int nthreads);
 
 /* ---- Graph (S/data/graph/Graph.scala) ---- */
 typedef struct gko_graph gko_graph;

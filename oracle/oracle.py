@@ -70,6 +70,7 @@ def lib():
         "gko_pmap_delete_lt": (None, [vp, C.c_int32]),
         "gko_pmap_export_sorted": (C.c_size_t, [vp, u64p, u64p, i32p, C.c_size_t]),
         "gko_count_reads": (C.c_long, [vp, u8p, C.c_size_t, C.c_uint64]),
+        "gko_count_reads_mt": (C.c_long, [vp, u8p, C.c_size_t, C.c_uint64, C.c_int]),
         "gko_graph_build": (vp, [vp]),
         "gko_graph_free": (None, [vp]),
         "gko_graph_num_nodes": (C.c_long, [vp]),
@@ -143,6 +144,14 @@ class PMap:
         buf = np.frombuffer(bin_bytes, dtype=np.uint8) if not isinstance(bin_bytes, np.ndarray) else bin_bytes
         buf = np.ascontiguousarray(buf)
         r = lib().gko_count_reads(self.h, _p(buf, C.c_uint8), buf.size, nreads)
+        if r < 0:
+            raise ValueError("truncated .bin stream")
+        return r
+
+    def count_reads_mt(self, bin_bytes, nreads: int, nthreads: int) -> int:
+        buf = np.frombuffer(bin_bytes, dtype=np.uint8) if not isinstance(bin_bytes, np.ndarray) else bin_bytes
+        buf = np.ascontiguousarray(buf)
+        r = lib().gko_count_reads_mt(self.h, _p(buf, C.c_uint8), buf.size, nreads, nthreads)
         if r < 0:
             raise ValueError("truncated .bin stream")
         return r

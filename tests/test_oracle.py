@@ -305,3 +305,18 @@ def test_synth_is_chunk_invariant():
     rd = R.reads_from_bin(synth.reads_mode_g(20, 40, 500, 0.0, 1).tobytes(), 20)
     for r in rd:
         assert r in gen or R.rev_comp(r) in gen
+
+
+def test_multithreaded_baseline_equals_sequential():
+    """gko_count_reads_mt (the CPU baseline's multi-core form) == the sequential PartitionedDNAMap."""
+    rnd = random.Random(21)
+    reads = _random_reads(rnd, 400, 20, 120, 900, 0.02) + ["", "AG"]
+    binb = R.reads_to_bin(reads)
+    for k, P, T in [(21, 4, 3), (35, 3, 5), (11, 1, 2)]:
+        seq = O.PMap(k, P); seq.count_reads(binb, len(reads))
+        mt = O.PMap(k, P)
+        assert mt.count_reads_mt(binb, len(reads), T) == sum(max(0, len(r) - k + 1) for r in reads)
+        for x, y in zip(seq.export_sorted(), mt.export_sorted()):
+            assert np.array_equal(x, y)
+        for p in range(P):
+            assert seq.part_stats(p)[0] == mt.part_stats(p)[0]
