@@ -49,7 +49,7 @@ def cpu_baseline(rec_host: np.ndarray, nreads_total: int, k: int, target_s: floa
     reads: first one thread / one partition (= one ArrayDNAMap), then P = usable cores threads and
     partitions (= PartitionedDNAMap without the network).  The multi-core figure is the reported value."""
     from oracle import oracle as O
-    cores = max(1, min(len(os.sched_getaffinity(0)), 64))
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))     # a 1-GPU box has a 16-core share
     probe = min(2000, nreads_total)
     pm = O.PMap(k, 1)
     t0 = time.perf_counter()

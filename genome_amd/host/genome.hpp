@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <functional>
 #include <optional>
+#include <ostream>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -241,6 +242,22 @@ class Graph {
             return DNASeq::code(a.seq[0]) < DNASeq::code(b.seq[0]);
         });
         return out;
+    }
+
+    // the `contigs` file of GraphSimplifier.scala:338-347: per edge its sequence, then ">abacaba<i>"
+    // (edge order: canonical, since the reference's is ConcurrentHashMap order)
+    void writeContigs(std::ostream &out) const {
+        size_t i = 0;
+        for (const auto &e : getEdges()) out << e.seq << "\n>abacaba" << i++ << "\n";
+    }
+    // Graph.writeDot (Graph.scala:74-88): `start -> end [label=seq|length]`, ids = rank of the node's k-mer
+    void writeDot(std::ostream &out) const {
+        const auto nodes = getNodes();
+        auto id = [&](const DNASeq &s) { return (size_t)(std::lower_bound(nodes.begin(), nodes.end(), s) - nodes.begin()) + 1; };
+        out << "digraph G {\n";
+        for (const auto &e : getEdges())
+            out << id(e.start) << " -> " << id(e.end) << " [label=" << (e.seq.size() <= 50 ? e.seq : std::to_string(e.seq.size())) << "]\n";
+        out << "}\n";
     }
 
   private:

@@ -3,7 +3,9 @@
 // builds the de Bruijn graph, keeps the largest component, and writes the graph as text.
 // The reference logs its counters through akka Logging (:34-53); here they are one JSON object.
 //
-//   graph_builder <reads.bin> <pairs> <k> [--rounds 3] [--take-first N] [--no-retain] [--out prefix]
+//   graph_builder <reads.bin> <pairs> <k> [--rounds 3] [--take-first N] [--no-retain] [--simplify] [--out prefix]
+//   --simplify runs removeBubbles + simplifyGraph (GraphSimplifier.scala:317-318) before writing;
+//   --out writes <prefix>.nodes.txt, .edges.txt, .contigs (GraphSimplifier.scala:338-347) and .dot (Graph.scala:74-88)
 //
 // Build: g++ -std=c++17 -O2 -I include genome_amd/host/graph_builder.cpp -L genome_amd -lgenome_amd
 //        -Wl,-rpath,'$ORIGIN/..' -o genome_amd/host/graph_builder
@@ -17,7 +19,7 @@
 
 int main(int argc, char **argv) {
     if (argc < 4) {
-        std::fprintf(stderr, "usage: %s <reads.bin> <pairs> <k> [--rounds 3] [--take-first N] [--no-retain] [--out prefix]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <reads.bin> <pairs> <k> [--rounds 3] [--take-first N] [--no-retain] [--simplify] [--out prefix]\n", argv[0]);
         return 2;
     }
     const std::string infile = argv[1];
@@ -26,12 +28,13 @@ int main(int argc, char **argv) {
     const int k = std::stoi(argv[3]);
     int rounds = 3;                               // GraphBuilder.scala:30
     uint64_t takeFirst = UINT64_MAX;              // genome.takeFirst
-    bool retain = true;
+    bool retain = true, simplify = false;
     std::string out;
     for (int i = 4; i < argc; i++) {
         if (!std::strcmp(argv[i], "--rounds") && i + 1 < argc) rounds = std::stoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--take-first") && i + 1 < argc) takeFirst = std::stoull(argv[++i]);
         else if (!std::strcmp(argv[i], "--no-retain")) retain = false;
+        else if (!std::strcmp(argv[i], "--simplify")) simplify = true;
         else if (!std::strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
         else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
@@ -44,6 +47,7 @@ int main(int argc, char **argv) {
         const uint64_t good = kmersFreq.size();                                                          // :34
         auto graph = genome::Graph::buildGraph(k, kmersFreq);                                            // :36
         auto [nodes, edges, totalLen] = graph.counts();                                                  // :39
+        if (simplify) { graph.removeBubbles(); graph.simplifyGraph(); }                                  // GraphSimplifier.scala:317-318
         uint64_t kept = nodes, comps = 0;
         if (retain) std::tie(kept, comps) = graph.retainLargestComponent();                              // :52-54
         auto [n2, e2, l2] = graph.counts();
@@ -57,6 +61,9 @@ int main(int argc, char **argv) {
             std::ofstream nf(out + ".nodes.txt"), ef(out + ".edges.txt");
             for (const auto &n : graph.getNodes()) nf << n.toString() << "\n";
             for (const auto &e : graph.getEdges()) ef << e.start.toString() << " " << e.end.toString() << " " << e.seq << "\n";
+            std::ofstream cf(out + ".contigs"), df(out + ".dot");
+            graph.writeContigs(cf);
+            graph.writeDot(df);
         }
     } catch (const std::exception &e) {
         std::fprintf(stderr, "graph_builder: %s\n", e.what());

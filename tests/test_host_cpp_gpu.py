@@ -23,7 +23,7 @@ def exe():
     return EXE
 
 
-@pytest.mark.parametrize("name", ["g_k11_p1", "g_k31_p1", "snp_k35_p1", "g_k63_p1"])
+@pytest.mark.parametrize("name", ["g_k11_p1", "g_k31_p1", "snp_k35_p1", "g_k63_p1", "snp_k11_p2"])
 def test_graph_builder_cli_matches_golden(exe, tmp_path, name):
     fx = json.load(open(os.path.join(GOLDEN, name + ".json")))
     binf = tmp_path / "reads.bin"
@@ -39,6 +39,20 @@ def test_graph_builder_cli_matches_golden(exe, tmp_path, name):
     assert open(str(out) + ".nodes.txt").read().split() == fx["nodes"]
     edges = [line.split() for line in open(str(out) + ".edges.txt").read().splitlines()]
     assert edges == fx["edges"]
+    # contigs file (GraphSimplifier.scala:338-347): sequence line, then ">abacaba<i>"
+    contigs = open(str(out) + ".contigs").read().splitlines()
+    assert contigs[0::2] == [e[2] for e in fx["edges"]]
+    assert contigs[1::2] == [f">abacaba{i}" for i in range(len(fx["edges"]))]
+    dot = open(str(out) + ".dot").read().splitlines()                       # Graph.scala:74-88
+    assert dot[0] == "digraph G {" and dot[-1] == "}" and len(dot) == len(fx["edges"]) + 2
+    ids = {s: i + 1 for i, s in enumerate(fx["nodes"])}
+    for line, (s, t, q) in zip(dot[1:-1], fx["edges"]):
+        assert line == f"{ids[s]} -> {ids[t]} [label={q if len(q) <= 50 else len(q)}]"
+    # --simplify = removeBubbles + simplifyGraph before writing
+    res = subprocess.run([exe, str(binf), str(fx["nreads"] // 2), str(fx["k"]), "--rounds", str(fx["rounds"]),
+                          "--no-retain", "--simplify", "--out", str(out) + "s"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert [line.split() for line in open(str(out) + "s.edges.txt").read().splitlines()] == fx["edges_after_simplify"]
 
 
 def test_graph_builder_cli_retain_and_errors(exe, tmp_path):
