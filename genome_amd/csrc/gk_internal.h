@@ -43,6 +43,7 @@ struct gk_map {
     int insert_path = 0;         // 0 auto, 1 direct (global atomics), 2 partitioned (LDS build)
     bool pending_clear = false;  // gk_map_clear deferred: slots are stale until materialised
     uint64_t part_launches = 0, direct_launches = 0;
+    uint64_t spilled_keys = 0, failed_segments = 0, retries_direct = 0;   // partitioned-path skew counters
     float phase_ms[5] = {0, 0, 0, 0, 0};   // last insert: hist1, scatter1, hist2, scatter2, seg_insert (or [0] = direct kernel)
 };
 
@@ -85,7 +86,8 @@ int map_reserve(gk_map *m, uint64_t extra_keys);     // grow so that size+extra 
 int map_sync_counters(gk_map *m);                    // refresh m->size, detect device-side error flag
 int map_materialize(gk_map *m);                      // run a deferred clear so that the slots are valid
 int map_add_keys_direct(gk_map *m, const uint64_t *d_keys, uint64_t n);   // k_add_keys on device keys (W words each)
-// partitioned path
+// partitioned path (part_count may return PART_RETRY_DIRECT: take the direct path for this batch)
+constexpr int PART_RETRY_DIRECT = 1;
 int part_count(gk_map *m, PartScratch **pps, const uint8_t *d_rec, uint64_t nreads, const uint32_t *d_off, uint32_t stride, int group,
                const uint64_t *d_keys, uint64_t nkeys_in, uint64_t nkeys_bound, bool from_empty);
 // lanes per read in the window loops: 64 for reads, 32/16 for short records (super-k-mers)

@@ -27,8 +27,10 @@
 // Algorithmic bytes per occurrence (k<=31): P1 0.31, P2 0.31 + 8, P3 8, P4 8 + 8, P5 8 + slot
 // traffic (32 B of table per slot streamed in and out, or 16 B out only from empty).
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <string>
+#include <vector>
 
 #include "gk_internal.h"
 #include "gk_tile.h"
@@ -52,7 +54,32 @@ struct PartArrays {
     u32 *cursor2;                   // [nseg]
     u32 *failed;                    // [nseg] list of segments that overflowed
     u32 *n_failed;
+    // over-provisioned mode (op = 1): no histogram passes; bucket b owns the fixed region
+    // [b * cap, (b + 1) * cap) of the key buffer and whatever does not fit goes to the spill list
+    int op;
+    unsigned long long cap1, cap2;  // keys per L1 region / per segment region
+    u64 *spill;                     // [spill_cap * W]
+    unsigned long long *nspill;
+    unsigned long long spill_cap;
+    u32 *overflow;                  // spill list itself overflowed: abandon the pipeline (scratch only so far)
 };
+__device__ __forceinline__ u64 l1_begin(const PartArrays &a, u32 b) { return a.op ? (u64)b * a.cap1 : a.l1_base[b]; }
+__device__ __forceinline__ u64 l1_count(const PartArrays &a, u32 b) {
+    return a.op ? min(a.cursor1[b], a.cap1) : a.l1_base[b + 1] - a.l1_base[b];
+}
+__device__ __forceinline__ u64 fine_begin(const PartArrays &a, u64 s) { return a.op ? s * a.cap2 : a.fine_base[s]; }
+__device__ __forceinline__ u64 fine_count(const PartArrays &a, u64 s) {
+    return a.op ? min((unsigned long long)a.cursor2[s], a.cap2) : a.fine_base[s + 1] - a.fine_base[s];
+}
+template <int W> __device__ __forceinline__ void spill_key(const PartArrays &a, u64 w0, u64 w1) {
+    const unsigned long long si = atomicAdd(a.nspill, 1ull);
+    if (si < a.spill_cap) {
+        if constexpr (W == 1) a.spill[si] = w0;
+        else { a.spill[2 * si] = w0; a.spill[2 * si + 1] = w1; }
+    } else {
+        *a.overflow = 1;
+    }
+}
 
 template <int W> __device__ __forceinline__ Kmer<W> load_key(const u64 *keys, u64 i) {
     if constexpr (W == 1) return Kmer<1>{keys[i]};
@@ -174,9 +201,8 @@ __global__ __launch_bounds__(BLOCK) void k_part_hist1_keys(const u64 *__restrict
 // position [TILE2] u16, per-bin offset [nbins] u32, per-bin destination [nbins] u64.
 template <int W, int LEVEL>
 __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u64 begin, u32 cnt, const Table<W> &t, u32 nbins,
-                                              u64 *sorted, uint16_t *binof, u32 *off, unsigned long long *gb, u32 *wsum,
-                                              const unsigned long long *bin_base, unsigned long long *cursor64, u32 *cursor32,
-                                              u64 bin0, u64 *__restrict__ out) {
+                                              u64 *sorted, uint16_t *binof, u32 *off, u32 *lim, unsigned long long *gb, u32 *wsum,
+                                              const PartArrays &a, u64 bin0, u64 *__restrict__ out) {
     Kmer<W> key[KEYS_PER_THREAD];
     u32 bin[KEYS_PER_THREAD], rank[KEYS_PER_THREAD];
     for (u32 b = threadIdx.x; b < nbins; b += PBLOCK) off[b] = 0;
@@ -201,10 +227,19 @@ __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u64 be
     __syncthreads();
     for (u32 b = threadIdx.x; b < nbins; b += PBLOCK) {        // reserve the bin's run in the output
         const u32 c = off[b];
+        u32 fit = c;
         if (c) {
-            if (LEVEL == 1) gb[b] = bin_base[b] + atomicAdd(&cursor64[b], (unsigned long long)c);
-            else gb[b] = bin_base[bin0 + b] + atomicAdd(&cursor32[bin0 + b], c);
+            const unsigned long long at = LEVEL == 1 ? atomicAdd(&a.cursor1[b], (unsigned long long)c)
+                                                     : (unsigned long long)atomicAdd(&a.cursor2[bin0 + b], c);
+            if (a.op) {
+                const unsigned long long cap = LEVEL == 1 ? a.cap1 : a.cap2;
+                gb[b] = (bin0 + b) * cap + at;
+                fit = at >= cap ? 0u : (u32)min((unsigned long long)c, cap - at);
+            } else {
+                gb[b] = (LEVEL == 1 ? a.l1_base[b] : a.fine_base[bin0 + b]) + at;
+            }
         }
+        lim[b] = fit;
     }
     __syncthreads();
     block_scan_inplace(off, nbins, wsum);                      // counts -> offsets in the sorted chunk
@@ -217,28 +252,31 @@ __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u64 be
         }
     __syncthreads();
     for (u32 i = threadIdx.x; i < cnt; i += PBLOCK) {          // linear, coalesced write-out
-        const u32 b = binof[i];
-        store_key<W>(out, gb[b] + (i - off[b]), load_key<W>(sorted, i));
+        const u32 b = binof[i], j = i - off[b];
+        const Kmer<W> x = load_key<W>(sorted, i);
+        if (j < lim[b]) store_key<W>(out, gb[b] + j, x);
+        else if constexpr (W == 1) spill_key<1>(a, x.lo, 0);
+        else spill_key<2>(a, x.lo, x.hi);
     }
     __syncthreads();
 }
 
 // dynamic LDS carve for scatter_chunk
 template <int W> struct ScatterLds {
-    u64 *sorted; uint16_t *binof; u32 *off; unsigned long long *gb; u32 *wsum;
+    u64 *sorted; uint16_t *binof; u32 *off, *lim; unsigned long long *gb; u32 *wsum;
     __device__ __forceinline__ ScatterLds(unsigned long long *base, u32 nbins) {
         gb = base;                                                       // [nbins] u64
         sorted = reinterpret_cast<u64 *>(base + nbins);                  // [TILE2 * W] u64
         off = reinterpret_cast<u32 *>(sorted + (size_t)TILE2 * W);       // [nbins] u32
-        wsum = off + nbins;                                              // [PBLOCK / 64]
+        lim = off + nbins;                                               // [nbins] u32
+        wsum = lim + nbins;                                              // [PBLOCK / 64]
         binof = reinterpret_cast<uint16_t *>(wsum + PBLOCK / 64);        // [TILE2] u16
     }
-    static size_t bytes(u32 nbins) { return (size_t)nbins * 12 + (size_t)TILE2 * W * 8 + (PBLOCK / 64) * 4 + (size_t)TILE2 * 2 + 16; }
+    static size_t bytes(u32 nbins) { return (size_t)nbins * 16 + (size_t)TILE2 * W * 8 + (PBLOCK / 64) * 4 + (size_t)TILE2 * 2 + 16; }
 };
 
 template <int W>
-__global__ __launch_bounds__(PBLOCK) void k_part_scatter1_keys(const u64 *__restrict__ keys, u64 n, Table<W> t,
-                                                               const unsigned long long *l1_base, unsigned long long *cursor1,
+__global__ __launch_bounds__(PBLOCK) void k_part_scatter1_keys(const u64 *__restrict__ keys, u64 n, Table<W> t, PartArrays a,
                                                                u64 *__restrict__ out) {
     extern __shared__ unsigned long long lds_dyn1[];
     ScatterLds<W> L(lds_dyn1, 256u);
@@ -246,25 +284,93 @@ __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_keys(const u64 *__rest
     for (u64 c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const u64 begin = c * TILE2;
         const u32 cnt = (u32)min((u64)TILE2, n - begin);
-        scatter_chunk<W, 1>(keys, begin, cnt, t, 256u, L.sorted, L.binof, L.off, L.gb, L.wsum, l1_base, cursor1, nullptr, 0, out);
+        scatter_chunk<W, 1>(keys, begin, cnt, t, 256u, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a, 0, out);
     }
+}
+
+// P2 of the over-provisioned mode for fixed-stride records: ONE window-extraction pass.  The tile's
+// canonical keys and their L1 buckets are parked in LDS while the per-bucket counts are built, the
+// bucket regions are reserved (one global atomic per (tile, bucket)), then the keys go out.  No P1.
+static constexpr int OP_CAP = 5632;         // LDS key buffer, in 64-bit words (2 workgroups per CU)
+static constexpr int OP_TILE_READS = 128;
+static constexpr int OP_TILE_WORDS = OP_TILE_READS * 65 / 4 + 64;
+template <int W>
+__global__ __launch_bounds__(PBLOCK) void k_op_scatter1_reads(const uint8_t *__restrict__ rec, u64 nreads, u32 stride, int k, int group,
+                                                              int rs /* reads per tile */, int nk_max, Table<W> t, PartArrays a,
+                                                              Counters *ctr, u64 *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) u32 tile[OP_TILE_WORDS];
+    __shared__ u64 flat[OP_CAP];
+    __shared__ uint16_t fbin[OP_CAP / W];      // 0xffff = hole (bucket ids use all 256 byte values)
+    __shared__ u32 hist[256], rank[256], lim[256];
+    __shared__ unsigned long long gb[256];
+    u32 occ = 0;
+    const u64 ntiles = (nreads + rs - 1) / rs;
+    for (u64 tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const u64 r0 = tl * rs;
+        const int nr = (int)min((u64)rs, nreads - r0);
+        const u32 nflat = (u32)(nr * nk_max);
+        __syncthreads();
+        if (threadIdx.x < 256) { hist[threadIdx.x] = 0; rank[threadIdx.x] = 0; }
+        for (u32 i = threadIdx.x; i < nflat; i += PBLOCK) fbin[i] = 0xffff;
+        const u64 a0 = stage_tile(tile, rec, r0 * stride, (r0 + nr) * stride);
+        __syncthreads();
+        for_each_window_at<W>(tile, a0, r0, nr, stride, k, group, [&](int r, int p, Kmer<W> x) {
+            const Kmer<W> y = canonical(x, k);
+            const u32 b = seg_l1(t, slot_hash(y));
+            const u32 i = (u32)(r * nk_max + p);
+            store_key<W>(flat, i, y);
+            fbin[i] = (uint16_t)b;
+            atomicAdd(&hist[b], 1u);
+            occ++;
+        });
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            const u32 c = hist[threadIdx.x];
+            u32 fit = 0;
+            if (c) {
+                const unsigned long long at = atomicAdd(&a.cursor1[threadIdx.x], (unsigned long long)c);
+                gb[threadIdx.x] = (unsigned long long)threadIdx.x * a.cap1 + at;
+                fit = at >= a.cap1 ? 0u : (u32)min((unsigned long long)c, a.cap1 - at);
+            }
+            lim[threadIdx.x] = fit;
+        }
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < nflat; i += PBLOCK) {
+            const u32 b = fbin[i];
+            if (b == 0xffff) continue;
+            const u32 j = atomicAdd(&rank[b], 1u);
+            const Kmer<W> x = load_key<W>(flat, i);
+            if (j < lim[b]) store_key<W>(out, gb[b] + j, x);
+            else if constexpr (W == 1) spill_key<1>(a, x.lo, 0);
+            else spill_key<2>(a, x.lo, x.hi);
+        }
+    }
+    for (int d = 32; d; d >>= 1) occ += __shfl_down(occ, d);
+    __syncthreads();
+    if (threadIdx.x == 0) hist[0] = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && occ) atomicAdd(&hist[0], occ);
+    __syncthreads();
+    if (threadIdx.x == 0 && hist[0]) atomicAdd(&ctr->occurrences, (unsigned long long)hist[0]);
 }
 
 // exclusive scan of the 256 L1 counts; chunk table for P3/P4 (chunks never straddle L1 buckets)
 __global__ __launch_bounds__(256) void k_part_prefix1(PartArrays a, u32 nb1) {
     __shared__ unsigned long long s[256], c[256];
     const u32 i = threadIdx.x;
-    s[i] = i < nb1 ? a.hist1[i] : 0;
+    s[i] = i < nb1 ? (a.op ? min(a.cursor1[i], a.cap1) : a.hist1[i]) : 0;
     c[i] = (s[i] + TILE2 - 1) / TILE2;
     __syncthreads();
     if (i == 0) {
         unsigned long long acc = 0, cacc = 0;
         for (u32 b = 0; b < 256; b++) {
             const unsigned long long v = s[b], cv = c[b];
-            a.l1_base[b] = acc; a.cbase[b] = cacc;
+            if (!a.op) a.l1_base[b] = acc;
+            a.cbase[b] = cacc;
             acc += v; cacc += cv;
         }
-        a.l1_base[256] = acc; a.cbase[256] = cacc;
+        if (!a.op) a.l1_base[256] = acc;
+        a.cbase[256] = cacc;
     }
 }
 
@@ -284,14 +390,14 @@ __global__ __launch_bounds__(PBLOCK) void k_part_hist2(const u64 *__restrict__ b
     const u64 total_chunks = a.cbase[256];
     for (u64 c = blockIdx.x; c < total_chunks && c < max_chunks; c += gridDim.x) {
         const u32 b1 = chunk_bucket(a.cbase, c);
-        const u64 bsize = a.l1_base[b1 + 1] - a.l1_base[b1];
+        const u64 bsize = l1_count(a, b1);
         const u64 begin = (c - a.cbase[b1]) * TILE2;
         const u32 cnt = (u32)min((u64)TILE2, bsize - begin);
         for (u32 b = threadIdx.x; b < t.nb2; b += PBLOCK) lds_hist[b] = 0;
         __syncthreads();
         {
             Kmer<W> key[KEYS_PER_THREAD];
-            const u64 kb = a.l1_base[b1] + begin;
+            const u64 kb = l1_begin(a, b1) + begin;
 #pragma unroll
             for (int j = 0; j < KEYS_PER_THREAD; j++) {
                 const u32 i = threadIdx.x + j * PBLOCK;
@@ -342,11 +448,11 @@ __global__ __launch_bounds__(PBLOCK) void k_part_scatter2(const u64 *__restrict_
     const u64 total_chunks = a.cbase[256];
     for (u64 c = blockIdx.x; c < total_chunks && c < max_chunks; c += gridDim.x) {
         const u32 b1 = chunk_bucket(a.cbase, c);
-        const u64 bsize = a.l1_base[b1 + 1] - a.l1_base[b1];
+        const u64 bsize = l1_count(a, b1);
         const u64 begin = (c - a.cbase[b1]) * TILE2;
         const u32 cnt = (u32)min((u64)TILE2, bsize - begin);
-        scatter_chunk<W, 2>(bufA, a.l1_base[b1] + begin, cnt, t, t.nb2, L.sorted, L.binof, L.off, L.gb, L.wsum, a.fine_base, nullptr,
-                            a.cursor2, (u64)b1 * t.nb2, bufB);
+        scatter_chunk<W, 2>(bufA, l1_begin(a, b1) + begin, cnt, t, t.nb2, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a,
+                            (u64)b1 * t.nb2, bufB);
     }
 }
 
@@ -375,7 +481,7 @@ __global__ __launch_bounds__(SBLOCK) void k_seg_insert(Table<W> t, const u64 *__
     u32 wg_claims = 0;      // thread 0 only: ONE global atomic per workgroup at the end (a same-address
                             // atomic per segment caps the kernel at ~88 segments/us chip-wide)
     for (u64 s = blockIdx.x; s < nseg; s += gridDim.x) {
-        const u64 kb = a.fine_base[s], ke = a.fine_base[s + 1];
+        const u64 kb = fine_begin(a, s), ke = kb + fine_count(a, s);
         uint4 *gseg = reinterpret_cast<uint4 *>(t.slots + (s << SegBits<W>::value));
         if (kb == ke) {
             if (from_empty) {       // materialise the pending clear of a segment that gets no key
@@ -449,23 +555,31 @@ namespace gk {
 struct PartScratch {
     void *blob = nullptr;        // all the small arrays
     size_t blob_bytes = 0;
-    u64 nseg = 0;
-    u64 *bufA = nullptr, *bufB = nullptr;
-    u64 buf_keys = 0;            // capacity in keys of each buffer
+    u64 *bufA = nullptr, *bufB = nullptr, *spill = nullptr;
+    u64 bufA_keys = 0, bufB_keys = 0, spill_keys = 0;     // capacities in keys
     int W = 1;
     bool lds_attr_set = false;
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static int part_prepare(gk_map *m, PartScratch *ps, u64 nkeys, PartArrays *arr, bool need_a) {
+static int grow_buf(gk_ctx *ctx, u64 **buf, u64 *have, u64 want, int W) {
+    if (*have >= want) return GK_OK;
+    if (*buf) GK_HIP(ctx, hipFree(*buf));
+    *buf = nullptr; *have = 0;
+    GK_HIP(ctx, hipMalloc((void **)buf, std::max<u64>(want, 1) * 8 * W));
+    *have = want;
+    return GK_OK;
+}
+
+static int part_prepare(gk_map *m, PartScratch *ps, u64 nkeys, bool op, PartArrays *arr) {
     gk_ctx *ctx = m->ctx;
-    const u64 nseg = (u64)m->nb2 << m->lnb1;
+    const u64 nseg = (u64)m->nb2 << m->lnb1, nb1 = 1ull << m->lnb1;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_hist1 = take(256 * 8), o_l1 = take(257 * 8), o_cur1 = take(256 * 8), o_cb = take(257 * 8);
     const size_t o_hist2 = take(nseg * 4), o_fine = take((nseg + 1) * 8), o_cur2 = take(nseg * 4), o_failed = take(nseg * 4),
-                 o_nf = take(4);
+                 o_nf = take(4), o_nsp = take(8), o_ovf = take(4);
     if (ps->blob_bytes < off) {
         if (ps->blob) GK_HIP(ctx, hipFree(ps->blob));
         ps->blob = nullptr; ps->blob_bytes = 0;
@@ -478,15 +592,29 @@ static int part_prepare(gk_map *m, PartScratch *ps, u64 nkeys, PartArrays *arr, 
     arr->cursor1 = (unsigned long long *)(b + o_cur1); arr->cbase = (unsigned long long *)(b + o_cb);
     arr->hist2 = (u32 *)(b + o_hist2); arr->fine_base = (unsigned long long *)(b + o_fine);
     arr->cursor2 = (u32 *)(b + o_cur2); arr->failed = (u32 *)(b + o_failed); arr->n_failed = (u32 *)(b + o_nf);
-    if (ps->buf_keys < nkeys || ps->W != m->W) {
-        if (ps->bufA) GK_HIP(ctx, hipFree(ps->bufA));
-        if (ps->bufB) GK_HIP(ctx, hipFree(ps->bufB));
-        ps->bufA = ps->bufB = nullptr; ps->buf_keys = 0;
-        GK_HIP(ctx, hipMalloc((void **)&ps->bufA, std::max<u64>(nkeys, 1) * 8 * m->W));
-        GK_HIP(ctx, hipMalloc((void **)&ps->bufB, std::max<u64>(nkeys, 1) * 8 * m->W));
-        ps->buf_keys = nkeys; ps->W = m->W;
+    arr->nspill = (unsigned long long *)(b + o_nsp); arr->overflow = (u32 *)(b + o_ovf);
+    if (ps->W != m->W) {     // key width changed: drop the buffers
+        for (u64 **bp : {&ps->bufA, &ps->bufB, &ps->spill}) { if (*bp) GK_HIP(ctx, hipFree(*bp)); *bp = nullptr; }
+        ps->bufA_keys = ps->bufB_keys = ps->spill_keys = 0;
+        ps->W = m->W;
     }
-    (void)need_a;
+    arr->op = op ? 1 : 0;
+    arr->cap1 = arr->cap2 = 0; arr->spill_cap = 0;
+    u64 wantA = nkeys, wantB = nkeys, wantS = 0;
+    if (op) {
+        // Bucket sizes of hashed keys concentrate (binomial): mean + 8 sigma + slack never overflows
+        // for distinct-ish keys; heavy hitters (one k-mer repeated thousands of times) do, and go to
+        // the spill list, which the direct path absorbs after the segments are built.
+        const double m1 = (double)nkeys / (double)nb1, m2 = (double)nkeys / (double)nseg;
+        arr->cap1 = (u64)(m1 + 8.0 * std::sqrt(m1) + 1024.0);
+        arr->cap2 = (u64)(m2 + 8.0 * std::sqrt(m2) + 64.0);
+        arr->spill_cap = nkeys / 16 + 65536;
+        wantA = nb1 * arr->cap1; wantB = nseg * arr->cap2; wantS = arr->spill_cap;
+    }
+    if (int rc = grow_buf(ctx, &ps->bufA, &ps->bufA_keys, wantA, m->W)) return rc;
+    if (int rc = grow_buf(ctx, &ps->bufB, &ps->bufB_keys, wantB, m->W)) return rc;
+    if (int rc = grow_buf(ctx, &ps->spill, &ps->spill_keys, wantS, m->W)) return rc;
+    arr->spill = ps->spill;
     return GK_OK;
 }
 
@@ -495,16 +623,23 @@ void part_scratch_free(PartScratch *ps) {
     if (ps->blob) (void)hipFree(ps->blob);
     if (ps->bufA) (void)hipFree(ps->bufA);
     if (ps->bufB) (void)hipFree(ps->bufB);
+    if (ps->spill) (void)hipFree(ps->spill);
     delete ps;
 }
 
+// returns GK_OK, an error (< 0), or PART_RETRY_DIRECT: the over-provisioned regions and the spill
+// list overflowed (extreme skew); nothing but scratch was touched, the caller takes the direct path
 template <int W>
 static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads, const u32 *d_off, u32 stride, int group,
                     const u64 *d_keys, u64 nkeys_in, u64 nkeys_bound, bool from_empty) {
     gk_ctx *ctx = m->ctx;
     Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u};
     PartArrays a;
-    if (int rc = part_prepare(m, ps, nkeys_bound, &a, true)) return rc;
+    // fixed-stride records and key arrays: their key count is known exactly, so regions can be sized
+    // up front and the two histogram passes (P1, P3) dropped; ragged streams keep the exact pipeline
+    const int max_windows = d_rec && !d_off ? std::max(0, (int)(stride - 1) * 4 - m->k + 1) : 0;
+    const bool op = !d_off && !getenv("GK_PART_EXACT") && (d_keys || (max_windows > 0 && max_windows <= OP_CAP / W));
+    if (int rc = part_prepare(m, ps, nkeys_bound, op, &a)) return rc;
     const u32 nb1 = 1u << m->lnb1;
     const u64 nseg = t.nseg();
     const int cu8 = ctx->cu_count * 8;
@@ -519,7 +654,16 @@ static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads
     }
     // P1 + prefix + P2
     GK_HIP(ctx, hipEventRecord(ctx->pev[0], ctx->stream));
-    if (d_rec) {
+    if (d_rec && op) {
+        GK_HIP(ctx, hipEventRecord(ctx->pev[1], ctx->stream));
+        // reads per tile: their windows must fit the LDS key buffer and their bytes the LDS tile
+        const u64 by_bytes = ((u64)OP_TILE_WORDS * 4 - 96) / stride;
+        const int rs = (int)std::max<u64>(1, std::min<u64>(by_bytes, (u64)(OP_CAP / W) / (u64)max_windows));
+        const u64 ntiles = (nreads + rs - 1) / rs;
+        const int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)ctx->cu_count * 2);
+        hipLaunchKernelGGL(k_op_scatter1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, nreads, stride, m->k, group, rs, max_windows,
+                           t, a, m->d_ctr, ps->bufA);
+    } else if (d_rec) {
         const u64 ntiles = (nreads + PTILE_READS - 1) / PTILE_READS;
         const int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)ctx->cu_count * 4);
         hipLaunchKernelGGL(k_part_hist1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k, group, t, a.hist1, m->d_ctr);
@@ -530,25 +674,48 @@ static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads
         hipLaunchKernelGGL(k_part_scatter1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k, group, t,
                            a.l1_base, a.cursor1, ps->bufA);
     } else {
-        const int grid = (int)std::min<u64>(std::max<u64>((nkeys_in + BLOCK - 1) / BLOCK, 1), (u64)cu8);
-        hipLaunchKernelGGL(k_part_hist1_keys<W>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_keys, nkeys_in, t, a.hist1);
-        hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(256), 0, ctx->stream, a, nb1);
+        if (!op) {
+            const int grid = (int)std::min<u64>(std::max<u64>((nkeys_in + BLOCK - 1) / BLOCK, 1), (u64)cu8);
+            hipLaunchKernelGGL(k_part_hist1_keys<W>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_keys, nkeys_in, t, a.hist1);
+            hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(256), 0, ctx->stream, a, nb1);
+        }
         GK_HIP(ctx, hipEventRecord(ctx->pev[1], ctx->stream));
         const int g2 = (int)std::min<u64>(std::max<u64>((nkeys_in + TILE2 - 1) / TILE2, 1), (u64)ctx->cu_count * 4);
-        hipLaunchKernelGGL(k_part_scatter1_keys<W>, dim3(g2), dim3(PBLOCK), ScatterLds<W>::bytes(256u), ctx->stream, d_keys, nkeys_in, t, a.l1_base, a.cursor1, ps->bufA);
+        hipLaunchKernelGGL(k_part_scatter1_keys<W>, dim3(g2), dim3(PBLOCK), ScatterLds<W>::bytes(256u), ctx->stream, d_keys, nkeys_in, t, a, ps->bufA);
     }
+    if (op) hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(256), 0, ctx->stream, a, nb1);     // chunk table from the cursors
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipEventRecord(ctx->pev[2], ctx->stream));
     // P3 + prefix + P4
     const u64 max_chunks = nkeys_bound / TILE2 + 257;
     const int gchunks = (int)std::min<u64>(max_chunks, (u64)ctx->cu_count * 4);
     const u64 *fine_keys = ps->bufB;
-    hipLaunchKernelGGL(k_part_hist2<W>, dim3(gchunks), dim3(PBLOCK), m->nb2 * 4, ctx->stream, ps->bufA, t, a, max_chunks);
-    hipLaunchKernelGGL(k_part_prefix2, dim3(nb1), dim3(256), 0, ctx->stream, a, nb1, m->nb2);
+    if (!op) {
+        hipLaunchKernelGGL(k_part_hist2<W>, dim3(gchunks), dim3(PBLOCK), m->nb2 * 4, ctx->stream, ps->bufA, t, a, max_chunks);
+        hipLaunchKernelGGL(k_part_prefix2, dim3(nb1), dim3(256), 0, ctx->stream, a, nb1, m->nb2);
+    }
     GK_HIP(ctx, hipEventRecord(ctx->pev[3], ctx->stream));
     hipLaunchKernelGGL(k_part_scatter2<W>, dim3(gchunks), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2), ctx->stream, ps->bufA, t, a, max_chunks, ps->bufB);
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipEventRecord(ctx->pev[4], ctx->stream));
+    unsigned long long nspill = 0;
+    if (op) {   // the table is still untouched: if even the spill list overflowed, hand the batch back
+        u32 ovf = 0;
+        GK_HIP(ctx, hipMemcpyAsync(&nspill, a.nspill, 8, hipMemcpyDeviceToHost, ctx->stream));
+        GK_HIP(ctx, hipMemcpyAsync(&ovf, a.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+        GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ovf) {
+            if (d_rec) {   // P2 already counted this batch's windows
+                unsigned long long occ = 0;
+                GK_HIP(ctx, hipMemcpy(&occ, &m->d_ctr->occurrences, 8, hipMemcpyDeviceToHost));
+                occ -= std::min<unsigned long long>(occ, nkeys_bound);
+                GK_HIP(ctx, hipMemcpy(&m->d_ctr->occurrences, &occ, 8, hipMemcpyHostToDevice));
+            }
+            GK_HIP(ctx, hipEventRecord(ctx->pev[5], ctx->stream));
+            m->retries_direct++;
+            return PART_RETRY_DIRECT;
+        }
+    }
     // P5
     const int gseg = (int)std::min<u64>(nseg, (u64)ctx->cu_count * 24);
     hipLaunchKernelGGL(k_seg_insert<W>, dim3(gseg), dim3(SBLOCK), lds, ctx->stream, t, fine_keys, a, from_empty ? 1 : 0, m->d_ctr);
@@ -558,17 +725,26 @@ static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads
     u32 n_failed = 0;
     GK_HIP(ctx, hipMemcpyAsync(&n_failed, a.n_failed, 4, hipMemcpyDeviceToHost, ctx->stream));
     if (int rc = map_sync_counters(m)) return rc;
+    m->failed_segments += n_failed;
+    m->spilled_keys += nspill;
     if (n_failed) {
         std::vector<u32> failed(n_failed);
-        std::vector<unsigned long long> fb(nseg + 1);
         GK_HIP(ctx, hipMemcpy(failed.data(), a.failed, n_failed * 4ull, hipMemcpyDeviceToHost));
-        GK_HIP(ctx, hipMemcpy(fb.data(), a.fine_base, (nseg + 1) * 8, hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> fb;
+        std::vector<u32> cur;
+        if (op) { cur.resize(nseg); GK_HIP(ctx, hipMemcpy(cur.data(), a.cursor2, nseg * 4, hipMemcpyDeviceToHost)); }
+        else { fb.resize(nseg + 1); GK_HIP(ctx, hipMemcpy(fb.data(), a.fine_base, (nseg + 1) * 8, hipMemcpyDeviceToHost)); }
+        auto seg_begin = [&](u32 s) { return op ? (u64)s * a.cap2 : (u64)fb[s]; };
+        auto seg_count = [&](u32 s) { return op ? std::min<u64>(cur[s], a.cap2) : (u64)(fb[s + 1] - fb[s]); };
         u64 total = 0;
-        for (u32 s : failed) total += fb[s + 1] - fb[s];
+        for (u32 s : failed) total += seg_count(s);
         if (int rc = map_reserve(m, std::max<u64>(total, m->capacity / 2))) return rc;
         for (u32 s : failed) {
-            if (int rc = map_add_keys_direct(m, fine_keys + fb[s] * m->W, fb[s + 1] - fb[s])) return rc;
+            if (int rc = map_add_keys_direct(m, fine_keys + seg_begin(s) * m->W, seg_count(s))) return rc;
         }
+    }
+    if (nspill) {
+        if (int rc = map_add_keys_direct(m, ps->spill, nspill)) return rc;
     }
     return GK_OK;
 }

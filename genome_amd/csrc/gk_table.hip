@@ -510,7 +510,15 @@ static int launch_partitioned(gk_map *m, const uint8_t *d_rec, u64 nreads, const
     GK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     const bool from_empty = m->pending_clear;
     m->pending_clear = false;
-    if (int rc = part_count(m, &m->part, d_rec, nreads, d_off, stride, group, d_keys, nkeys_in, bound, from_empty)) return rc;
+    const int prc = part_count(m, &m->part, d_rec, nreads, d_off, stride, group, d_keys, nkeys_in, bound, from_empty);
+    if (prc < 0) return prc;
+    if (prc == PART_RETRY_DIRECT) {        // extreme skew: nothing but scratch was touched
+        m->pending_clear = from_empty;
+        if (int rc = map_materialize(m)) return rc;
+        if (int rc = map_reserve(m, bound)) return rc;
+        if (d_rec) return launch_count(m, d_rec, nreads, d_off, stride, group);
+        return map_add_keys_direct(m, d_keys, nkeys_in);
+    }
     GK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     GK_HIP(ctx, hipEventSynchronize(ctx->ev1));
     float ms = 0.f;
@@ -903,12 +911,14 @@ int gk_map_stats(gk_map *m, char *json, size_t cap) {
     int w = snprintf(json, cap,
                      "{\"k\":%d,\"key_words\":%d,\"slot_bytes\":%zu,\"slots\":%llu,\"size\":%llu,\"tombstones\":%llu,"
                      "\"load\":%.6f,\"occurrences\":%llu,\"grows\":%llu,\"last_count_kernel_ms\":%.6f,"
-                     "\"last_count_occurrences\":%llu,\"partitioned_launches\":%llu,\"direct_launches\":%llu,\"device\":%d,\"cu_count\":%d}",
+                     "\"last_count_occurrences\":%llu,\"partitioned_launches\":%llu,\"direct_launches\":%llu,"
+                     "\"spilled_keys\":%llu,\"failed_segments\":%llu,\"retries_direct\":%llu,\"device\":%d,\"cu_count\":%d}",
                      m->k, m->W, slot_bytes(m->W), (unsigned long long)m->capacity, (unsigned long long)m->size,
                      (unsigned long long)m->tombstones, m->capacity ? (double)m->size / (double)m->capacity : 0.0,
                      (unsigned long long)m->total_occurrences, (unsigned long long)m->grows, m->last_count_ms,
                      (unsigned long long)m->last_count_occ, (unsigned long long)m->part_launches,
-                     (unsigned long long)m->direct_launches, m->ctx->device, m->ctx->cu_count);
+                     (unsigned long long)m->direct_launches, (unsigned long long)m->spilled_keys,
+                     (unsigned long long)m->failed_segments, (unsigned long long)m->retries_direct, m->ctx->device, m->ctx->cu_count);
     if (w < 0 || (size_t)w >= cap) return fail(m->ctx, GK_E_CAPACITY, "stats buffer too small");
     return GK_OK;
 }

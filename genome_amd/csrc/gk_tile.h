@@ -62,5 +62,18 @@ __device__ __forceinline__ void for_each_window(const u32 *tile, u64 a0, u64 r0,
         for (int p = gl; p < nk; p += G) f(tile_kmer(tile, bit0 + 2 * p, k, (Kmer<W> *)nullptr));
     }
 }
+// same walk, but the callback also gets the tile-local read index and the window position
+template <int W, class F>
+__device__ __forceinline__ void for_each_window_at(const u32 *tile, u64 a0, u64 r0, int nr, u32 stride, int k, int G, F f) {
+    const uint8_t *tb = reinterpret_cast<const uint8_t *>(tile);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int per_wave = 64 / G, sub = lane / G, gl = lane & (G - 1);
+    for (int r = wave * per_wave + sub; r < nr; r += nwaves * per_wave) {
+        const u32 ro = (u32)((r0 + r) * stride - a0);
+        const int nk = (int)tb[ro] - k + 1;
+        const u32 bit0 = (ro + 1) * 8;
+        for (int p = gl; p < nk; p += G) f(r, p, tile_kmer(tile, bit0 + 2 * p, k, (Kmer<W> *)nullptr));
+    }
+}
 
 }  // namespace gk
