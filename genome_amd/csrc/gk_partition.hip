@@ -19,6 +19,14 @@
 //                       EMPTY when the table is known to be empty), insert the segment's keys with
 //                       LDS atomics (same probe sequence as gk::table_add), store it back.
 //
+// Two forms.  EXACT (ragged read streams): all five passes; the histograms size every region
+// exactly.  OVER-PROVISIONED (fixed-stride records, key arrays — the key count is known up front):
+// hashed keys spread binomially, so every L1 bucket and every segment gets a fixed region of
+// mean + 8 sigma + slack keys, P1 and P3 disappear, and P2 (k_op_scatter1_reads) extracts each window
+// ONCE, parking the tile's keys in LDS while it counts and reserves.  Keys that do not fit a region
+// (heavy hitters) go to a spill list replayed through the direct path after P5; if the spill list
+// overflows too, only scratch has been touched and the whole batch takes the direct path.
+//
 // The source is either a `.bin` read stream (extract + canonicalise on the fly, FreqFilter.scala:28-36)
 // or an array of already-routed keys (the owner side of the all-to-all).  Results are identical
 // to the direct path: same slots layout, same probing; only the order of insertion differs, which
