@@ -476,7 +476,10 @@ struct LdsAdd {
     __device__ __forceinline__ void operator()(u32 *p, u32 v) const { atomicAdd(p, v); }
 };
 
-static constexpr int SBLOCK = GK_SEG_BITS1 <= 10 ? 256 : 512;                 // threads per segment workgroup
+#ifndef GK_SBLOCK
+#define GK_SBLOCK (GK_SEG_BITS1 <= 10 ? 256 : 512)
+#endif
+static constexpr int SBLOCK = GK_SBLOCK;               // threads per segment workgroup
 static constexpr int SEG_KPT = (1 << GK_SEG_BITS1) / SBLOCK;                  // keys preloaded per thread
 template <int W>
 __global__ __launch_bounds__(SBLOCK) void k_seg_insert(Table<W> t, const u64 *__restrict__ keys, PartArrays a, int from_empty, Counters *ctr) {

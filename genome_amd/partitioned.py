@@ -199,8 +199,9 @@ def exchange_records(dist, send, rec_counts, kmer_counts, slot: int, region_reco
     nrec, nkm = int(rcn[:, 0].sum()), int(rcn[:, 1].sum())
     if recv is None or recv.numel() < nrec * slot:
         recv = torch.empty(max(nrec * slot, slot), dtype=torch.uint8, device=send.device)
-    ins = [send[p * region_records * slot: (p * region_records + int(rec_counts[p])) * slot] for p in range(P)]
-    off = np.concatenate([[0], np.cumsum(rcn[:, 0])]).astype(np.int64)
-    outs = [recv[int(off[p]) * slot: int(off[p + 1]) * slot] for p in range(P)]
-    dist.all_to_all(outs, ins, group=group)
+    # pack the P region prefixes back to back (one device copy), then ONE all_to_all_single with split sizes
+    packed = torch.cat([send[p * region_records * slot: (p * region_records + int(rec_counts[p])) * slot] for p in range(P)])
+    dist.all_to_all_single(recv[:nrec * slot], packed,
+                           output_split_sizes=[int(c) * slot for c in rcn[:, 0]],
+                           input_split_sizes=[int(c) * slot for c in rec_counts], group=group)
     return recv, nrec, nkm

@@ -80,3 +80,39 @@ def test_two_rank_exchange_equals_single_table(tmp_path, k):
     # what rank a sent to rank b is what rank b says it received from a
     assert parts[0]["sent"][1] == parts[1]["received"][0] and parts[1]["sent"][0] == parts[0]["received"][1]
     assert min(len(p["lo"]) for p in parts) > 0
+
+
+def _worker_records(rank, world, port, out_dir):
+    """exchange_records (the super-k-mer form bench.py uses over RCCL) on two gloo ranks: records are
+    synthetic fixed slots tagged with (source rank, destination rank, serial)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from genome_amd.partitioned import exchange_records
+    slot, region = 16, 50
+    rec_counts = np.array([7 + 3 * rank, 11 - 2 * rank], np.int64)      # records for rank 0 / rank 1
+    kmer_counts = rec_counts * (5 + rank)
+    send = torch.zeros(world * region * slot, dtype=torch.uint8)
+    for p in range(world):
+        for i in range(int(rec_counts[p])):
+            o = (p * region + i) * slot
+            send[o], send[o + 1], send[o + 2] = rank, p, i
+    recv, nrec, nkm = exchange_records(dist, send, rec_counts, kmer_counts, slot, region)
+    got = recv[:nrec * slot].numpy().reshape(-1, slot)
+    np.savez(os.path.join(out_dir, f"rec{rank}.npz"), got=got, nrec=nrec, nkm=nkm)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_record_exchange(tmp_path):
+    world, port = 2, 31500 + os.getpid() % 2000
+    mp.start_processes(_worker_records, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method="spawn")
+    sent = {0: np.array([7, 11]), 1: np.array([10, 9])}
+    for rank in range(world):
+        z = np.load(tmp_path / f"rec{rank}.npz")
+        want_n = sent[0][rank] + sent[1][rank]
+        assert int(z["nrec"]) == want_n == len(z["got"])
+        assert int(z["nkm"]) == sent[0][rank] * 5 + sent[1][rank] * 6
+        rows = [tuple(int(x) for x in r[:3]) for r in z["got"]]
+        want = [(0, rank, i) for i in range(sent[0][rank])] + [(1, rank, i) for i in range(sent[1][rank])]
+        assert rows == want            # grouped by source rank, in order; nothing from the region padding
