@@ -14,6 +14,7 @@ struct gk_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // phase boundaries of the partitioned path
     int cu_count = 256;
+    void *skm_counts = nullptr;      // device scratch of gk_shard_superkmers_dev (cursors, counts, overflow flag)
     std::string err;
 };
 

@@ -187,8 +187,6 @@ __global__ __launch_bounds__(BLOCK) void k_skm_route(const uint8_t *__restrict__
     if (threadIdx.x < P && h_kmer[threadIdx.x]) atomicAdd(&kmer_counts[threadIdx.x], (unsigned long long)h_kmer[threadIdx.x]);
 }
 
-static thread_local unsigned long long *tls_counts = nullptr;   // [2 * MAX_PARTS + 1]: cursors, k-mer counts, overflow
-
 extern "C" {
 
 int gk_skm_slot_bytes(int k) { return k_supported(k) ? skm_slot_bytes(k) : 0; }
@@ -206,7 +204,9 @@ int gk_shard_superkmers_dev(gk_ctx *ctx, int k, const void *dev_records, uint64_
     if (nreads == 0 || nk == 0) return GK_OK;
     if (!dev_out) return fail(ctx, GK_E_INVALID, "null record buffer");
     const u64 region_cap = out_cap_records / (u64)P;
-    if (!tls_counts) GK_HIP(ctx, hipMalloc((void **)&tls_counts, (2 * MAX_PARTS + 1) * sizeof(unsigned long long)));
+    if (region_cap == 0) return fail(ctx, GK_E_CAPACITY, "record buffer too small: out_cap_records must be at least P");
+    if (!ctx->skm_counts) GK_HIP(ctx, hipMalloc(&ctx->skm_counts, (2 * MAX_PARTS + 1) * sizeof(unsigned long long)));
+    unsigned long long *tls_counts = (unsigned long long *)ctx->skm_counts;   // [2 * MAX_PARTS + 1]: cursors, k-mer counts, overflow
     GK_HIP(ctx, hipMemsetAsync(tls_counts, 0, (2 * MAX_PARTS + 1) * sizeof(unsigned long long), ctx->stream));
     const u32 stride = 1 + (read_len + 3) / 4;
     const u64 ntiles = (nreads + TILE_READS - 1) / TILE_READS;
