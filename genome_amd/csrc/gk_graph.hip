@@ -21,6 +21,8 @@
 // Where the reference's result depends on node iteration order (out-edge insertion order after
 // simplifyGraph), this file reproduces "ascending k-mer order", the oracle's deterministic choice.
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -280,6 +282,155 @@ __global__ __launch_bounds__(BLOCK) void k_walk(Table<W> t, int k, GraphView g, 
             if (end != NONE) atomicAdd(&g.in_deg[end], 1u);             // end.inEdgeIds += id    :181
             else *err = 3;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Unitigs by POINTER JUMPING (list ranking) instead of one lane walking each edge base by base:
+// k_walk is one dependent probe per base, so a single 4.6 Mbp unitig (an error-free bacterial
+// genome) costs 2 x 4.6M x ~1 us = 10 s on one lane.  Here every ORIENTED interior k-mer
+// (id = 2*slot + orientation; interior = non-terminal with exactly one successor) starts with a
+// pointer to its successor and distance 1, pre-terminals (successor is a terminal k-mer) absorb,
+// and log2(longest unitig) rounds of  d[u] += d[next[u]]; next[u] = next[next[u]]  give every
+// interior k-mer its pre-terminal and its distance to it.  From that:
+//   edge (s, b): u0 = s.drop(1) :+ b;  len = d[u0] + 2;  end = successor of pt[u0]
+//   the base appended after interior u (position j+1 of its edge, u = u_j) is placed by u itself:
+//   the chain of rc(u) runs rc(u_{j-1}), ..., rc(u_0), rc(s), so j = d[rc u], u0 = rc(pt[rc u]),
+//   s = rc(successor of pt[rc u]), b = last base of u0 — no walk anywhere.
+// Members of all-(1,1) cycles never absorb and are skipped (Graph.scala:375 "perfect cycles are
+// ignored").  Same results as k_walk (tests run both).
+// ---------------------------------------------------------------------------------------------
+template <int W> __device__ __forceinline__ Kmer<W> oriented_kmer(const Table<W> &t, u64 id, int k) {
+    Kmer<W> y = slot_key(t.slots, id >> 1, t.tagged);
+    return (id & 1) ? revcomp(y, k) : y;
+}
+// unique outgoing base of an interior oriented k-mer (from the slot's masks), -1 if not exactly one
+__device__ __forceinline__ int single_out_base(u32 aux, int ori) {
+    const u32 om = ori ? rev4(aux & 15u) : ((aux >> 4) & 15u);
+    return __popc(om) == 1 ? __ffs(om) - 1 : -1;
+}
+
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_pj_init(Table<W> t, int k, u64 *nxt, u32 *dist, u64 *active, unsigned long long *n_active) {
+    __shared__ u32 lds4[BLOCK / 64];
+    __shared__ unsigned long long s_base;
+    const u64 ncap = t.capacity();
+    const u64 ngroups = (ncap + BLOCK - 1) / BLOCK;
+    for (u64 grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const u64 i = grp * BLOCK + threadIdx.x;
+        u32 nact = 0;
+        u64 nx[2] = {0, 0};
+        u32 dd[2] = {0, 0};
+        bool act[2] = {false, false};
+        if (i < ncap && slot_live(&t.slots[i])) {
+            const u32 aux = t.slots[i].aux;
+            if (!(aux & (AUX_TERMINAL | AUX_SECONDARY))) {
+                const Kmer<W> y = slot_key(t.slots, i, t.tagged);
+                for (int ori = 0; ori < 2; ori++) {
+                    const int nb = single_out_base(aux, ori);
+                    if (nb < 0) continue;                              // (0,0) k-mers are in no unitig
+                    const Kmer<W> u = ori ? revcomp(y, k) : y;
+                    bool fwd;
+                    const i64 ws = table_find_either(t, append_base(u, nb, k), k, &fwd);
+                    if (ws < 0) continue;
+                    const u64 self = 2 * i + ori;
+                    if (t.slots[ws].aux & AUX_TERMINAL) { nx[ori] = self; dd[ori] = 0; }     // pre-terminal: absorbs
+                    else { nx[ori] = 2 * (u64)ws + (fwd ? 0 : 1); dd[ori] = 1; }
+                    act[ori] = true;
+                    nact++;
+                }
+            }
+        }
+        u64 o = block_reserve(nact, n_active, lds4, &s_base);
+        for (int ori = 0; ori < 2; ori++)
+            if (act[ori]) {
+                const u64 self = 2 * i + ori;
+                nxt[self] = nx[ori];
+                dist[self] = dd[ori];
+                active[o++] = self;
+            }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_pj_round(const u64 *__restrict__ active, u64 n, const u64 *__restrict__ nxtA,
+                                                    const u32 *__restrict__ dA, u64 *__restrict__ nxtB, u32 *__restrict__ dB, u32 *changed) {
+    bool ch = false;
+    for (u64 a = (u64)blockIdx.x * BLOCK + threadIdx.x; a < n; a += (u64)gridDim.x * BLOCK) {
+        const u64 u = active[a];
+        const u64 tt = nxtA[u];
+        if (tt == u) { nxtB[u] = u; dB[u] = dA[u]; continue; }
+        const u64 t2 = nxtA[tt];
+        nxtB[u] = t2;
+        dB[u] = dA[u] + dA[tt];
+        if (nxtA[t2] != t2) ch = true;                // not absorbed yet
+    }
+    if (ch) *changed = 1;
+}
+
+// terminal reached from a pre-terminal oriented k-mer: node id, or NONE
+template <int W>
+__device__ __forceinline__ u32 pj_end_node(const Table<W> &t, int k, u64 pt, const u32 *slot_node) {
+    const u32 aux = t.slots[pt >> 1].aux;
+    const int nb = single_out_base(aux, (int)(pt & 1));
+    if (nb < 0) return NONE;
+    bool fwd;
+    const i64 ws = table_find_either(t, append_base(oriented_kmer(t, pt, k), nb, k), k, &fwd);
+    if (ws < 0 || !(t.slots[ws].aux & AUX_TERMINAL)) return NONE;
+    return slot_node[ws] + (fwd ? 0u : 1u);
+}
+
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_pj_edges(Table<W> t, int k, GraphView g, const u32 *slot_node, const u64 *nxt, const u32 *dist,
+                                                    u32 *err) {
+    for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < g.n_edges; e += (u64)gridDim.x * BLOCK) {
+        const u32 n = g.e_start[e];
+        const Kmer<W> u0 = append_base(node_kmer<W>(g, n), g.e_first[e], k);
+        bool fwd;
+        const i64 s0 = table_find_either(t, u0, k, &fwd);
+        if (s0 < 0) { *err = 1; continue; }
+        u32 end = NONE;
+        u64 len = 1;
+        if (t.slots[s0].aux & AUX_TERMINAL) {
+            end = slot_node[s0] + (fwd ? 0u : 1u);
+        } else {
+            const u64 id0 = 2 * (u64)s0 + (fwd ? 0 : 1);
+            const u64 pt = nxt[id0];
+            if (pt >= 2 * t.capacity() || nxt[pt] != pt) { *err = 4; continue; }   // unregistered / not absorbed: cannot happen from a terminal
+            len = (u64)dist[id0] + 2;
+            end = pj_end_node(t, k, pt, slot_node);
+        }
+        g.e_end[e] = end;
+        g.e_len[e] = len;
+        if (end != NONE) atomicAdd(&g.in_deg[end], 1u);
+        else *err = 3;
+    }
+}
+
+__device__ __forceinline__ void pool_or(uint8_t *pool, u64 off, u64 pos, int base) {
+    const u64 byte = off + (pos >> 2);
+    u32 *w = reinterpret_cast<u32 *>(pool) + (byte >> 2);
+    atomicOr(w, (u32)base << (((byte & 3) * 8) + (pos & 3) * 2));
+}
+
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_pj_emit(Table<W> t, int k, GraphView g, const u32 *slot_node, const u64 *active, u64 n_active,
+                                                   const u64 *nxt, const u32 *dist, u32 *err) {
+    const u64 tid = (u64)blockIdx.x * BLOCK + threadIdx.x, stride = (u64)gridDim.x * BLOCK;
+    for (u64 e = tid; e < g.n_edges; e += stride) pool_or(g.pool, g.e_off[e], 0, g.e_first[e]);       // builder += base  :352
+    for (u64 a = tid; a < n_active; a += stride) {
+        const u64 u = active[a], v = u ^ 1;                     // v = rc(u): same slot, other orientation
+        const u64 pt = nxt[v], ptu = nxt[u], nid = 2 * t.capacity();
+        if (pt >= nid || ptu >= nid) { *err = 7; continue; }    // the partner orientation must have been registered too
+        if (nxt[pt] != pt || nxt[ptu] != ptu) continue;         // member of an all-(1,1) cycle
+        const int nb = single_out_base(t.slots[u >> 1].aux, (int)(u & 1));
+        const u32 rs_node = pj_end_node(t, k, pt, slot_node);   // node of rc(s)
+        if (nb < 0 || rs_node == NONE) { *err = 5; continue; }
+        const u32 partner = rs_node ^ 1u;
+        const u32 s_node = g.node_alive[partner] ? partner : rs_node;      // palindromic node: s == rc(s)
+        const int b = 3 - first_base(oriented_kmer(t, pt, k));            // last base of u0 = complement of first base of rc(u0)
+        const u32 e = g.out_edge[(u64)s_node * 4 + b];
+        if (e == NONE) { *err = 6; continue; }
+        pool_or(g.pool, g.e_off[e], (u64)dist[v] + 1, nb);
     }
 }
 
@@ -725,9 +876,9 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
     u64 *tslots = nullptr;
     int rc = GK_OK;
     hipError_t e = hipMalloc((void **)&d_cnt, 8 * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_err, 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_err, 8);
     if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, 64, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_err, 0, 4, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_err, 0, 8, ctx->stream);
     unsigned long long h_cnt[8] = {0};
     u32 h_err = 0;
     auto done = [&](int code) {
@@ -771,9 +922,48 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
         // every edge slot the walk will visit must have been written by k_make_nodes
         if (h_cnt[3] != nE) return done(fail(ctx, GK_E_STATE, "edge stub count mismatch: " + std::to_string(h_cnt[3]) + " vs " + std::to_string(nE)));
     }
-    // 3. walks: measure, reserve the sequence pool, emit
+    // 3. unitigs: measure, reserve the sequence pool, emit.  One lane per edge walking base by base
+    //    (k_walk) when edges are short; pointer jumping when they are long (see k_pj_* above).
     if (nE) {
-        hipLaunchKernelGGL(k_walk<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node, 0, m->capacity + 1, d_err);
+        const char *force = getenv("GK_GRAPH_UNITIGS");        // "walk" | "pj": test hook
+        const bool use_pj = force ? !strcmp(force, "pj") : (m->size / std::max<u64>(nE, 1) >= 16);
+        u64 *nxtA = nullptr, *nxtB = nullptr, *active = nullptr;
+        u32 *dA = nullptr, *dB = nullptr;
+        u64 n_active = 0;
+        auto pj_free = [&]() {
+            for (void *p : {(void *)nxtA, (void *)nxtB, (void *)active, (void *)dA, (void *)dB}) if (p) (void)hipFree(p);
+        };
+        if (use_pj) {
+            const u64 nid = 2 * m->capacity;
+            e = hipMalloc((void **)&nxtA, nid * 8);
+            if (e == hipSuccess) e = hipMalloc((void **)&nxtB, nid * 8);
+            if (e == hipSuccess) e = hipMalloc((void **)&dA, nid * 4);
+            if (e == hipSuccess) e = hipMalloc((void **)&dB, nid * 4);
+            if (e == hipSuccess) e = hipMalloc((void **)&active, std::max<u64>(2 * m->size, 1) * 8);
+            if (e == hipSuccess) e = hipMemsetAsync(nxtA, 0xff, nid * 8, ctx->stream);       // unregistered ids are out of range
+            if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: pointer-jumping arrays")); }
+            hipLaunchKernelGGL(k_pj_init<W>, dim3(ggrid(ctx, m->capacity)), dim3(BLOCK), 0, ctx->stream, t, k, nxtA, dA, active, &d_cnt[5]);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 48, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: pj init")); }
+            n_active = h_cnt[5];
+            for (int round = 0; round < 64 && n_active; round++) {
+                u32 changed = 0;
+                e = hipMemsetAsync(d_err + 1, 0, 4, ctx->stream);
+                if (e != hipSuccess) break;
+                hipLaunchKernelGGL(k_pj_round, dim3(ggrid(ctx, n_active)), dim3(BLOCK), 0, ctx->stream, active, n_active, nxtA, dA, nxtB, dB, d_err + 1);
+                e = hipMemcpyAsync(&changed, d_err + 1, 4, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                std::swap(nxtA, nxtB);
+                std::swap(dA, dB);
+                if (e != hipSuccess || !changed) break;
+            }
+            if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: pj rounds")); }
+            hipLaunchKernelGGL(k_pj_edges<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node, nxtA, dA, d_err);
+        } else {
+            hipLaunchKernelGGL(k_walk<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node, 0, m->capacity + 1, d_err);
+        }
         e = hipGetLastError();
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_reserve_pool, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, g->v, (u64)0, &d_cnt[4]);
@@ -782,17 +972,29 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
         if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 40, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: walk"));
-        if (h_err) return done(fail(ctx, GK_E_STATE, "unitig walk failed (code " + std::to_string(h_err) +
-                                    "): the table changed since classification or is inconsistent"));
+        if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: walk")); }
+        if (h_err) { pj_free(); return done(fail(ctx, GK_E_STATE, "unitig construction failed (code " + std::to_string(h_err) +
+                                    "): the table changed since classification or is inconsistent")); }
         g->pool_used = h_cnt[4];
-        g->pool_cap = std::max<u64>(g->pool_used, 1);
+        g->pool_cap = (std::max<u64>(g->pool_used, 1) + 7) / 4 * 4;        // whole 32-bit words (k_pj_emit ORs words)
         e = hipMalloc((void **)&g->v.pool, g->pool_cap);
-        if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: pool"));
-        hipLaunchKernelGGL(k_walk<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node, 1, m->capacity + 1, d_err);
-        e = hipGetLastError();
+        if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: pool")); }
+        if (use_pj) {
+            e = hipMemsetAsync(g->v.pool, 0, g->pool_cap, ctx->stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_pj_emit<W>, dim3(ggrid(ctx, std::max<u64>(n_active, nE))), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node,
+                                   active, n_active, nxtA, dA, d_err);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream);
+        } else {
+            hipLaunchKernelGGL(k_walk<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node, 1, m->capacity + 1, d_err);
+            e = hipGetLastError();
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        pj_free();
         if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: emit"));
+        if (h_err) return done(fail(ctx, GK_E_STATE, "unitig emission failed (code " + std::to_string(h_err) + ")"));
     } else {
         e = hipMalloc((void **)&g->v.pool, 1);
         if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: pool"));

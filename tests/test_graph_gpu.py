@@ -206,3 +206,52 @@ def test_graph_at_scale_properties(ctx):
     g.simplifyGraph()
     assert g.counts()[:2] == (nn, ne)            # a fresh graph has no (1,1)/(0,0) node
     g.close(); m.close(); ctx.free(d)
+
+
+@pytest.mark.parametrize("mode", ["walk", "pj"])
+@pytest.mark.parametrize("k,seed,hap", [(11, 2, 2), (31, 5, 2), (35, 6, 2), (64, 9, 1)])
+def test_unitig_construction_modes_agree_with_oracle(ctx, monkeypatch, mode, k, seed, hap):
+    """Both unitig constructions — one lane walking each edge (k_walk) and pointer jumping
+    (k_pj_*) — must give the oracle's graph, on bushy graphs and on a long clean unitig."""
+    monkeypatch.setenv("GK_GRAPH_UNITIGS", mode)
+    rnd = random.Random(seed)
+    for err, nreads in ((0.01, 700), (0.0, 400)):
+        reads = _reads(rnd, nreads, k + 5, min(255, k + 90), 1500, err, hap)
+        binb = dna.reads_to_bin(reads)
+        m = HipDNAMap(ctx, k); ref = O.PMap(k, 1)
+        m.count_reads(binb, len(reads)); ref.count_reads(binb, len(reads))
+        m.deleteAll_lt(2); ref.delete_lt(2)
+        g, og = buildGraph(k, m), O.Graph(ref)
+        assert g.canonical() == oracle_canonical(og)
+        g.removeBubbles(); og.remove_bubbles(); g.simplifyGraph(); og.simplify()
+        assert g.canonical() == oracle_canonical(og)
+        g.close(); m.close()
+
+
+def test_long_unitig_is_fast_and_exact(ctx):
+    """A 300 kbp error-free genome is two mirrored unitigs of ~3e5 bases: pointer jumping builds them
+    in milliseconds (one lane walking would take ~0.6 s); the sequence must BE the genome."""
+    import time
+    n, L_, k, G = 60000, 150, 31, 300_000
+    d = ctx.alloc(n * synth.record_stride(L_) + 64)
+    ctx.synth_reads(d, n, L_, "G", 12, 0, G, 0.0)
+    m = HipDNAMap(ctx, k, G * 2)
+    m.count_reads_dev(d, n, L_)
+    m.deleteAll_lt(1)
+    t0 = time.perf_counter()
+    g = buildGraph(k, m)
+    dt = time.perf_counter() - t0
+    nodes, edges = g.canonical()
+    genome = synth.bases_to_str(synth.genome_bases(G, 12))
+    total = sum(len(q) for _, _, q in edges)
+    assert len(nodes) % 2 == 0 and total == g.counts()[2]
+    # every edge, prefixed by its start node, is a substring of the genome or of its reverse complement
+    rc = R.rev_comp(genome)
+    for s, t_, q in edges:
+        w = s + q
+        assert (w in genome) or (w in rc)
+        assert w.endswith(t_)
+    longest = max(len(q) for _, _, q in edges)
+    assert longest > 20000
+    assert dt < 5.0
+    g.close(); m.close(); ctx.free(d)
