@@ -482,7 +482,7 @@ struct LdsAdd {
 static constexpr int SBLOCK = GK_SBLOCK;               // threads per segment workgroup
 static constexpr int SEG_KPT = (1 << GK_SEG_BITS1) / SBLOCK;                  // keys preloaded per thread
 template <int W>
-__global__ __launch_bounds__(SBLOCK) void k_seg_insert(Table<W> t, const u64 *__restrict__ keys, PartArrays a, int from_empty, Counters *ctr) {
+__global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W> t, const u64 *__restrict__ keys, PartArrays a, int from_empty, Counters *ctr) {
     extern __shared__ uint4 lds_raw[];
     constexpr u32 S = 1u << SegBits<W>::value;
     constexpr u32 NVEC = S * sizeof(Slot<W>) / 16;
