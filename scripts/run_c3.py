@@ -1,6 +1,6 @@
 """BASELINE.json configs[2] rehearsal: N x 150 bp reads over an E. coli-scale genome, k=31, one GPU:
 count (chunked) -> deleteAll(<3) -> buildGraph -> removeBubbles -> simplifyGraph -> retainLargest, timed.
-usage: python scripts/run_c3.py [reads=5000000] [genome=4600000] [err=0.005]"""
+usage: python scripts/run_c3.py [reads=5000000] [genome=4600000] [err=0.005] [chunk_reads=2000000] [capacity_hint=0]"""
 import sys, time, json
 sys.path.insert(0, '.')
 import numpy as np
@@ -11,11 +11,13 @@ from genome_amd.graph import buildGraph
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 4_600_000
 err = float(sys.argv[3]) if len(sys.argv) > 3 else 0.005
-L, k, chunk = 150, 31, 2_000_000
+L, k = 150, 31
+chunk = int(sys.argv[4]) if len(sys.argv) > 4 else 2_000_000
+hint = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 ctx = Context(0)
 stride = synth.record_stride(L)
 d = ctx.alloc(chunk * stride + 64)
-m = HipDNAMap(ctx, k, 0)
+m = HipDNAMap(ctx, k, hint)
 t = {}
 t0 = time.perf_counter(); occ = 0; tgen = 0.0
 for first in range(0, n, chunk):

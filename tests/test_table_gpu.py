@@ -37,7 +37,7 @@ def test_device_is_gfx950(ctx):
     assert L.device_count() >= 1
 
 
-@pytest.mark.parametrize("name", sorted(f[:-5] for f in os.listdir(GOLDEN) if f.endswith(".json")))
+@pytest.mark.parametrize("name", sorted(f[:-5] for f in os.listdir(GOLDEN) if f.endswith(".json") and f != "hash_ties.json"))
 def test_golden_tables(ctx, name):
     fx = json.load(open(os.path.join(GOLDEN, name + ".json")))
     k, P, rounds = fx["k"], fx["P"], fx["rounds"]
