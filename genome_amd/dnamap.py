@@ -163,6 +163,26 @@ class HipDNAMap:
                                       n, C.byref(got)), self.ctx.h)
         return lo, hi, cnt
 
+    def mapReduce(self, map_fn, reduce_fn):                  # :58 — closures run on the host over the export
+        """DNAMap.mapReduce(map, reduce) (ArrayDNAMap.scala:234-241): `map_fn((key_str, count))` returns
+        None or a value, `reduce_fn(list_of_values)` folds them.  The table comes back once
+        (gk_map_export); the one closure the hot path passes (buildGraph's classify) is fused on
+        the GPU instead — see genome_amd.graph.buildGraph."""
+        lo, hi, cnt = self.items()
+        vals = []
+        for a, b, c in zip(lo.tolist(), hi.tolist(), cnt.tolist()):
+            v = map_fn((dna.unpack(a, b, self.k), c))
+            if v is not None:
+                vals.append(v)
+        return reduce_fn(vals)
+
+    def foreach(self, f):                                    # :59
+        self.mapReduce(lambda kv: (f(kv), None)[1], lambda _: None)
+
+    def getAll(self, key):                                   # :52 — an Int map holds at most one value per key
+        v = self.apply(key)
+        return [] if v is None else [v]
+
     def sorted_items(self):
         """Canonical table serialisation: sorted by (hi, lo) unsigned."""
         lo, hi, cnt = self.items()

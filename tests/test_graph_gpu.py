@@ -298,3 +298,28 @@ def test_hash_tie_kmers_table_and_graph(ctx, idx, rounds):
         assert g.canonical() == oracle_canonical(og)
         g.close()
     m.close()
+
+
+def test_graphbuilder_flow_through_the_mirror_api(ctx):
+    """GraphBuilder.startup (S/scripts/GraphBuilder.scala:28-54) spelled with the Python mirror:
+    extractFilteredKmers(data, k, rounds=3) -> size -> buildGraph -> components/retain, for one
+    table and for 4 logical partitions, against the oracle."""
+    from genome_amd.freqfilter import PairedEndData, extractFilteredKmers
+    k, rounds = 21, 3
+    rec = synth.reads_mode_g(6000, 100, 12000, 0.01, config_id=31)
+    data = PairedEndData(count=3000, bin_bytes=rec.tobytes())
+    ref = O.PMap(k, 1)
+    ref.count_reads(rec[:5000].tobytes(), 5000)          # take_first = 2500 pairs
+    ref.delete_lt(rounds)
+    og = O.Graph(ref)
+    want = oracle_canonical(og)
+    for parts in (1, 4):
+        kmers = extractFilteredKmers(data, k, rounds, ctx=ctx, take_first=2500, partitions=parts)
+        assert kmers.size() == ref.size()
+        g = buildGraph(k, kmers)
+        assert g.canonical() == want
+        kept, comps = g.retainLargest()
+        og2 = O.Graph(ref)
+        assert comps == og2.num_components() and kept == og2.retain_largest()
+        assert g.canonical() == oracle_canonical(og2)
+        g.close(); kmers.close()

@@ -142,6 +142,12 @@ def test_apply_contains_update(ctx, k):
     rc = R.rev_comp(keys[0])
     if rc not in want:
         assert not m.contains(rc)
+    # mapReduce / foreach / getAll of the trait (ArrayDNAMap.scala:52,58-59), closures on the host
+    assert m.mapReduce(lambda kv: kv[1] if kv[1] > 1 else None, sum) == sum(v for v in want.values() if v > 1)
+    seen = {}
+    m.foreach(lambda kv: seen.__setitem__(kv[0], kv[1]))
+    assert seen == want
+    assert m.getAll(keys[0]) == [want[keys[0]]] and m.getAll(keys[-1]) == []
     m.clear()
     assert m.size() == 0 and m.apply(keys[0]) is None
     m.close()
