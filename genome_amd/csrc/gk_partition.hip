@@ -79,6 +79,17 @@ __device__ __forceinline__ u64 fine_begin(const PartArrays &a, u64 s) { return a
 __device__ __forceinline__ u64 fine_count(const PartArrays &a, u64 s) {
     return a.op ? min((unsigned long long)a.cursor2[s], a.cap2) : a.fine_base[s + 1] - a.fine_base[s];
 }
+// Load a word that is the same for the whole workgroup and was written by an EARLIER kernel through
+// the scalar cache (constant address space): it then counts on lgkmcnt, not vmcnt, so waiting for it
+// does not also wait for every vector store the wave still has in flight.
+template <class T> __device__ __forceinline__ T uniform_load(const T *p) {
+    return *(const __attribute__((address_space(4))) T *)(p);
+}
+__device__ __forceinline__ u64 fine_begin_u(const PartArrays &a, u64 s) { return a.op ? s * a.cap2 : uniform_load(&a.fine_base[s]); }
+__device__ __forceinline__ u64 fine_count_u(const PartArrays &a, u64 s) {
+    return a.op ? min((unsigned long long)uniform_load(&a.cursor2[s]), a.cap2)
+                : uniform_load(&a.fine_base[s + 1]) - uniform_load(&a.fine_base[s]);
+}
 template <int W> __device__ __forceinline__ void spill_key(const PartArrays &a, u64 w0, u64 w1) {
     const unsigned long long si = atomicAdd(a.nspill, 1ull);
     if (si < a.spill_cap) {
@@ -348,6 +359,13 @@ __global__ __launch_bounds__(PBLOCK) void k_op_scatter1_reads(const uint8_t *__r
             if (b == 0xffff) continue;
             const u32 j = atomicAdd(&rank[b], 1u);
             const Kmer<W> x = load_key<W>(flat, i);
+#if defined(GK_ABLATE) && GK_ABLATE == 4     // timing experiment: no global stores
+            if (x.lo == 0x1234567ull) store_key<W>(out, i, x);
+            continue;
+#elif defined(GK_ABLATE) && GK_ABLATE == 6   // timing experiment: linear stores
+            store_key<W>(out, tl * (OP_CAP / W) + i, x);
+            continue;
+#endif
             if (j < lim[b]) store_key<W>(out, gb[b] + j, x);
             else if constexpr (W == 1) spill_key<1>(a, x.lo, 0);
             else spill_key<2>(a, x.lo, x.hi);
@@ -476,84 +494,155 @@ struct LdsAdd {
     __device__ __forceinline__ void operator()(u32 *p, u32 v) const { atomicAdd(p, v); }
 };
 
+// Insert into a segment held in LDS that is KNOWN to keep a free slot (built from empty with fewer
+// keys than slots): the probe needs no bound and no look-before-CAS.  The general seg_add spends
+// ~35 instructions per probe step on nested divergent branches, and k_seg_insert is bound by
+// instruction issue (PMC: ~180 VALU + ~210 SALU per 64 keys, LDS array 40 % busy), not by HBM; this
+// form is one ds_cmpst, two compares and the step.  Same slot protocol as seg_add.
+__device__ __forceinline__ u32 lds_add_unbounded(Slot<1> *seg, u32 pos, Kmer<1> key) {
+    constexpr u32 smask = (1u << SegBits<1>::value) - 1u;
+    u32 i = pos;
+    u64 old;
+    for (;;) {
+        old = atomicCAS(reinterpret_cast<unsigned long long *>(&seg[i].w0), (unsigned long long)KEY_EMPTY, (unsigned long long)key.lo);
+        if (old == KEY_EMPTY || old == key.lo) break;
+        i = (i + 1) & smask;
+    }
+    if (old == KEY_EMPTY) return 1u;
+    atomicAdd(&seg[i].extra, 1u);
+    return 0u;
+}
+__device__ __forceinline__ u32 lds_add_unbounded(Slot<2> *seg, u32 pos, Kmer<2> key) {
+    constexpr u32 smask = (1u << SegBits<2>::value) - 1u;
+    const Stored<2> k = to_stored(key);
+    u32 i = pos;
+    for (;;) {
+        const u64 c0 = atomicCAS(reinterpret_cast<unsigned long long *>(&seg[i].w0), (unsigned long long)KEY_EMPTY, (unsigned long long)k.w0);
+        if (c0 == KEY_EMPTY || c0 == k.w0) {
+            const u64 c1 = atomicCAS(reinterpret_cast<unsigned long long *>(&seg[i].w1), (unsigned long long)KEY_EMPTY, (unsigned long long)k.w1);
+            if (c1 == KEY_EMPTY) return 1u;
+            if (c1 == k.w1) { atomicAdd(&seg[i].extra, 1u); return 0u; }
+        }
+        i = (i + 1) & smask;
+    }
+}
+
 #ifndef GK_SBLOCK
 #define GK_SBLOCK (GK_SEG_BITS1 <= 10 ? 256 : 512)
 #endif
 static constexpr int SBLOCK = GK_SBLOCK;               // threads per segment workgroup
-static constexpr int SEG_KPT = (1 << GK_SEG_BITS1) / SBLOCK;                  // keys preloaded per thread
 template <int W>
 __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W> t, const u64 *__restrict__ keys, PartArrays a, int from_empty, Counters *ctr) {
     extern __shared__ uint4 lds_raw[];
     constexpr u32 S = 1u << SegBits<W>::value;
     constexpr u32 NVEC = S * sizeof(Slot<W>) / 16;
+    constexpr int KPT = (int)(S / SBLOCK);                          // keys preloaded per thread
     Slot<W> *seg = reinterpret_cast<Slot<W> *>(lds_raw);
     u32 *flags = reinterpret_cast<u32 *>(lds_raw + NVEC);         // [0] claims, [1] overflow
     const u64 nseg = t.nseg();
     u32 wg_claims = 0;      // thread 0 only: ONE global atomic per workgroup at the end (a same-address
                             // atomic per segment caps the kernel at ~88 segments/us chip-wide)
-    for (u64 s = blockIdx.x; s < nseg; s += gridDim.x) {
-        const u64 kb = fine_begin(a, s), ke = kb + fine_count(a, s);
+    // Software pipeline over this workgroup's segments.  One segment is a chain of dependent round
+    // trips (key range -> keys -> LDS inserts -> write-back) and only four workgroups fit a CU, so
+    // the next segment's keys are requested before the current segment's inserts and the key range
+    // of the one after that before that: both latencies hide behind the insert phase.
+    auto range_of = [&](u64 s2, u64 &b, u32 &n) {
+        const u64 sc = s2 < nseg ? s2 : nseg - 1;                     // clamped, branch-free loads
+        const u64 cnt = fine_count_u(a, sc);
+        b = fine_begin_u(a, sc);
+        n = s2 < nseg ? (u32)min(cnt, (u64)0xffffffffu) : 0u;
+    };
+    auto request_keys = [&](Kmer<W> (&kk)[KPT], u64 b, u32 n) {
+        const u32 nk = min(n, (u32)(SBLOCK * KPT));
+#pragma unroll
+        for (int j = 0; j < KPT; j++) {
+            const u32 i = threadIdx.x + j * SBLOCK;
+            kk[j] = load_key<W>(keys, nk ? b + (i < nk ? i : nk - 1) : 0);
+        }
+    };
+    u64 kb, kbn; u32 cnt, cntn;
+    // one segment; `cur` holds its keys (requested one step earlier), `nxt` receives the next one's.
+    // The two register sets swap roles from step to step (a copy would have to wait for the loads).
+    auto step = [&](u64 s, Kmer<W> (&cur)[KPT], Kmer<W> (&nxt)[KPT]) {
+        u64 kbnn; u32 cntnn;
+        range_of(s + 2ull * gridDim.x, kbnn, cntnn);                  // two ahead: its key range
+        request_keys(nxt, kbn, cntn);                                 // one ahead: its keys
         uint4 *gseg = reinterpret_cast<uint4 *>(t.slots + (s << SegBits<W>::value));
-        if (kb == ke) {
+        if (cnt == 0) {
             if (from_empty) {       // materialise the pending clear of a segment that gets no key
+#pragma unroll
                 for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) {
                     if constexpr (W == 1) gseg[i] = make_uint4(~0u, ~0u, 0u, 0u);
                     else gseg[i] = (i & 1) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
                 }
-            }
-            continue;
-        }
-        __syncthreads();
-        if (threadIdx.x < 2) flags[threadIdx.x] = 0;
-        // the segment's keys: issue every load now (clamped index, no branch) so that their latency
-        // overlaps the LDS fill below — one memory round trip per segment
-        const u32 nk = (u32)min(ke - kb, (u64)SBLOCK * SEG_KPT);
-        Kmer<W> key[SEG_KPT];
-#pragma unroll
-        for (int j = 0; j < SEG_KPT; j++) {
-            const u32 i = threadIdx.x + j * SBLOCK;
-            key[j] = load_key<W>(keys, kb + (i < nk ? i : nk - 1));
-        }
-        if (from_empty) {
-            for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) {
-                if constexpr (W == 1) lds_raw[i] = make_uint4(~0u, ~0u, 0u, 0u);
-                else lds_raw[i] = (i & 1) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
             }
         } else {
-            for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) lds_raw[i] = gseg[i];
-        }
-        __syncthreads();
-        u32 claims = 0;
-        bool overflow = false;
+            __syncthreads();
+            if (threadIdx.x < 2) flags[threadIdx.x] = 0;
+            const u32 nk = min(cnt, (u32)(SBLOCK * KPT));
+            if (from_empty) {
 #pragma unroll
-        for (int j = 0; j < SEG_KPT; j++) {
-            if (threadIdx.x + j * SBLOCK < nk) {
-                const int r = seg_add(seg, seg_pos<W>(slot_hash(key[j])), key[j], 1u, LdsCas(), LdsAdd(), t.tagged);
+                for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) {
+                    if constexpr (W == 1) lds_raw[i] = make_uint4(~0u, ~0u, 0u, 0u);
+                    else lds_raw[i] = (i & 1) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
+                }
+            } else {
+#pragma unroll
+                for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) lds_raw[i] = gseg[i];
+            }
+            __syncthreads();
+            u32 claims = 0;
+            bool overflow = false;
+            if (from_empty && cnt < S && !t.tagged) {       // fewer keys than slots: cannot fill up
+#pragma unroll
+                for (int j = 0; j < KPT; j++)
+                    if (threadIdx.x + j * SBLOCK < nk) claims += lds_add_unbounded(seg, seg_pos<W>(slot_hash(cur[j])), cur[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < KPT; j++) {
+                    if (threadIdx.x + j * SBLOCK < nk) {
+                        const int r = seg_add(seg, seg_pos<W>(slot_hash(cur[j])), cur[j], 1u, LdsCas(), LdsAdd(), t.tagged);
+                        if (r < 0) overflow = true; else claims += (u32)r;
+                    }
+                }
+            }
+            for (u64 i = kb + (u64)SBLOCK * KPT + threadIdx.x; i < kb + cnt; i += SBLOCK) {   // heavy buckets (repeats)
+                const Kmer<W> kx = load_key<W>(keys, i);
+                const int r = seg_add(seg, seg_pos<W>(slot_hash(kx)), kx, 1u, LdsCas(), LdsAdd(), t.tagged);
                 if (r < 0) overflow = true; else claims += (u32)r;
             }
+            for (int d = 32; d; d >>= 1) claims += __shfl_down(claims, d);
+            if ((threadIdx.x & 63) == 0 && claims) atomicAdd(&flags[0], claims);
+            if (overflow) flags[1] = 1;
+            __syncthreads();
+            if (flags[1]) {
+                // segment full: leave the HBM copy as it was (or EMPTY) and hand the bucket to the host,
+                // which grows the table and replays these keys through the direct path
+                if (from_empty)
+                    for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) {
+                        if constexpr (W == 1) gseg[i] = make_uint4(~0u, ~0u, 0u, 0u);
+                        else gseg[i] = (i & 1) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
+                    }
+                if (threadIdx.x == 0) a.failed[atomicAdd(a.n_failed, 1u)] = (u32)s;
+            } else {
+#pragma unroll
+                for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) gseg[i] = lds_raw[i];
+                if (threadIdx.x == 0) wg_claims += flags[0];
+            }
         }
-        for (u64 i = kb + (u64)SBLOCK * SEG_KPT + threadIdx.x; i < ke; i += SBLOCK) {   // heavy buckets (repeats)
-            const Kmer<W> kx = load_key<W>(keys, i);
-            const int r = seg_add(seg, seg_pos<W>(slot_hash(kx)), kx, 1u, LdsCas(), LdsAdd(), t.tagged);
-            if (r < 0) overflow = true; else claims += (u32)r;
-        }
-        for (int d = 32; d; d >>= 1) claims += __shfl_down(claims, d);
-        if ((threadIdx.x & 63) == 0 && claims) atomicAdd(&flags[0], claims);
-        if (overflow) flags[1] = 1;
-        __syncthreads();
-        if (flags[1]) {
-            // segment full: leave the HBM copy as it was (or EMPTY) and hand the bucket to the host,
-            // which grows the table and replays these keys through the direct path
-            if (from_empty)
-                for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) {
-                    if constexpr (W == 1) gseg[i] = make_uint4(~0u, ~0u, 0u, 0u);
-                    else gseg[i] = (i & 1) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
-                }
-            if (threadIdx.x == 0) a.failed[atomicAdd(a.n_failed, 1u)] = (u32)s;
-            continue;
-        }
-        for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) gseg[i] = lds_raw[i];
-        if (threadIdx.x == 0) wg_claims += flags[0];
+        kb = kbn; cnt = cntn; kbn = kbnn; cntn = cntnn;
+    };
+    Kmer<W> keyA[KPT], keyB[KPT];
+    u64 s = blockIdx.x;
+    range_of(s, kb, cnt);
+    range_of(s + gridDim.x, kbn, cntn);
+    request_keys(keyA, kb, cnt);
+    while (s < nseg) {
+        step(s, keyA, keyB);
+        s += gridDim.x;
+        if (s >= nseg) break;
+        step(s, keyB, keyA);
+        s += gridDim.x;
     }
     if (threadIdx.x == 0 && wg_claims) atomicAdd(&ctr->size, (unsigned long long)wg_claims);
 }
