@@ -538,7 +538,7 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W> t, const u64 
     constexpr u32 NVEC = S * sizeof(Slot<W>) / 16;
     constexpr int KPT = (int)(S / SBLOCK);                          // keys preloaded per thread
     Slot<W> *seg = reinterpret_cast<Slot<W> *>(lds_raw);
-    u32 *flags = reinterpret_cast<u32 *>(lds_raw + NVEC);         // [0] claims, [1] overflow
+    u32 *flags = reinterpret_cast<u32 *>(lds_raw + NVEC);         // [0] claims, [1] overflow, [2] free slots found while loading
     const u64 nseg = t.nseg();
     u32 wg_claims = 0;      // thread 0 only: ONE global atomic per workgroup at the end (a same-address
                             // atomic per segment caps the kernel at ~88 segments/us chip-wide)
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W> t, const u64 
             }
         } else {
             __syncthreads();
-            if (threadIdx.x < 2) flags[threadIdx.x] = 0;
+            if (threadIdx.x < 3) flags[threadIdx.x] = 0;
             const u32 nk = min(cnt, (u32)(SBLOCK * KPT));
             if (from_empty) {
 #pragma unroll
@@ -587,13 +587,21 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W> t, const u64 
                     else lds_raw[i] = (i & 1) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
                 }
             } else {
+                u32 nfree = 0;                                  // a slot is free iff its first key word is EMPTY
 #pragma unroll
-                for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) lds_raw[i] = gseg[i];
+                for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) {
+                    const uint4 v = gseg[i];
+                    lds_raw[i] = v;
+                    if ((W == 1 || !(i & 1)) && (v.x & v.y) == ~0u) nfree++;
+                }
+                __syncthreads();                                // flags[2] = 0 is visible
+                for (int d = 32; d; d >>= 1) nfree += __shfl_down(nfree, d);
+                if ((threadIdx.x & 63) == 0 && nfree) atomicAdd(&flags[2], nfree);
             }
             __syncthreads();
             u32 claims = 0;
             bool overflow = false;
-            if (from_empty && cnt < S && !t.tagged) {       // fewer keys than slots: cannot fill up
+            if (!t.tagged && cnt < (from_empty ? S : flags[2])) {     // fewer keys than free slots: cannot fill up
 #pragma unroll
                 for (int j = 0; j < KPT; j++)
                     if (threadIdx.x + j * SBLOCK < nk) claims += lds_add_unbounded(seg, seg_pos<W>(slot_hash(cur[j])), cur[j]);
