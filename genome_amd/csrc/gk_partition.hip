@@ -307,6 +307,19 @@ __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_keys(const u64 *__rest
     }
 }
 
+// Optional in-kernel phase timers (-DGK_TIMERS; scripts/run_timers.py): thread 0 of every workgroup adds
+// the wall-clock ticks (s_memrealtime, 100 MHz) it spent in each phase; read back with gk_debug_timers.
+#ifdef GK_TIMERS
+__device__ unsigned long long g_timers[16];
+#define GK_T0() unsigned long long t_prev = __builtin_amdgcn_s_memrealtime(), t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define GK_TICK(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); t_acc[i] += t_now - t_prev; t_prev = t_now; } while (0)
+#define GK_TFLUSH(base) do { if (threadIdx.x == 0) for (int q = 0; q < 8; q++) if (t_acc[q]) atomicAdd(&g_timers[(base) + q], t_acc[q]); } while (0)
+#else
+#define GK_T0() do {} while (0)
+#define GK_TICK(i) do {} while (0)
+#define GK_TFLUSH(base) do {} while (0)
+#endif
+
 // P2 of the over-provisioned mode for fixed-stride records: ONE window-extraction pass.  The tile's
 // canonical keys and their L1 buckets are parked in LDS while the per-bucket counts are built, the
 // bucket regions are reserved (one global atomic per (tile, bucket)), then the keys go out.  No P1.
@@ -324,15 +337,18 @@ __global__ __launch_bounds__(PBLOCK) void k_op_scatter1_reads(const uint8_t *__r
     __shared__ unsigned long long gb[256];
     u32 occ = 0;
     const u64 ntiles = (nreads + rs - 1) / rs;
+    GK_T0();
     for (u64 tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const u64 r0 = tl * rs;
         const int nr = (int)min((u64)rs, nreads - r0);
         const u32 nflat = (u32)(nr * nk_max);
         __syncthreads();
+        GK_TICK(5);
         if (threadIdx.x < 256) { hist[threadIdx.x] = 0; rank[threadIdx.x] = 0; }
         for (u32 i = threadIdx.x; i < nflat; i += PBLOCK) fbin[i] = 0xffff;
         const u64 a0 = stage_tile(tile, rec, r0 * stride, (r0 + nr) * stride);
         __syncthreads();
+        GK_TICK(0);
         for_each_window_at<W>(tile, a0, r0, nr, stride, k, group, [&](int r, int p, Kmer<W> x) {
             const Kmer<W> y = canonical(x, k);
             const u32 b = seg_l1(t, slot_hash(y));
@@ -342,7 +358,9 @@ __global__ __launch_bounds__(PBLOCK) void k_op_scatter1_reads(const uint8_t *__r
             atomicAdd(&hist[b], 1u);
             occ++;
         });
+        GK_TICK(1);
         __syncthreads();
+        GK_TICK(2);
         if (threadIdx.x < 256) {
             const u32 c = hist[threadIdx.x];
             u32 fit = 0;
@@ -354,23 +372,19 @@ __global__ __launch_bounds__(PBLOCK) void k_op_scatter1_reads(const uint8_t *__r
             lim[threadIdx.x] = fit;
         }
         __syncthreads();
+        GK_TICK(3);
         for (u32 i = threadIdx.x; i < nflat; i += PBLOCK) {
             const u32 b = fbin[i];
             if (b == 0xffff) continue;
             const u32 j = atomicAdd(&rank[b], 1u);
             const Kmer<W> x = load_key<W>(flat, i);
-#if defined(GK_ABLATE) && GK_ABLATE == 4     // timing experiment: no global stores
-            if (x.lo == 0x1234567ull) store_key<W>(out, i, x);
-            continue;
-#elif defined(GK_ABLATE) && GK_ABLATE == 6   // timing experiment: linear stores
-            store_key<W>(out, tl * (OP_CAP / W) + i, x);
-            continue;
-#endif
             if (j < lim[b]) store_key<W>(out, gb[b] + j, x);
             else if constexpr (W == 1) spill_key<1>(a, x.lo, 0);
             else spill_key<2>(a, x.lo, x.hi);
         }
+        GK_TICK(4);
     }
+    GK_TFLUSH(0);
     for (int d = 32; d; d >>= 1) occ += __shfl_down(occ, d);
     __syncthreads();
     if (threadIdx.x == 0) hist[0] = 0;
@@ -865,5 +879,13 @@ int part_count(gk_map *m, PartScratch **pps, const uint8_t *d_rec, u64 nreads, c
 }
 
 bool part_supported(const gk_map *m) { return m->nb2 <= MAX_NB2; }
+
+#ifdef GK_TIMERS
+extern "C" int gk_debug_timers(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_timers), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_timers), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 }  // namespace gk
