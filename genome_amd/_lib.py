@@ -88,6 +88,13 @@ SIGNATURES = {
     "gk_graph_export_edges": (C.c_int, [vp, u64p, u64p, u64p, u64p, i64p, i64p, C.c_uint64, u64p, u8p, C.c_uint64, u64p]),
     "gk_graph_out_order": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gk_synth_reads_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32]),
+    "gk_prefilter_create": (C.c_int, [vp, C.c_int, C.c_uint64, C.POINTER(vp)]),
+    "gk_prefilter_destroy": (None, [vp]),
+    "gk_prefilter_add_reads": (C.c_int, [vp, u8p, C.c_size_t, C.c_uint64]),
+    "gk_prefilter_add_reads_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int]),
+    "gk_map_count_reads_prefiltered": (C.c_int, [vp, vp, u8p, C.c_size_t, C.c_uint64, u64p, u64p]),
+    "gk_map_count_reads_prefiltered_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, u64p, u64p]),
+    "gk_prefilter_stats": (C.c_int, [vp, u64p, u64p, u64p, u64p]),
 }
 
 

@@ -6,6 +6,7 @@ else is expressed on exported arrays.  All compute happens on the GPU through th
 from __future__ import annotations
 
 import ctypes as C
+import sys
 import json
 import os
 
@@ -29,10 +30,16 @@ class Context:
             self.h = None
 
     def __del__(self):
+        if sys.is_finalizing():      # process exit: the HIP runtime may already be gone, and frees everything anyway
+            return
         try:
             self.close()
         except Exception:
             pass
+
+    def sync(self):
+        """Wait for everything queued on the context's stream."""
+        L.check(L.lib().gk_ctx_sync(self.h), self.h)
 
     def alloc(self, nbytes: int) -> int:
         p = L.vp()
@@ -112,6 +119,8 @@ class HipDNAMap:
             self.h = None
 
     def __del__(self):
+        if sys.is_finalizing():      # process exit: the HIP runtime may already be gone, and frees everything anyway
+            return
         try:
             self.close()
         except Exception:

@@ -5,6 +5,7 @@ canonical serialisation used for parity.
 from __future__ import annotations
 
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -26,6 +27,8 @@ class HipGraph:
             self.h = None
 
     def __del__(self):
+        if sys.is_finalizing():      # process exit: the HIP runtime may already be gone, and frees everything anyway
+            return
         try:
             self.close()
         except Exception:

@@ -50,6 +50,7 @@ typedef enum {
 typedef struct gk_ctx gk_ctx;       /* one device + stream; replaces ActorsHome.system (S/scripts/ActorsHome.scala:20-30) */
 typedef struct gk_map gk_map;       /* one ArrayDNAMap[Int] partition, resident in HBM */
 typedef struct gk_graph gk_graph;   /* a MapGraph, resident in HBM */
+typedef struct gk_prefilter gk_prefilter;   /* exact two-pass singleton pre-filter (2-bit counters) */
 
 /* ---- context ---------------------------------------------------------------------------- */
 int gk_device_count(void);                       /* number of HIP devices, 0 if none / no runtime */
@@ -170,6 +171,28 @@ int gk_graph_export_edges(gk_graph *g, uint64_t *start_lo, uint64_t *start_hi, u
 /* out-edge insertion order of one node (the reference's immutable Map1..Map4 order, used by
  * removeBubbles); bases4 gets up to 4 base codes, *count their number (-1 = no such node) */
 int gk_graph_out_order(gk_graph *g, uint64_t lo, uint64_t hi, int *bases4, int *count);
+
+/* ---- exact two-pass singleton pre-filter -------------------------- */
+/* Analogue of the reference's unused Bloom filter (S/ds/BloomFilter.scala:17-70) in front of
+ * FreqFilter.add (S/data/FreqFilter.scala:28-36): an array of 2-bit saturating counters, 4 per
+ * expected distinct k-mer (1 byte per k-mer instead of a 16/32-byte table slot).
+ *   pass 1: gk_prefilter_add_reads[_dev] over EVERY read that will be counted;
+ *   pass 2: gk_map_count_reads_prefiltered[_dev] over the same reads: a window enters the table only
+ *           if its counter says "seen at least twice".
+ * Every k-mer with true count >= 2 then holds its exact count; a k-mer seen once is either absent or
+ * present with count 1.  So for rounds >= 2, gk_map_filter_lt(rounds) leaves exactly the table that
+ * plain counting + filter_lt(rounds) leaves (FreqFilter.scala:55) — whatever the filter's size. */
+int gk_prefilter_create(gk_ctx *ctx, int k, uint64_t expected_distinct, gk_prefilter **out);
+void gk_prefilter_destroy(gk_prefilter *pf);
+int gk_prefilter_add_reads(gk_prefilter *pf, const uint8_t *bin_host, size_t nbytes, uint64_t nreads);
+int gk_prefilter_add_reads_dev(gk_prefilter *pf, const void *dev_records, uint64_t nreads, int read_len);
+/* *occurrences = windows looked at, *admitted = windows inserted (either may be NULL) */
+int gk_map_count_reads_prefiltered(gk_map *m, gk_prefilter *pf, const uint8_t *bin_host, size_t nbytes, uint64_t nreads,
+                                   uint64_t *occurrences, uint64_t *admitted);
+int gk_map_count_reads_prefiltered_dev(gk_map *m, gk_prefilter *pf, const void *dev_records, uint64_t nreads, int read_len,
+                                       uint64_t *occurrences, uint64_t *admitted);
+/* counters in state "once" / "twice or more", buckets in total, windows fed to pass 1 (any may be NULL) */
+int gk_prefilter_stats(gk_prefilter *pf, uint64_t *buckets, uint64_t *seen_once, uint64_t *seen_twice_or_more, uint64_t *windows_added);
 
 /* ---- synthetic reads (bench / tests) ---------------------------------------- */
 /* Fill dev_records with nreads fixed-length `.bin` records generated on device, bit-identical to
