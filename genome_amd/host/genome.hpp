@@ -162,11 +162,23 @@ class DNAMap {
 namespace FreqFilter {
 // FreqFilter.extractFilteredKmers(data, k, rounds) (FreqFilter.scala:25-58); `takeFirst` is
 // genome.takeFirst (:40, :44)
+// prefilterDistinct > 0 (rounds >= 2 only): the exact two-pass singleton pre-filter sized for that many
+// distinct k-mers runs first (include/genome_amd.h); same result, k-mers seen once take no table slot
 inline DNAMap extractFilteredKmers(Context &ctx, const PairedEndData &data, int k, int rounds,
-                                   uint64_t takeFirst = UINT64_MAX, uint64_t capacityHint = 0) {
+                                   uint64_t takeFirst = UINT64_MAX, uint64_t capacityHint = 0, uint64_t prefilterDistinct = 0) {
     DNAMap kmersFreq(ctx, k, capacityHint);
     const uint64_t pairs = std::min<uint64_t>(data.count, takeFirst);
-    kmersFreq.countReads(data.bin.data(), data.bin.size(), 2 * pairs);
+    if (prefilterDistinct) {
+        if (rounds < 2) throw GkError(GK_E_INVALID, "the singleton pre-filter needs rounds >= 2");
+        gk_prefilter *pf = nullptr;
+        check(gk_prefilter_create(ctx.handle(), k, prefilterDistinct, &pf), ctx.handle());
+        int rc = gk_prefilter_add_reads(pf, data.bin.data(), data.bin.size(), 2 * pairs);
+        if (rc == GK_OK) rc = gk_map_count_reads_prefiltered(kmersFreq.handle(), pf, data.bin.data(), data.bin.size(), 2 * pairs, nullptr, nullptr);
+        gk_prefilter_destroy(pf);
+        check(rc, ctx.handle());
+    } else {
+        kmersFreq.countReads(data.bin.data(), data.bin.size(), 2 * pairs);
+    }
     kmersFreq.deleteAll(ValueLessThan{rounds});
     return kmersFreq;
 }

@@ -3,7 +3,7 @@
 // builds the de Bruijn graph, keeps the largest component, and writes the graph as text.
 // The reference logs its counters through akka Logging (:34-53); here they are one JSON object.
 //
-//   graph_builder <reads.bin> <pairs> <k> [--rounds 3] [--take-first N] [--no-retain] [--simplify] [--out prefix]
+//   graph_builder <reads.bin> <pairs> <k> [--rounds 3] [--take-first N] [--prefilter DISTINCT] [--no-retain] [--simplify] [--out prefix]
 //   --simplify runs removeBubbles + simplifyGraph (GraphSimplifier.scala:317-318) before writing;
 //   --out writes <prefix>.nodes.txt, .edges.txt, .contigs (GraphSimplifier.scala:338-347) and .dot (Graph.scala:74-88)
 //
@@ -19,7 +19,7 @@
 
 int main(int argc, char **argv) {
     if (argc < 4) {
-        std::fprintf(stderr, "usage: %s <reads.bin> <pairs> <k> [--rounds 3] [--take-first N] [--no-retain] [--simplify] [--out prefix]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <reads.bin> <pairs> <k> [--rounds 3] [--take-first N] [--prefilter DISTINCT] [--no-retain] [--simplify] [--out prefix]\n", argv[0]);
         return 2;
     }
     const std::string infile = argv[1];
@@ -28,11 +28,13 @@ int main(int argc, char **argv) {
     const int k = std::stoi(argv[3]);
     int rounds = 3;                               // GraphBuilder.scala:30
     uint64_t takeFirst = UINT64_MAX;              // genome.takeFirst
+    uint64_t prefilter = 0;                       // expected distinct k-mers; 0 = no singleton pre-filter
     bool retain = true, simplify = false;
     std::string out;
     for (int i = 4; i < argc; i++) {
         if (!std::strcmp(argv[i], "--rounds") && i + 1 < argc) rounds = std::stoi(argv[++i]);
         else if (!std::strcmp(argv[i], "--take-first") && i + 1 < argc) takeFirst = std::stoull(argv[++i]);
+        else if (!std::strcmp(argv[i], "--prefilter") && i + 1 < argc) prefilter = std::stoull(argv[++i]);
         else if (!std::strcmp(argv[i], "--no-retain")) retain = false;
         else if (!std::strcmp(argv[i], "--simplify")) simplify = true;
         else if (!std::strcmp(argv[i], "--out") && i + 1 < argc) out = argv[++i];
@@ -43,7 +45,7 @@ int main(int argc, char **argv) {
         if (!f) throw std::runtime_error("cannot open " + infile);
         data.bin.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
         genome::Context ctx(0);
-        auto kmersFreq = genome::FreqFilter::extractFilteredKmers(ctx, data, k, rounds, takeFirst);      // :32
+        auto kmersFreq = genome::FreqFilter::extractFilteredKmers(ctx, data, k, rounds, takeFirst, 0, prefilter);      // :32
         const uint64_t good = kmersFreq.size();                                                          // :34
         auto graph = genome::Graph::buildGraph(k, kmersFreq);                                            // :36
         auto [nodes, edges, totalLen] = graph.counts();                                                  // :39

@@ -48,6 +48,13 @@ def test_graph_builder_cli_matches_golden(exe, tmp_path, name):
     ids = {s: i + 1 for i, s in enumerate(fx["nodes"])}
     for line, (s, t, q) in zip(dot[1:-1], fx["edges"]):
         assert line == f"{ids[s]} -> {ids[t]} [label={q if len(q) <= 50 else len(q)}]"
+    # --prefilter (exact two-pass singleton pre-filter): same outputs whenever rounds >= 2
+    if fx["rounds"] >= 2:
+        res = subprocess.run([exe, str(binf), str(fx["nreads"] // 2), str(fx["k"]), "--rounds", str(fx["rounds"]), "--prefilter", "1000",
+                              "--no-retain", "--out", str(out) + "p"], capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
+        assert json.loads(res.stdout) == stats
+        assert [line.split() for line in open(str(out) + "p.edges.txt").read().splitlines()] == fx["edges"]
     # --simplify = removeBubbles + simplifyGraph before writing
     res = subprocess.run([exe, str(binf), str(fx["nreads"] // 2), str(fx["k"]), "--rounds", str(fx["rounds"]),
                           "--no-retain", "--simplify", "--out", str(out) + "s"], capture_output=True, text=True)
