@@ -1,6 +1,6 @@
 // gk_partition.hip — the partitioned form of FreqFilter.add / DNAMap.update(key, 1, _+1):
 // radix-partition a batch of canonical k-mers by table SEGMENT, then let one workgroup per segment
-// build its 64 KiB piece of the table in LDS and stream it back.
+// build its 32 KiB piece of the table in LDS and stream it back.
 //
 // Why: the direct path (k_count_reads / k_add_keys) costs one memory-side atomic per distinct key
 // and one 64-B sector per 8-B touch — 15.8 GB of HBM traffic for 2.9 GB of algorithmic bytes at C2
@@ -17,7 +17,8 @@
 //   P4 k_part_scatter2  L1 region chunks -> keys in segment order
 //   P5 k_seg_insert     one workgroup per segment: load the segment into LDS (or start from
 //                       EMPTY when the table is known to be empty), insert the segment's keys with
-//                       LDS atomics (same probe sequence as gk::table_add), store it back.
+//                       LDS atomics (same probe sequence as gk::table_add; an unbounded one-CAS-per-step
+//                       probe when the segment provably keeps a free slot), store it back.
 //
 // Two forms.  EXACT (ragged read streams): all five passes; the histograms size every region
 // exactly.  OVER-PROVISIONED (fixed-stride records, key arrays — the key count is known up front):
