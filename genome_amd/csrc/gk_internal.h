@@ -97,3 +97,26 @@ bool part_supported(const gk_map *m);
 void part_scratch_free(PartScratch *ps);
 
 }  // namespace gk
+
+// Optional in-kernel phase timers (-DGK_TIMERS; scripts/run_timers.py): thread 0 of every workgroup adds
+// the wall-clock ticks (s_memrealtime, 100 MHz) it spent in each phase.  A translation unit that uses
+// them says GK_TIMERS_DEFINE(suffix) once at file scope: its counters and the C entry point
+// gk_debug_timers_<suffix>(out[16], reset) that reads them back.
+#ifdef GK_TIMERS
+#define GK_TIMERS_DEFINE(suffix)                                                                                          \
+    static __device__ unsigned long long g_timers[16];                                                                   \
+    extern "C" int gk_debug_timers_##suffix(unsigned long long *out16, int reset) {                                      \
+        if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_timers), sizeof(unsigned long long) * 16) != hipSuccess) return -1;  \
+        unsigned long long z[16] = {0};                                                                                  \
+        if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_timers), z, sizeof(z)) != hipSuccess) return -1;                     \
+        return 0;                                                                                                        \
+    }
+#define GK_T0() unsigned long long t_prev = __builtin_amdgcn_s_memrealtime(), t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define GK_TICK(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); t_acc[i] += t_now - t_prev; t_prev = t_now; } while (0)
+#define GK_TFLUSH(base) do { if (threadIdx.x == 0) for (int q = 0; q < 8; q++) if (t_acc[q]) atomicAdd(&g_timers[(base) + q], t_acc[q]); } while (0)
+#else
+#define GK_TIMERS_DEFINE(suffix)
+#define GK_T0() do {} while (0)
+#define GK_TICK(i) do {} while (0)
+#define GK_TFLUSH(base) do {} while (0)
+#endif

@@ -46,6 +46,8 @@
 
 using namespace gk;
 
+GK_TIMERS_DEFINE(partition)
+
 static constexpr int PBLOCK = 512;          // threads of the key-streaming kernels
 static constexpr int KEYS_PER_THREAD = 8;
 static constexpr int PTILE_READS = 256;     // reads per LDS tile in P1/P2 (runs of ~120 keys per bucket)
@@ -307,19 +309,6 @@ __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_keys(const u64 *__rest
         scatter_chunk<W, 1>(keys, begin, cnt, t, 256u, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a, 0, out);
     }
 }
-
-// Optional in-kernel phase timers (-DGK_TIMERS; scripts/run_timers.py): thread 0 of every workgroup adds
-// the wall-clock ticks (s_memrealtime, 100 MHz) it spent in each phase; read back with gk_debug_timers.
-#ifdef GK_TIMERS
-__device__ unsigned long long g_timers[16];
-#define GK_T0() unsigned long long t_prev = __builtin_amdgcn_s_memrealtime(), t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define GK_TICK(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); t_acc[i] += t_now - t_prev; t_prev = t_now; } while (0)
-#define GK_TFLUSH(base) do { if (threadIdx.x == 0) for (int q = 0; q < 8; q++) if (t_acc[q]) atomicAdd(&g_timers[(base) + q], t_acc[q]); } while (0)
-#else
-#define GK_T0() do {} while (0)
-#define GK_TICK(i) do {} while (0)
-#define GK_TFLUSH(base) do {} while (0)
-#endif
 
 // P2 of the over-provisioned mode for fixed-stride records: ONE window-extraction pass.  The tile's
 // canonical keys and their L1 buckets are parked in LDS while the per-bucket counts are built, the
@@ -881,12 +870,5 @@ int part_count(gk_map *m, PartScratch **pps, const uint8_t *d_rec, u64 nreads, c
 
 bool part_supported(const gk_map *m) { return m->nb2 <= MAX_NB2; }
 
-#ifdef GK_TIMERS
-extern "C" int gk_debug_timers(unsigned long long *out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_timers), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_timers), z, sizeof(z)) != hipSuccess) return -1; }
-    return 0;
-}
-#endif
 
 }  // namespace gk

@@ -24,6 +24,8 @@
 
 using namespace gk;
 
+GK_TIMERS_DEFINE(skm)
+
 static constexpr int MAX_PARTS = 64;
 static constexpr int MAX_POS = 256;       // positions per read (len <= 255)
 
@@ -79,110 +81,128 @@ __device__ __forceinline__ void write_record(const u32 *tile, u32 bit, int nbase
 
 // One pass: owners -> runs -> records.  Per tile of 64 reads:
 //   phase 1  each wave takes reads round-robin; per read the m-mer scores of its positions go to the
-//            wave's LDS strip, each window lane takes the minimum over its k-m+1 positions -> owner
-//            byte in LDS; run starts are found with a ballot (owner differs from the previous
-//            lane's; lane 0 of every 64-window block starts a record too, so that everything stays
-//            wave-local), run lengths with bit scans of the ballot — no loops; records per owner
-//            are counted in an LDS histogram
+//            wave's LDS strip, each window lane takes the minimum over its k-m+1 positions -> owner;
+//            run starts are found with a ballot (owner differs from the previous lane's; lane 0 of
+//            every 64-window block starts a record too, so that everything stays wave-local), run
+//            lengths with bit scans of the ballot — no loops.  Every run start appends ONE 32-bit
+//            descriptor (read, first window, run length, owner) to an LDS list and counts its
+//            records in an LDS histogram per owner.
 //   reserve  one global atomic per (tile, owner) hands out a contiguous run of slots in the owner's
 //            region; a region that would overflow sets the overflow flag (the caller retries larger)
-//   phase 2  the same ballots, now on the owner bytes kept in LDS, and every run start lane writes
-//            its records: a 120-bit (or 248-bit) slice of the read, shifted behind a length byte,
-//            as one or two 16-B stores
+//   phase 2  one LANE per descriptor (not one per window): it takes its slots from the owner's LDS
+//            rank counter and writes its records: a 120-bit (or 248-bit) slice of the read, shifted
+//            behind a length byte, as one or two 16-B stores.  (Re-deriving the runs from per-window
+//            owner bytes with the same ballots left 1 lane in 10 busy during the record writes:
+//            42 % of the kernel's time by the in-kernel phase timers; this form: see DESIGN.md.)
+// The descriptor list holds DESC_CAP runs; a tile whose reads fragment into more than that (owners
+// alternating from window to window — not something hashed minimizers do on real reads) is redone in
+// groups of 16 reads, which always fit (16 x 254 windows).
+static constexpr int DESC_CAP = 4096;
 template <int SLOT>
 __global__ __launch_bounds__(BLOCK) void k_skm_route(const uint8_t *__restrict__ rec, u64 nreads, u32 stride, int k, int P,
                                                      u64 region_cap /* records per owner region */, unsigned long long *cursors,
                                                      unsigned long long *kmer_counts, u32 *overflow, uint8_t *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) u32 tile[TILE_WORDS];
     __shared__ u32 strips[(BLOCK / 64) * MAX_POS];
-    __shared__ uint8_t own[TILE_READS * MAX_POS];
-    __shared__ u32 hist[MAX_PARTS], h_kmer[MAX_PARTS];
+    __shared__ u32 desc[DESC_CAP];            // r (6 bits) | first window (8) << 6 | run length (8) << 14 | owner (6) << 22
+    __shared__ u32 hist[MAX_PARTS], t_kmer[MAX_PARTS], h_kmer[MAX_PARTS];
     __shared__ unsigned long long base[MAX_PARTS];
+    __shared__ u32 s_ndesc, s_over;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = k < 11 ? k : 11, w = k - m + 1, rmax = skm_max_run(k);
     if (threadIdx.x < MAX_PARTS) h_kmer[threadIdx.x] = 0;
     const u64 ntiles = (nreads + TILE_READS - 1) / TILE_READS;
+    GK_T0();
     for (u64 tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const u64 r0 = tl * TILE_READS;
         const int nr = (int)min((u64)TILE_READS, nreads - r0);
         __syncthreads();
-        if (threadIdx.x < MAX_PARTS) hist[threadIdx.x] = 0;
+        GK_TICK(4);
         const u64 a0 = stage_tile(tile, rec, r0 * stride, (r0 + nr) * stride);
-        __syncthreads();
         const uint8_t *tb = reinterpret_cast<const uint8_t *>(tile);
         u32 *strip = strips + wave * MAX_POS;
-        // ---- phase 1
-        for (int r = wave; r < nr; r += BLOCK / 64) {
-            const u32 ro = (u32)((r0 + r) * stride - a0);
-            const int len = tb[ro], nk = len - k + 1, nm = len - m + 1;
-            const u32 bit0 = (ro + 1) * 8;
-            uint8_t *o_r = own + r * MAX_POS;
-            __builtin_amdgcn_wave_barrier();
-            for (int q = lane; q < nm; q += 64) strip[q] = mmer_score(tile, bit0 + 2 * q, m);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (int pb = 0; pb < nk; pb += 64) {
-                const int p = pb + lane;
-                const bool valid = p < nk;
-                u32 best = 0xffffffffu;
-                if (valid) {
-                    best = strip[p];
-                    for (int j = 1; j < w; j++) best = min(best, strip[p + j]);
-                }
-                const int o = (int)(((u64)hash32(best ^ 0x5bd1e995u) * (u64)P) >> 32);      // == gk::owner_of
-                if (valid) o_r[p] = (uint8_t)o;
-                const int prev = __shfl_up(o, 1);
-                const bool start = valid && (lane == 0 || o != prev);
-                const unsigned long long S = __ballot(start), V = __ballot(valid);
-                if (start) {
-                    const unsigned long long nxt = lane == 63 ? 0ull : (S >> (lane + 1));
-                    const int rl = nxt ? __ffsll((long long)nxt) : (__popcll(V) - lane);
-                    atomicAdd(&hist[o], (u32)((rl + rmax - 1) / rmax));
-                    atomicAdd(&h_kmer[o], (u32)rl);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        }
-        __syncthreads();
-        // ---- reserve
-        if (threadIdx.x < P) {
-            const u32 c = hist[threadIdx.x];
-            unsigned long long b = ~0ull;
-            if (c) {
-                const unsigned long long at = atomicAdd(&cursors[threadIdx.x], (unsigned long long)c);
-                if (at + c <= region_cap) b = (unsigned long long)threadIdx.x * region_cap + at;
-                else *overflow = 1;
-            }
-            base[threadIdx.x] = b;
-            hist[threadIdx.x] = 0;      // becomes the rank counter
-        }
-        __syncthreads();
-        // ---- phase 2
-        for (int r = wave; r < nr; r += BLOCK / 64) {
-            const u32 ro = (u32)((r0 + r) * stride - a0);
-            const int nk = (int)tb[ro] - k + 1;
-            const uint8_t *o_r = own + r * MAX_POS;
-            for (int pb = 0; pb < nk; pb += 64) {
-                const int p = pb + lane;
-                const bool valid = p < nk;
-                const int o = valid ? o_r[p] : 0xff;
-                const int prev = __shfl_up(o, 1);
-                const bool start = valid && (lane == 0 || o != prev);
-                const unsigned long long S = __ballot(start), V = __ballot(valid);
-                if (start && base[o] != ~0ull) {
-                    const unsigned long long nxt = lane == 63 ? 0ull : (S >> (lane + 1));
-                    const int rl = nxt ? __ffsll((long long)nxt) : (__popcll(V) - lane);
-                    const int nrec = (rl + rmax - 1) / rmax;
-                    const u64 slot0 = base[o] + atomicAdd(&hist[o], (u32)nrec);
-                    for (int c = 0; c < nrec; c++) {
-                        const int ps = p + c * rmax;
-                        const int wl = min(rmax, rl - c * rmax);
-                        write_record<SLOT>(tile, (ro + 1) * 8 + 2 * ps, wl + k - 1, out + (slot0 + c) * SLOT);
+        int gsz = TILE_READS, g0 = 0;
+        while (g0 < nr) {
+            const int g1 = min(g0 + gsz, nr);
+            __syncthreads();                  // tile staged / previous group's descriptors consumed
+            if (threadIdx.x < MAX_PARTS) { hist[threadIdx.x] = 0; t_kmer[threadIdx.x] = 0; }
+            if (threadIdx.x == 0) { s_ndesc = 0; s_over = 0; }
+            __syncthreads();
+            GK_TICK(0);
+            // ---- phase 1
+            for (int r = g0 + wave; r < g1; r += BLOCK / 64) {
+                const u32 ro = (u32)((r0 + r) * stride - a0);
+                const int len = tb[ro], nk = len - k + 1, nm = len - m + 1;
+                const u32 bit0 = (ro + 1) * 8;
+                __builtin_amdgcn_wave_barrier();
+                for (int q = lane; q < nm; q += 64) strip[q] = mmer_score(tile, bit0 + 2 * q, m);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int pb = 0; pb < nk; pb += 64) {
+                    const int p = pb + lane;
+                    const bool valid = p < nk;
+                    u32 best = 0xffffffffu;
+                    if (valid) {
+                        best = strip[p];
+                        for (int j = 1; j < w; j++) best = min(best, strip[p + j]);
+                    }
+                    const int o = (int)(((u64)hash32(best ^ 0x5bd1e995u) * (u64)P) >> 32);      // == gk::owner_of
+                    const int prev = __shfl_up(o, 1);
+                    const bool start = valid && (lane == 0 || o != prev);
+                    const unsigned long long S = __ballot(start), V = __ballot(valid);
+                    u32 at = 0;
+                    if (lane == 0 && S) at = atomicAdd(&s_ndesc, (u32)__popcll(S));
+                    at = __shfl(at, 0);
+                    if (start) {
+                        const unsigned long long nxt = lane == 63 ? 0ull : (S >> (lane + 1));
+                        const int rl = nxt ? __ffsll((long long)nxt) : (__popcll(V) - lane);
+                        const u32 idx = at + (u32)__popcll(S & ((1ull << lane) - 1ull));
+                        if (idx < (u32)DESC_CAP) desc[idx] = (u32)(r - g0) | ((u32)p << 6) | ((u32)rl << 14) | ((u32)o << 22);
+                        else s_over = 1;
+                        atomicAdd(&hist[o], (u32)((rl + rmax - 1) / rmax));
+                        atomicAdd(&t_kmer[o], (u32)rl);
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
+            GK_TICK(1);
+            __syncthreads();
+            if (s_over) { gsz = 16; continue; }       // uniform: redo this group in pieces that always fit
+            // ---- reserve
+            if (threadIdx.x < P) {
+                const u32 c = hist[threadIdx.x];
+                unsigned long long b = ~0ull;
+                if (c) {
+                    const unsigned long long at = atomicAdd(&cursors[threadIdx.x], (unsigned long long)c);
+                    if (at + c <= region_cap) b = (unsigned long long)threadIdx.x * region_cap + at;
+                    else *overflow = 1;
+                }
+                base[threadIdx.x] = b;
+                hist[threadIdx.x] = 0;      // becomes the rank counter
+                h_kmer[threadIdx.x] += t_kmer[threadIdx.x];
+            }
+            __syncthreads();
+            GK_TICK(2);
+            // ---- phase 2
+            const u32 ndesc = s_ndesc;
+            for (u32 i = threadIdx.x; i < ndesc; i += BLOCK) {
+                const u32 dsc = desc[i];
+                const int r = g0 + (int)(dsc & 63u), p = (int)((dsc >> 6) & 255u), rl = (int)((dsc >> 14) & 255u), o = (int)(dsc >> 22);
+                if (base[o] == ~0ull) continue;
+                const u32 ro = (u32)((r0 + r) * stride - a0);
+                const int nrec = (rl + rmax - 1) / rmax;
+                const u64 slot0 = base[o] + atomicAdd(&hist[o], (u32)nrec);
+                for (int c = 0; c < nrec; c++) {
+                    const int ps = p + c * rmax;
+                    const int wl = min(rmax, rl - c * rmax);
+                    write_record<SLOT>(tile, (ro + 1) * 8 + 2 * ps, wl + k - 1, out + (slot0 + c) * SLOT);
+                }
+            }
+            GK_TICK(3);
+            g0 = g1;
         }
     }
+    GK_TFLUSH(0);
     __syncthreads();
     if (threadIdx.x < P && h_kmer[threadIdx.x]) atomicAdd(&kmer_counts[threadIdx.x], (unsigned long long)h_kmer[threadIdx.x]);
 }

@@ -311,7 +311,8 @@ def test_partitioned_path_heavy_hitters_and_tiny_batches(ctx):
     m.close()
 
 
-@pytest.mark.parametrize("k,L_,P", [(31, 150, 8), (21, 100, 3), (11, 60, 2), (55, 150, 8), (63, 200, 4), (34, 255, 5), (64, 150, 8)])
+@pytest.mark.parametrize("k,L_,P", [(31, 150, 8), (21, 100, 3), (11, 60, 2), (55, 150, 8), (63, 200, 4), (34, 255, 5), (64, 150, 8),
+                                    (7, 255, 16)])     # k < m: a run per window, the descriptor list overflows and the tile is regrouped
 def test_superkmer_records(ctx, k, L_, P):
     """gk_shard_superkmers_dev: every record is a run of same-owner windows of one read, in the `.bin`
     framing; together the records hold every window exactly once (multiset of canonical k-mers ==
