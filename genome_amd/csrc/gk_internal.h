@@ -112,11 +112,15 @@ void part_scratch_free(PartScratch *ps);
         return 0;                                                                                                        \
     }
 #define GK_T0() unsigned long long t_prev = __builtin_amdgcn_s_memrealtime(), t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define GK_TARGS_DECL unsigned long long &t_prev, unsigned long long (&t_acc)[8]      /* pass the timers into a helper */
+#define GK_TARGS t_prev, t_acc
 #define GK_TICK(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memrealtime(); t_acc[i] += t_now - t_prev; t_prev = t_now; } while (0)
 #define GK_TFLUSH(base) do { if (threadIdx.x == 0) for (int q = 0; q < 8; q++) if (t_acc[q]) atomicAdd(&g_timers[(base) + q], t_acc[q]); } while (0)
 #else
 #define GK_TIMERS_DEFINE(suffix)
 #define GK_T0() do {} while (0)
+#define GK_TARGS_DECL int
+#define GK_TARGS 0
 #define GK_TICK(i) do {} while (0)
 #define GK_TFLUSH(base) do {} while (0)
 #endif

@@ -224,11 +224,12 @@ __global__ __launch_bounds__(BLOCK) void k_part_hist1_keys(const u64 *__restrict
 template <int W, int LEVEL>
 __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u64 begin, u32 cnt, const Table<W> &t, u32 nbins,
                                               u64 *sorted, uint16_t *binof, u32 *off, u32 *lim, unsigned long long *gb, u32 *wsum,
-                                              const PartArrays &a, u64 bin0, u64 *__restrict__ out) {
+                                              const PartArrays &a, u64 bin0, u64 *__restrict__ out, GK_TARGS_DECL) {
     Kmer<W> key[KEYS_PER_THREAD];
     u32 bin[KEYS_PER_THREAD], rank[KEYS_PER_THREAD];
     for (u32 b = threadIdx.x; b < nbins; b += PBLOCK) off[b] = 0;
     __syncthreads();
+    GK_TICK(0);
     // all loads first, unconditionally (index clamped): one memory round trip per chunk instead of
     // one per key — a load inside `if (i < cnt)` is sunk next to its use and serialises
 #pragma unroll
@@ -246,7 +247,9 @@ __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u64 be
             rank[j] = atomicAdd(&off[bin[j]], 1u);             // rank inside its bin
         }
     }
+    GK_TICK(1);
     __syncthreads();
+    GK_TICK(2);
     for (u32 b = threadIdx.x; b < nbins; b += PBLOCK) {        // reserve the bin's run in the output
         const u32 c = off[b];
         u32 fit = c;
@@ -264,7 +267,9 @@ __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u64 be
         lim[b] = fit;
     }
     __syncthreads();
+    GK_TICK(3);
     block_scan_inplace(off, nbins, wsum);                      // counts -> offsets in the sorted chunk
+    GK_TICK(4);
 #pragma unroll
     for (int j = 0; j < KEYS_PER_THREAD; j++)
         if (bin[j] != 0xffffffffu) {
@@ -273,6 +278,7 @@ __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u64 be
             binof[pos] = (uint16_t)bin[j];
         }
     __syncthreads();
+    GK_TICK(5);
     for (u32 i = threadIdx.x; i < cnt; i += PBLOCK) {          // linear, coalesced write-out
         const u32 b = binof[i], j = i - off[b];
         const Kmer<W> x = load_key<W>(sorted, i);
@@ -280,7 +286,9 @@ __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u64 be
         else if constexpr (W == 1) spill_key<1>(a, x.lo, 0);
         else spill_key<2>(a, x.lo, x.hi);
     }
+    GK_TICK(6);
     __syncthreads();
+    GK_TICK(7);
 }
 
 // dynamic LDS carve for scatter_chunk
@@ -303,10 +311,11 @@ __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_keys(const u64 *__rest
     extern __shared__ unsigned long long lds_dyn1[];
     ScatterLds<W> L(lds_dyn1, 256u);
     const u64 nchunks = (n + TILE2 - 1) / TILE2;
+    GK_T0();
     for (u64 c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const u64 begin = c * TILE2;
         const u32 cnt = (u32)min((u64)TILE2, n - begin);
-        scatter_chunk<W, 1>(keys, begin, cnt, t, 256u, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a, 0, out);
+        scatter_chunk<W, 1>(keys, begin, cnt, t, 256u, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a, 0, out, GK_TARGS);
     }
 }
 
@@ -475,15 +484,26 @@ __global__ __launch_bounds__(PBLOCK) void k_part_scatter2(const u64 *__restrict_
                                                           u64 *__restrict__ bufB) {
     extern __shared__ unsigned long long lds_dyn[];
     ScatterLds<W> L(lds_dyn, t.nb2);
-    const u64 total_chunks = a.cbase[256];
-    for (u64 c = blockIdx.x; c < total_chunks && c < max_chunks; c += gridDim.x) {
-        const u32 b1 = chunk_bucket(a.cbase, c);
-        const u64 bsize = l1_count(a, b1);
-        const u64 begin = (c - a.cbase[b1]) * TILE2;
-        const u32 cnt = (u32)min((u64)TILE2, bsize - begin);
-        scatter_chunk<W, 2>(bufA, l1_begin(a, b1) + begin, cnt, t, t.nb2, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a,
-                            (u64)b1 * t.nb2, bufB);
+    // chunk table and L1 bucket extents: LDS copies (the binary search below was eight dependent global
+    // loads per chunk: 16 % of the kernel by the phase timers)
+    __shared__ unsigned long long s_cbase[257], s_l1n[256], s_l1b[256];
+    for (u32 b = threadIdx.x; b < 257u; b += PBLOCK) s_cbase[b] = a.cbase[b];
+    for (u32 b = threadIdx.x; b < 256u; b += PBLOCK) {
+        const bool live = b < (1u << t.lnb1);
+        s_l1n[b] = live ? l1_count(a, b) : 0ull;
+        s_l1b[b] = live ? l1_begin(a, b) : 0ull;
     }
+    __syncthreads();
+    const u64 total_chunks = s_cbase[256];
+    GK_T0();
+    for (u64 c = blockIdx.x; c < total_chunks && c < max_chunks; c += gridDim.x) {
+        const u32 b1 = chunk_bucket(s_cbase, c);
+        const u64 begin = (c - s_cbase[b1]) * TILE2;
+        const u32 cnt = (u32)min((u64)TILE2, s_l1n[b1] - begin);
+        scatter_chunk<W, 2>(bufA, s_l1b[b1] + begin, cnt, t, t.nb2, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a,
+                            (u64)b1 * t.nb2, bufB, GK_TARGS);
+    }
+    GK_TFLUSH(8);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(BLOCK) void k_skm_route(const uint8_t *__restrict__
                                                      u64 region_cap /* records per owner region */, unsigned long long *cursors,
                                                      unsigned long long *kmer_counts, u32 *overflow, uint8_t *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) u32 tile[TILE_WORDS];
-    __shared__ u32 strips[(BLOCK / 64) * MAX_POS];
+    __shared__ u32 strips[(BLOCK / 64) * MAX_POS], strips2[(BLOCK / 64) * MAX_POS];
     __shared__ u32 desc[DESC_CAP];            // r (6 bits) | first window (8) << 6 | run length (8) << 14 | owner (6) << 22
     __shared__ u32 hist[MAX_PARTS], t_kmer[MAX_PARTS], h_kmer[MAX_PARTS];
     __shared__ unsigned long long base[MAX_PARTS];
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(BLOCK) void k_skm_route(const uint8_t *__restrict__
         GK_TICK(4);
         const u64 a0 = stage_tile(tile, rec, r0 * stride, (r0 + nr) * stride);
         const uint8_t *tb = reinterpret_cast<const uint8_t *>(tile);
-        u32 *strip = strips + wave * MAX_POS;
+        u32 *strip = strips + wave * MAX_POS, *strip2 = strips2 + wave * MAX_POS;
         int gsz = TILE_READS, g0 = 0;
         while (g0 < nr) {
             const int g1 = min(g0 + gsz, nr);
@@ -135,16 +135,37 @@ __global__ __launch_bounds__(BLOCK) void k_skm_route(const uint8_t *__restrict__
                 const int len = tb[ro], nk = len - k + 1, nm = len - m + 1;
                 const u32 bit0 = (ro + 1) * 8;
                 __builtin_amdgcn_wave_barrier();
+                GK_TICK(1);
                 for (int q = lane; q < nm; q += 64) strip[q] = mmer_score(tile, bit0 + 2 * q, m);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                GK_TICK(5);
+                // window minimum over w = k-m+1 scores.  A plain loop is w dependent LDS round trips per
+                // block (the reads are not batched: 90 % of the kernel by the phase timers); instead the
+                // minimum of every 8 consecutive scores is parked once per position, and a window takes the
+                // min of at most 7 of those (clamped offsets repeat harmlessly), all reads issued together.
+                const u32 *mins = strip;
+                if (w >= 8) {
+                    u32 *m8 = strip2;
+                    for (int q = lane; q < nm - 7; q += 64) {
+                        u32 v = strip[q];
+#pragma unroll
+                        for (int j = 1; j < 8; j++) v = min(v, strip[q + j]);
+                        m8[q] = v;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    mins = m8;
+                }
+                GK_TICK(6);
+                const int step = w >= 8 ? 8 : 1, last = w >= 8 ? w - 8 : w - 1;
                 for (int pb = 0; pb < nk; pb += 64) {
                     const int p = pb + lane;
                     const bool valid = p < nk;
                     u32 best = 0xffffffffu;
                     if (valid) {
-                        best = strip[p];
-                        for (int j = 1; j < w; j++) best = min(best, strip[p + j]);
+#pragma unroll
+                        for (int j = 0; j < 7; j++) best = min(best, mins[p + min(j * step, last)]);
                     }
                     const int o = (int)(((u64)hash32(best ^ 0x5bd1e995u) * (u64)P) >> 32);      // == gk::owner_of
                     const int prev = __shfl_up(o, 1);

@@ -14,10 +14,10 @@ lib = _lib.lib()
 buf = (C.c_ulonglong * 16)()
 
 
-def report(fn, names):
+def report(fn, names, base=0, reset=1):
     fn.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
-    fn(buf, 1)
-    t = [buf[i] / steps for i in range(8)]
+    fn(buf, reset)
+    t = [buf[base + i] / steps for i in range(8)]
     tot = sum(t) or 1
     for i, nm in enumerate(names):
         print(f"  {nm:28s} {100 * t[i] / tot:5.1f} %   ({t[i] / 100:.0f} us summed over workgroups per step)")
@@ -30,7 +30,9 @@ lib.gk_debug_timers_partition(buf, 1)
 for it in range(steps):
     m.clear(); m.count_reads_dev(d, n, L)
 print("P2 k_op_scatter1_reads; phase_ms", [round(x, 3) for x in m.last_phase_ms()])
-report(lib.gk_debug_timers_partition, ["zero+stage+barrier", "extract (wave 0)", "barrier after extract", "reserve+barrier", "write-out (wave 0)", "loop-top barrier"])
+report(lib.gk_debug_timers_partition, ["zero+stage+barrier", "extract (wave 0)", "barrier after extract", "reserve+barrier", "write-out (wave 0)", "loop-top barrier"], 0, 0)
+print("P4 k_part_scatter2")
+report(lib.gk_debug_timers_partition, ["locate+zero bins+barrier", "load keys + LDS ranks", "barrier", "reserve atomics + barrier", "scan", "place + barrier", "write-out (wave 0)", "final barrier"], 8, 1)
 
 P = 8
 cap = n * 24 // P * P
@@ -41,4 +43,4 @@ lib.gk_debug_timers_skm(buf, 1)
 for it in range(steps):
     ctx.shard_superkmers(k, d, n, L, P, out, cap)
 print("k_skm_route<16>, P=8")
-report(lib.gk_debug_timers_skm, ["stage+barrier", "phase 1 (scores, min, runs)", "barrier+reserve", "phase 2 (records)", "loop-top barrier"])
+report(lib.gk_debug_timers_skm, ["stage+barrier", "ph.1 window min + runs", "barrier+reserve", "phase 2 (records)", "loop-top barrier", "ph.1 m-mer scores", "ph.1 min of 8 per position"])
