@@ -217,7 +217,7 @@ def main():
         avg_kernel_ms = kernel_time_ms
         achieved = abytes / (avg_kernel_ms * 1e-3) / 1e9
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_pipeline_v7.json" if partitioned else "pmc_count_reads_v2.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_pipeline_v8.json" if partitioned else "pmc_count_reads_v2.json")
         if not sharded and args.mode == "U" and n == 1_000_000 and L == 150 and k == 31 and os.path.exists(pmc_file):
             pj = json.load(open(pmc_file))
             traffic = pj.get("hbm_bytes_per_launch", pj.get("k_count_reads<1>", {}).get("hbm_bytes_per_launch"))
