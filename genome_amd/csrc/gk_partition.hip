@@ -830,22 +830,30 @@ static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads
     hipLaunchKernelGGL(k_part_scatter2<W>, dim3(gchunks), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2), ctx->stream, ps->bufA, t, a, max_chunks, ps->bufB);
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipEventRecord(ctx->pev[4], ctx->stream));
+    // Did the spill list overflow (extreme skew)?  Then the batch has to take the direct path.  A table
+    // that holds data must not be touched before that is known (host round trip here); a table that is
+    // being rebuilt from empty can simply be cleared again, so P5 goes out first and the flag is read
+    // with everything else after it — one host round trip less per batch on the common path.
     unsigned long long nspill = 0;
-    if (op) {   // the table is still untouched: if even the spill list overflowed, hand the batch back
-        u32 ovf = 0;
+    u32 ovf = 0;
+    auto abandon = [&](bool table_touched) -> int {
+        unsigned long long occ = 0;
+        if (d_rec) {   // P2 already counted this batch's windows
+            GK_HIP(ctx, hipMemcpy(&occ, &m->d_ctr->occurrences, 8, hipMemcpyDeviceToHost));
+            occ -= std::min<unsigned long long>(occ, nkeys_bound);
+            GK_HIP(ctx, hipMemcpy(&m->d_ctr->occurrences, &occ, 8, hipMemcpyHostToDevice));
+        }
+        if (table_touched) GK_HIP(ctx, hipMemset(&m->d_ctr->size, 0, 8));     // from empty: whatever P5 claimed is void
+        m->retries_direct++;
+        return PART_RETRY_DIRECT;
+    };
+    if (op && !from_empty) {
         GK_HIP(ctx, hipMemcpyAsync(&nspill, a.nspill, 8, hipMemcpyDeviceToHost, ctx->stream));
         GK_HIP(ctx, hipMemcpyAsync(&ovf, a.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
         GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ovf) {
-            if (d_rec) {   // P2 already counted this batch's windows
-                unsigned long long occ = 0;
-                GK_HIP(ctx, hipMemcpy(&occ, &m->d_ctr->occurrences, 8, hipMemcpyDeviceToHost));
-                occ -= std::min<unsigned long long>(occ, nkeys_bound);
-                GK_HIP(ctx, hipMemcpy(&m->d_ctr->occurrences, &occ, 8, hipMemcpyHostToDevice));
-            }
             GK_HIP(ctx, hipEventRecord(ctx->pev[5], ctx->stream));
-            m->retries_direct++;
-            return PART_RETRY_DIRECT;
+            return abandon(false);
         }
     }
     // P5
@@ -853,10 +861,15 @@ static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads
     hipLaunchKernelGGL(k_seg_insert<W>, dim3(gseg), dim3(SBLOCK), lds, ctx->stream, t, fine_keys, a, from_empty ? 1 : 0, m->d_ctr);
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipEventRecord(ctx->pev[5], ctx->stream));
+    if (op && from_empty) {
+        GK_HIP(ctx, hipMemcpyAsync(&nspill, a.nspill, 8, hipMemcpyDeviceToHost, ctx->stream));
+        GK_HIP(ctx, hipMemcpyAsync(&ovf, a.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
     // failures (a segment filled up): grow, then replay those buckets through the direct path
     u32 n_failed = 0;
     GK_HIP(ctx, hipMemcpyAsync(&n_failed, a.n_failed, 4, hipMemcpyDeviceToHost, ctx->stream));
     if (int rc = map_sync_counters(m)) return rc;
+    if (ovf) return abandon(true);            // (only reachable from empty: see above)
     m->failed_segments += n_failed;
     m->spilled_keys += nspill;
     if (n_failed) {

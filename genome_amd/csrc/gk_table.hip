@@ -434,8 +434,7 @@ int gk_map_clear(gk_map *m) {
     gk_ctx *ctx = m->ctx;
     // Deferred: the next partitioned insert rebuilds every segment from EMPTY without reading it;
     // anything else materialises the clear first (map_materialize).
-    GK_HIP(ctx, hipMemsetAsync(m->d_ctr, 0, sizeof(Counters), ctx->stream));
-    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GK_HIP(ctx, hipMemsetAsync(m->d_ctr, 0, sizeof(Counters), ctx->stream));     // stream-ordered: no host round trip needed
     m->pending_clear = true;
     m->size = 0;
     m->tombstones = 0;
@@ -513,8 +512,9 @@ static int launch_partitioned(gk_map *m, const uint8_t *d_rec, u64 nreads, const
     m->pending_clear = false;
     const int prc = part_count(m, &m->part, d_rec, nreads, d_off, stride, group, d_keys, nkeys_in, bound, from_empty);
     if (prc < 0) return prc;
-    if (prc == PART_RETRY_DIRECT) {        // extreme skew: nothing but scratch was touched
+    if (prc == PART_RETRY_DIRECT) {        // extreme skew: nothing but scratch (or a table that was being rebuilt from empty) was touched
         m->pending_clear = from_empty;
+        if (from_empty) m->size = 0;
         if (int rc = map_materialize(m)) return rc;
         if (int rc = map_reserve(m, bound)) return rc;
         if (d_rec) return launch_count(m, d_rec, nreads, d_off, stride, group);
