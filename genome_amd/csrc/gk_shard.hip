@@ -35,7 +35,7 @@ __global__ __launch_bounds__(BLOCK) void k_shard_count(const uint8_t *__restrict
         });
     }
     __syncthreads();
-    if (threadIdx.x < P && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+    if (threadIdx.x < (u32)P && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
 }
 
 // pass 2: write each canonical k-mer into its owner's region.  Per tile: histogram in LDS, one
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(BLOCK) void k_shard_scatter(const uint8_t *__restri
         __syncthreads();
         for_each_window<W>(tile, a0, r0, nr, nullptr, stride, k, 64, [&](Kmer<W> x) { atomicAdd(&hist[owner_of(x, k, P)], 1u); });
         __syncthreads();
-        if (threadIdx.x < P && hist[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursors[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+        if (threadIdx.x < (u32)P && hist[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursors[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
         __syncthreads();
         for_each_window<W>(tile, a0, r0, nr, nullptr, stride, k, 64, [&](Kmer<W> x) {
             Kmer<W> y = canonical(x, k);                 // FreqFilter.scala:31-32, done by the sender

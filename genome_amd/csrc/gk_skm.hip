@@ -190,7 +190,7 @@ __global__ __launch_bounds__(BLOCK) void k_skm_route(const uint8_t *__restrict__
             __syncthreads();
             if (s_over) { gsz = 16; continue; }       // uniform: redo this group in pieces that always fit
             // ---- reserve
-            if (threadIdx.x < P) {
+            if (threadIdx.x < (u32)P) {
                 const u32 c = hist[threadIdx.x];
                 unsigned long long b = ~0ull;
                 if (c) {
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(BLOCK) void k_skm_route(const uint8_t *__restrict__
     }
     GK_TFLUSH(0);
     __syncthreads();
-    if (threadIdx.x < P && h_kmer[threadIdx.x]) atomicAdd(&kmer_counts[threadIdx.x], (unsigned long long)h_kmer[threadIdx.x]);
+    if (threadIdx.x < (u32)P && h_kmer[threadIdx.x]) atomicAdd(&kmer_counts[threadIdx.x], (unsigned long long)h_kmer[threadIdx.x]);
 }
 
 extern "C" {
