@@ -1,6 +1,7 @@
 """Property-based GPU-vs-oracle check (-m gpu): random k over every supported width, ragged random reads with
 errors, one or several batches, any insert path, optional singleton pre-filter, random filter threshold; the table
 (sorted content) and the graph after build / removeBubbles / simplifyGraph must equal the C oracle's bit for bit."""
+import os
 import random
 
 import numpy as np
@@ -55,7 +56,7 @@ def _oracle_graph(og, k):
     return nodes, edges
 
 
-@settings(max_examples=150, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@settings(max_examples=int(os.environ.get("GK_FUZZ_EXAMPLES", "150")), deadline=None, derandomize="GK_FUZZ_EXAMPLES" not in os.environ, suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
 @given(seed=st.integers(0, 10**6), k=st.sampled_from([2, 4, 9, 15, 21, 27, 31, 34, 35, 48, 62, 63, 64]),
        path=st.sampled_from(["auto", "direct", "partitioned"]), batches=st.integers(1, 3), rounds=st.integers(1, 4),
        err=st.sampled_from([0.0, 0.01, 0.04]), haplotypes=st.integers(0, 2), prefilter=st.booleans(), hint=st.sampled_from([0, 64, 20000]))
