@@ -46,8 +46,7 @@ template <int W> __device__ __forceinline__ u64 pf_bucket(Kmer<W> y, u64 nbucket
     return __umul64hi(h, nbuckets);
 }
 
-static constexpr int PF_SEL_READS = 16;       // reads per tile in pass 2 (their keys are parked in LDS)
-static constexpr int PF_SEL_KEYS = PF_SEL_READS * 255;
+static constexpr int PF_PARK_BYTES = 64 << 10;   // pass 2 parks a tile's admitted keys in LDS: reads per tile = what fits, at most 64
 
 // pass 1: counter 0 -> 1 -> 3 (bit 0 = seen, bit 1 = seen again).  The plain load is only a hint
 // (bits are only ever set): it saves the atomics of the common "already saturated" case.
@@ -91,18 +90,18 @@ __global__ __launch_bounds__(BLOCK) void k_pf_add(const uint8_t *__restrict__ re
 // writes them.
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_pf_select(const uint8_t *__restrict__ rec, u64 nreads, const u32 *__restrict__ offsets, u32 stride,
-                                                     int k, const u32 *__restrict__ words, u64 nbuckets, u64 *__restrict__ out, u64 out_cap,
+                                                     int k, int rs /* reads per tile */, const u32 *__restrict__ words, u64 nbuckets, u64 *__restrict__ out, u64 out_cap,
                                                      unsigned long long *cursor /* [0] admitted, [1] windows */, u32 *overflow) {
     __shared__ __attribute__((aligned(16))) u32 tile[TILE_WORDS];
-    extern __shared__ u64 park[];                 // [PF_SEL_KEYS * W]
+    extern __shared__ u64 park[];                 // [rs * max windows per read * W]
     __shared__ u32 s_n, s_occ;
     __shared__ unsigned long long s_base;
     if (threadIdx.x == 0) s_occ = 0;
     u32 occ = 0;
-    const u64 ntiles = (nreads + PF_SEL_READS - 1) / PF_SEL_READS;
+    const u64 ntiles = (nreads + rs - 1) / rs;
     for (u64 tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
-        const u64 r0 = tl * PF_SEL_READS;
-        const int nr = (int)min((u64)PF_SEL_READS, nreads - r0);
+        const u64 r0 = tl * rs;
+        const int nr = (int)min((u64)rs, nreads - r0);
         const u64 gb = offsets ? (u64)offsets[r0] : r0 * stride;
         const u64 ge = offsets ? (u64)offsets[r0 + nr] : (r0 + nr) * stride;
         __syncthreads();
@@ -167,7 +166,7 @@ int pf_launch_add(gk_prefilter *pf, const uint8_t *d_rec, u64 nreads, const u32 
 
 // pass 2 for one chunk of records whose windows fit the key buffer; feeds the admitted keys to the table
 int pf_select_and_insert(gk_prefilter *pf, gk_map *m, const uint8_t *d_rec, u64 nreads, const u32 *d_off, u32 stride, u64 max_windows,
-                         u64 *admitted_total) {
+                         u64 max_windows_per_read, u64 *admitted_total) {
     gk_ctx *ctx = pf->ctx;
     if (pf->keybuf_keys < max_windows) {
         if (pf->keybuf) GK_HIP(ctx, hipFree(pf->keybuf));
@@ -178,14 +177,16 @@ int pf_select_and_insert(gk_prefilter *pf, gk_map *m, const uint8_t *d_rec, u64 
     GK_HIP(ctx, hipMemsetAsync(pf->d_cursor, 0, 8, ctx->stream));                     // admitted
     u32 *d_ovf = reinterpret_cast<u32 *>(pf->d_cursor + 2);
     GK_HIP(ctx, hipMemsetAsync(d_ovf, 0, 4, ctx->stream));
-    const u64 ntiles = (nreads + PF_SEL_READS - 1) / PF_SEL_READS;
+    const u64 per_read = std::max<u64>(1, max_windows_per_read);
+    const int rs = (int)std::max<u64>(1, std::min<u64>(TILE_READS, (u64)PF_PARK_BYTES / (8ull * pf->W) / per_read));
+    const u64 ntiles = (nreads + rs - 1) / rs;
     const int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)ctx->cu_count * 8);
-    const size_t lds = (size_t)PF_SEL_KEYS * 8 * pf->W;
+    const size_t lds = (size_t)rs * per_read * 8 * pf->W;
     if (pf->W == 1)
-        hipLaunchKernelGGL(k_pf_select<1>, dim3(grid), dim3(BLOCK), lds, ctx->stream, d_rec, nreads, d_off, stride, pf->k, pf->words, pf->nbuckets,
+        hipLaunchKernelGGL(k_pf_select<1>, dim3(grid), dim3(BLOCK), lds, ctx->stream, d_rec, nreads, d_off, stride, pf->k, rs, pf->words, pf->nbuckets,
                            pf->keybuf, pf->keybuf_keys, pf->d_cursor, d_ovf);
     else
-        hipLaunchKernelGGL(k_pf_select<2>, dim3(grid), dim3(BLOCK), lds, ctx->stream, d_rec, nreads, d_off, stride, pf->k, pf->words, pf->nbuckets,
+        hipLaunchKernelGGL(k_pf_select<2>, dim3(grid), dim3(BLOCK), lds, ctx->stream, d_rec, nreads, d_off, stride, pf->k, rs, pf->words, pf->nbuckets,
                            pf->keybuf, pf->keybuf_keys, pf->d_cursor, d_ovf);
     GK_HIP(ctx, hipGetLastError());
     unsigned long long h[3] = {0, 0, 0};
@@ -276,8 +277,9 @@ int gk_prefilter_create(gk_ctx *ctx, int k, uint64_t expected_distinct, gk_prefi
     }
     GK_HIP(ctx, hipMemsetAsync(pf->words, 0, pf->nwords * 4, ctx->stream));
     GK_HIP(ctx, hipMemsetAsync(pf->d_cursor, 0, 4 * sizeof(unsigned long long), ctx->stream));
-    GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pf_select<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PF_SEL_KEYS * 8));
-    GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pf_select<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PF_SEL_KEYS * 16));
+    // one read of 255 bases at k = 2 has 254 windows: the parking area never needs more than max(PF_PARK_BYTES, one read)
+    GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pf_select<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PF_PARK_BYTES));
+    GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pf_select<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PF_PARK_BYTES));
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out = pf;
     return GK_OK;
@@ -336,7 +338,7 @@ int gk_map_count_reads_prefiltered_dev(gk_map *m, gk_prefilter *pf, const void *
     u64 adm = 0;
     for (u64 done = 0; done < nreads; done += chunk_reads) {
         const u64 n = std::min(chunk_reads, nreads - done);
-        if (int rc = pf_select_and_insert(pf, m, (const uint8_t *)dev_records + done * stride, n, nullptr, stride, n * nk, &adm)) return rc;
+        if (int rc = pf_select_and_insert(pf, m, (const uint8_t *)dev_records + done * stride, n, nullptr, stride, n * nk, nk, &adm)) return rc;
     }
     if (occurrences) *occurrences = nreads * nk;
     if (admitted) *admitted = adm;
@@ -355,7 +357,7 @@ int gk_map_count_reads_prefiltered(gk_map *m, gk_prefilter *pf, const uint8_t *b
     u64 adm = 0, occ_total = 0;
     int rc = pf_for_each_host_chunk(pf, bin, nbytes, nreads, PF_CHUNK_WINDOWS, [&](const uint8_t *d_rec, u64 n, const u32 *d_off, u64 occ) {
         occ_total += occ;
-        return occ ? pf_select_and_insert(pf, m, d_rec, n, d_off, 0, occ, &adm) : GK_OK;
+        return occ ? pf_select_and_insert(pf, m, d_rec, n, d_off, 0, occ, (u64)std::max(1, 255 - pf->k + 1), &adm) : GK_OK;
     });
     if (rc) return rc;
     if (occurrences) *occurrences = occ_total;

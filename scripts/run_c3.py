@@ -3,7 +3,7 @@ count (chunked) -> deleteAll(<3) -> buildGraph -> removeBubbles -> simplifyGraph
 usage: python scripts/run_c3.py [reads=5000000] [genome=4600000] [err=0.005] [chunk_reads=2000000] [capacity_hint=0] [prefilter_distinct=0]
 prefilter_distinct > 0: two passes over the (regenerated) chunks through the exact singleton pre-filter."""
 import sys, time, json
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 from genome_amd import synth
 from genome_amd.dnamap import Context, HipDNAMap

@@ -3,7 +3,7 @@
 Prints each phase's share of thread 0's wall clock, summed over workgroups.
 usage (GPU box): build a timers variant into genome_amd/variants/ and run scripts/sweep_timers.sh <name>"""
 import ctypes as C, sys
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from genome_amd import synth, _lib
 from genome_amd.dnamap import Context, HipDNAMap, skm_slot_bytes
 n, L, k, steps = 1_000_000, 150, 31, 5

@@ -3,7 +3,7 @@ the CPU oracle would take minutes for.  Random k (both key widths), read length,
 capacity hint (incl. far too small: growth, failed segments), 1-3 batches, clear in between or not.
 usage: python scripts/stress_paths.py [seconds=240] [seed=1]"""
 import random, sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 from genome_amd import synth
 from genome_amd.dnamap import Context, HipDNAMap

@@ -1,7 +1,7 @@
 """C2 mode G (1e6 x 150 bp over 5 Mbp, 1 % error), k=31: plain count + filter_lt(3) vs the exact two-pass
 singleton pre-filter; table sizes and wall times."""
 import sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from genome_amd import synth
 from genome_amd.dnamap import Context, HipDNAMap
 from genome_amd.prefilter import HipPrefilter
@@ -24,7 +24,7 @@ print(f"plain: {ms_plain:.2f} ms, distinct {distinct}, table slots {slots_plain}
 for mult in (1.0, 0.25):
     pf = HipPrefilter(ctx, k, int(distinct * mult))
     ms1, _ = t(lambda: pf.add_reads_dev(d, n, L), reps=1)
-    m2 = HipDNAMap(ctx, k, int(kept * 2))
+    m2 = HipDNAMap(ctx, k, int(distinct * (0.45 if mult >= 1 else 0.8)))
     def p2():
         m2.clear(); return pf.count_reads_dev(m2, d, n, L)
     ms2, (looked, adm) = t(p2)

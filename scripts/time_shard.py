@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 from genome_amd import synth
 from genome_amd.dnamap import Context, skm_slot_bytes
