@@ -561,7 +561,10 @@ int gk_map_count_reads_dev(gk_map *m, const void *dev_records, uint64_t nreads, 
     while (done < nreads) {
         u64 chunk = std::min(nreads - done, reads_per_launch(m, nk));
         if (nk && use_partitioned(m, chunk * nk)) {
-            if (!m->pending_clear) { if (int rc = map_reserve(m, chunk * nk)) return rc; }
+            // (GK_TEST_NO_RESERVE: test hook — leave the table too small on purpose so that segments fill up in P5
+            //  and the failed-segment replay runs; hashed keys never get there on their own)
+            const bool no_reserve = getenv("GK_TEST_NO_RESERVE") != nullptr;
+            if (!m->pending_clear && !no_reserve) { if (int rc = map_reserve(m, chunk * nk)) return rc; }
             if (int rc = launch_partitioned(m, rec + done * stride, chunk, nullptr, stride, nullptr, 0, chunk * nk)) return rc;
         } else {
             if (int rc = map_materialize(m)) return rc;
