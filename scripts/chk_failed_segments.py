@@ -1,3 +1,5 @@
+"""Which insert path runs, and with what side effects (growth, spills, failed segments, hand-backs), for one batch of
+device-resident reads at several capacity hints; both paths must give the same table."""
 import sys
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np

@@ -1,3 +1,4 @@
+"""Time the two routing kernels of the multi-GPU path (super-k-mer records vs 8-byte keys) at C2 for P = 1, 2, 8."""
 import sys, time
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
