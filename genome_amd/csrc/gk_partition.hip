@@ -322,7 +322,10 @@ __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_keys(const u64 *__rest
 // P2 of the over-provisioned mode for fixed-stride records: ONE window-extraction pass.  The tile's
 // canonical keys and their L1 buckets are parked in LDS while the per-bucket counts are built, the
 // bucket regions are reserved (one global atomic per (tile, bucket)), then the keys go out.  No P1.
-static constexpr int OP_CAP = 5632;         // LDS key buffer, in 64-bit words (2 workgroups per CU)
+#ifndef GK_OP_CAP
+#define GK_OP_CAP 5632
+#endif
+static constexpr int OP_CAP = GK_OP_CAP;    // LDS key buffer, in 64-bit words (5632: 2 workgroups per CU)
 static constexpr int OP_TILE_READS = 128;
 static constexpr int OP_TILE_WORDS = OP_TILE_READS * 65 / 4 + 64;
 template <int W>
