@@ -1,6 +1,6 @@
 """BASELINE.json configs[2] rehearsal: N x 150 bp reads over an E. coli-scale genome, k=31, one GPU:
 count (chunked) -> deleteAll(<3) -> buildGraph -> removeBubbles -> simplifyGraph -> retainLargest, timed.
-usage: python scripts/run_c3.py [reads=5000000] [genome=4600000] [err=0.005] [chunk_reads=2000000] [capacity_hint=0] [prefilter_distinct=0]
+usage: python scripts/run_c3.py [reads=5000000] [genome=4600000] [err=0.005] [chunk_reads=2000000] [capacity_hint=0] [prefilter_distinct=0] [k=31]
 prefilter_distinct > 0: two passes over the (regenerated) chunks through the exact singleton pre-filter."""
 import sys, time, json
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
@@ -12,7 +12,8 @@ from genome_amd.graph import buildGraph
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 4_600_000
 err = float(sys.argv[3]) if len(sys.argv) > 3 else 0.005
-L, k = 150, 31
+L = 150
+k = int(sys.argv[7]) if len(sys.argv) > 7 else 31
 chunk = int(sys.argv[4]) if len(sys.argv) > 4 else 2_000_000
 hint = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 pfd = int(sys.argv[6]) if len(sys.argv) > 6 else 0
