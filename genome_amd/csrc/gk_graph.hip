@@ -675,26 +675,55 @@ __global__ __launch_bounds__(BLOCK) void k_cc_hook(GraphView g, u32 *parent, u32
 __global__ __launch_bounds__(BLOCK) void k_cc_compress(GraphView g, u32 *parent) {
     for (u64 n = (u64)blockIdx.x * BLOCK + threadIdx.x; n < g.n_nodes; n += (u64)gridDim.x * BLOCK) parent[n] = cc_root(parent, (u32)n);
 }
+// component sizes.  A giant component means millions of increments of ONE counter, and same-address
+// atomics retire at ~88 per microsecond chip-wide (143 ms of the 169 ms retain step at C3): lanes of a
+// wave that share a root are combined first (ballot per distinct root), then one atomic per group.
 __global__ __launch_bounds__(BLOCK) void k_cc_sizes(GraphView g, const u32 *parent, u32 *size, unsigned long long *ncomp) {
-    for (u64 n = (u64)blockIdx.x * BLOCK + threadIdx.x; n < g.n_nodes; n += (u64)gridDim.x * BLOCK) {
-        if (!g.node_alive[n]) continue;
-        atomicAdd(&size[parent[n]], 1u);
-        if (parent[n] == n) atomicAdd(ncomp, 1ull);
+    __shared__ u32 s_roots;
+    if (threadIdx.x == 0) s_roots = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    u32 nroots = 0;
+    for (u64 n0 = (u64)blockIdx.x * BLOCK + (threadIdx.x & ~63u); n0 < g.n_nodes; n0 += (u64)gridDim.x * BLOCK) {   // wave-uniform trip count
+        const u64 n = n0 + lane;
+        const bool active = n < g.n_nodes && g.node_alive[n];
+        const u32 root = active ? parent[n] : 0xffffffffu;
+        unsigned long long todo = __ballot(active);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const u32 lr = __shfl(root, leader);
+            const unsigned long long same = __ballot(active && root == lr);
+            if (lane == leader) atomicAdd(&size[lr], (u32)__popcll(same));
+            todo &= ~same;
+        }
+        nroots += (u32)__popcll(__ballot(active && root == (u32)n));
     }
+    if (lane == 0 && nroots) atomicAdd(&s_roots, nroots);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_roots) atomicAdd(ncomp, (unsigned long long)s_roots);
 }
 __global__ __launch_bounds__(BLOCK) void k_cc_max(GraphView g, const u32 *size, u32 *best) {
+    u32 m = 0;
     for (u64 n = (u64)blockIdx.x * BLOCK + threadIdx.x; n < g.n_nodes; n += (u64)gridDim.x * BLOCK)
-        if (g.node_alive[n] && size[n]) atomicMax(best, size[n]);
+        if (g.node_alive[n]) m = max(m, size[n]);
+    for (int d = 32; d; d >>= 1) m = max(m, (u32)__shfl_down(m, d));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(best, m);
 }
 // among the components of maximal size pick the one holding the smallest k-mer: stage 0 min hi,
-// stage 1 min lo among those, stage 2 record its root
+// stage 1 min lo among those, stage 2 record its root (one atomic per wave, see k_cc_sizes)
 __global__ __launch_bounds__(BLOCK) void k_cc_pick(GraphView g, const u32 *parent, const u32 *size, u32 best, int stage,
                                                    unsigned long long *mins /* hi, lo */, u32 *winner) {
+    unsigned long long m = ~0ull;
+    const unsigned long long min_hi = stage >= 1 ? mins[0] : 0ull, min_lo = stage == 2 ? mins[1] : 0ull;
     for (u64 n = (u64)blockIdx.x * BLOCK + threadIdx.x; n < g.n_nodes; n += (u64)gridDim.x * BLOCK) {
         if (!g.node_alive[n] || size[parent[n]] != best) continue;
-        if (stage == 0) atomicMin(&mins[0], (unsigned long long)g.node_hi[n]);
-        else if (stage == 1) { if (g.node_hi[n] == mins[0]) atomicMin(&mins[1], (unsigned long long)g.node_lo[n]); }
-        else if (g.node_hi[n] == mins[0] && g.node_lo[n] == mins[1]) *winner = parent[n];
+        if (stage == 0) m = min(m, (unsigned long long)g.node_hi[n]);
+        else if (stage == 1) { if (g.node_hi[n] == min_hi) m = min(m, (unsigned long long)g.node_lo[n]); }
+        else if (g.node_hi[n] == min_hi && g.node_lo[n] == min_lo) *winner = parent[n];
+    }
+    if (stage < 2) {
+        for (int d = 32; d; d >>= 1) m = min(m, (unsigned long long)__shfl_down(m, d));
+        if ((threadIdx.x & 63) == 0 && m != ~0ull) atomicMin(&mins[stage], m);
     }
 }
 __global__ __launch_bounds__(BLOCK) void k_retain(GraphView g, const u32 *parent, u32 winner) {
