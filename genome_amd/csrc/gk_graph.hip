@@ -310,8 +310,12 @@ __device__ __forceinline__ int single_out_base(u32 aux, int ori) {
     return __popc(om) == 1 ? __ffs(om) - 1 : -1;
 }
 
+// pointer-jumping state of one oriented k-mer: successor id (itself once absorbed, ~0 if unregistered) and the
+// distance covered so far, side by side so that a jump is ONE 16-byte random read
+struct alignas(16) PjState { u64 nxt; u64 dist; };
+
 template <int W>
-__global__ __launch_bounds__(BLOCK) void k_pj_init(Table<W> t, int k, u64 *nxt, u32 *dist, u64 *active, unsigned long long *n_active) {
+__global__ __launch_bounds__(BLOCK) void k_pj_init(Table<W> t, int k, PjState *st, u64 *active, unsigned long long *n_active) {
     __shared__ u32 lds4[BLOCK / 64];
     __shared__ unsigned long long s_base;
     const u64 ncap = t.capacity();
@@ -345,24 +349,22 @@ __global__ __launch_bounds__(BLOCK) void k_pj_init(Table<W> t, int k, u64 *nxt, 
         for (int ori = 0; ori < 2; ori++)
             if (act[ori]) {
                 const u64 self = 2 * i + ori;
-                nxt[self] = nx[ori];
-                dist[self] = dd[ori];
+                st[self] = PjState{nx[ori], (u64)dd[ori]};
                 active[o++] = self;
             }
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_pj_round(const u64 *__restrict__ active, u64 n, const u64 *__restrict__ nxtA,
-                                                    const u32 *__restrict__ dA, u64 *__restrict__ nxtB, u32 *__restrict__ dB, u32 *changed) {
+__global__ __launch_bounds__(BLOCK) void k_pj_round(const u64 *__restrict__ active, u64 n, const PjState *__restrict__ A, PjState *__restrict__ B,
+                                                    u32 *changed) {
     bool ch = false;
     for (u64 a = (u64)blockIdx.x * BLOCK + threadIdx.x; a < n; a += (u64)gridDim.x * BLOCK) {
         const u64 u = active[a];
-        const u64 tt = nxtA[u];
-        if (tt == u) { nxtB[u] = u; dB[u] = dA[u]; continue; }
-        const u64 t2 = nxtA[tt];
-        nxtB[u] = t2;
-        dB[u] = dA[u] + dA[tt];
-        if (nxtA[t2] != t2) ch = true;                // not absorbed yet
+        const PjState su = A[u];
+        if (su.nxt == u) { B[u] = su; continue; }           // absorbed
+        const PjState sv = A[su.nxt];                       // the one random read of the round
+        B[u] = PjState{sv.nxt, su.dist + sv.dist};
+        if (sv.nxt != su.nxt) ch = true;                    // the pointer moved: not done yet
     }
     if (ch) *changed = 1;
 }
@@ -380,8 +382,7 @@ __device__ __forceinline__ u32 pj_end_node(const Table<W> &t, int k, u64 pt, con
 }
 
 template <int W>
-__global__ __launch_bounds__(BLOCK) void k_pj_edges(Table<W> t, int k, GraphView g, const u32 *slot_node, const u64 *nxt, const u32 *dist,
-                                                    u32 *err) {
+__global__ __launch_bounds__(BLOCK) void k_pj_edges(Table<W> t, int k, GraphView g, const u32 *slot_node, const PjState *st, u32 *err) {
     for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < g.n_edges; e += (u64)gridDim.x * BLOCK) {
         const u32 n = g.e_start[e];
         const Kmer<W> u0 = append_base(node_kmer<W>(g, n), g.e_first[e], k);
@@ -394,9 +395,10 @@ __global__ __launch_bounds__(BLOCK) void k_pj_edges(Table<W> t, int k, GraphView
             end = slot_node[s0] + (fwd ? 0u : 1u);
         } else {
             const u64 id0 = 2 * (u64)s0 + (fwd ? 0 : 1);
-            const u64 pt = nxt[id0];
-            if (pt >= 2 * t.capacity() || nxt[pt] != pt) { *err = 4; continue; }   // unregistered / not absorbed: cannot happen from a terminal
-            len = (u64)dist[id0] + 2;
+            const PjState s_id0 = st[id0];
+            const u64 pt = s_id0.nxt;
+            if (pt >= 2 * t.capacity() || st[pt].nxt != pt) { *err = 4; continue; }   // unregistered / not absorbed: cannot happen from a terminal
+            len = s_id0.dist + 2;
             end = pj_end_node(t, k, pt, slot_node);
         }
         g.e_end[e] = end;
@@ -414,14 +416,15 @@ __device__ __forceinline__ void pool_or(uint8_t *pool, u64 off, u64 pos, int bas
 
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_pj_emit(Table<W> t, int k, GraphView g, const u32 *slot_node, const u64 *active, u64 n_active,
-                                                   const u64 *nxt, const u32 *dist, u32 *err) {
+                                                   const PjState *st, u32 *err) {
     const u64 tid = (u64)blockIdx.x * BLOCK + threadIdx.x, stride = (u64)gridDim.x * BLOCK;
     for (u64 e = tid; e < g.n_edges; e += stride) pool_or(g.pool, g.e_off[e], 0, g.e_first[e]);       // builder += base  :352
     for (u64 a = tid; a < n_active; a += stride) {
         const u64 u = active[a], v = u ^ 1;                     // v = rc(u): same slot, other orientation
-        const u64 pt = nxt[v], ptu = nxt[u], nid = 2 * t.capacity();
+        const PjState s_v = st[v];
+        const u64 pt = s_v.nxt, ptu = st[u].nxt, nid = 2 * t.capacity();
         if (pt >= nid || ptu >= nid) { *err = 7; continue; }    // the partner orientation must have been registered too
-        if (nxt[pt] != pt || nxt[ptu] != ptu) continue;         // member of an all-(1,1) cycle
+        if (st[pt].nxt != pt || st[ptu].nxt != ptu) continue;   // member of an all-(1,1) cycle
         const int nb = single_out_base(t.slots[u >> 1].aux, (int)(u & 1));
         const u32 rs_node = pj_end_node(t, k, pt, slot_node);   // node of rc(s)
         if (nb < 0 || rs_node == NONE) { *err = 5; continue; }
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(BLOCK) void k_pj_emit(Table<W> t, int k, GraphView 
         const int b = 3 - first_base(oriented_kmer(t, pt, k));            // last base of u0 = complement of first base of rc(u0)
         const u32 e = g.out_edge[(u64)s_node * 4 + b];
         if (e == NONE) { *err = 6; continue; }
-        pool_or(g.pool, g.e_off[e], (u64)dist[v] + 1, nb);
+        pool_or(g.pool, g.e_off[e], s_v.dist + 1, nb);
     }
 }
 
@@ -956,22 +959,20 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
     if (nE) {
         const char *force = getenv("GK_GRAPH_UNITIGS");        // "walk" | "pj": test hook
         const bool use_pj = force ? !strcmp(force, "pj") : (m->size / std::max<u64>(nE, 1) >= 16);
-        u64 *nxtA = nullptr, *nxtB = nullptr, *active = nullptr;
-        u32 *dA = nullptr, *dB = nullptr;
+        PjState *stA = nullptr, *stB = nullptr;
+        u64 *active = nullptr;
         u64 n_active = 0;
         auto pj_free = [&]() {
-            for (void *p : {(void *)nxtA, (void *)nxtB, (void *)active, (void *)dA, (void *)dB}) if (p) (void)hipFree(p);
+            for (void *p : {(void *)stA, (void *)stB, (void *)active}) if (p) (void)hipFree(p);
         };
         if (use_pj) {
             const u64 nid = 2 * m->capacity;
-            e = hipMalloc((void **)&nxtA, nid * 8);
-            if (e == hipSuccess) e = hipMalloc((void **)&nxtB, nid * 8);
-            if (e == hipSuccess) e = hipMalloc((void **)&dA, nid * 4);
-            if (e == hipSuccess) e = hipMalloc((void **)&dB, nid * 4);
+            e = hipMalloc((void **)&stA, nid * sizeof(PjState));
+            if (e == hipSuccess) e = hipMalloc((void **)&stB, nid * sizeof(PjState));
             if (e == hipSuccess) e = hipMalloc((void **)&active, std::max<u64>(2 * m->size, 1) * 8);
-            if (e == hipSuccess) e = hipMemsetAsync(nxtA, 0xff, nid * 8, ctx->stream);       // unregistered ids are out of range
+            if (e == hipSuccess) e = hipMemsetAsync(stA, 0xff, nid * sizeof(PjState), ctx->stream);       // unregistered ids are out of range
             if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: pointer-jumping arrays")); }
-            hipLaunchKernelGGL(k_pj_init<W>, dim3(ggrid(ctx, m->capacity)), dim3(BLOCK), 0, ctx->stream, t, k, nxtA, dA, active, &d_cnt[5]);
+            hipLaunchKernelGGL(k_pj_init<W>, dim3(ggrid(ctx, m->capacity)), dim3(BLOCK), 0, ctx->stream, t, k, stA, active, &d_cnt[5]);
             e = hipGetLastError();
             if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 48, hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -981,15 +982,14 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
                 u32 changed = 0;
                 e = hipMemsetAsync(d_err + 1, 0, 4, ctx->stream);
                 if (e != hipSuccess) break;
-                hipLaunchKernelGGL(k_pj_round, dim3(ggrid(ctx, n_active)), dim3(BLOCK), 0, ctx->stream, active, n_active, nxtA, dA, nxtB, dB, d_err + 1);
+                hipLaunchKernelGGL(k_pj_round, dim3(ggrid(ctx, n_active)), dim3(BLOCK), 0, ctx->stream, active, n_active, stA, stB, d_err + 1);
                 e = hipMemcpyAsync(&changed, d_err + 1, 4, hipMemcpyDeviceToHost, ctx->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-                std::swap(nxtA, nxtB);
-                std::swap(dA, dB);
+                std::swap(stA, stB);
                 if (e != hipSuccess || !changed) break;
             }
             if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: pj rounds")); }
-            hipLaunchKernelGGL(k_pj_edges<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node, nxtA, dA, d_err);
+            hipLaunchKernelGGL(k_pj_edges<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node, stA, d_err);
         } else {
             hipLaunchKernelGGL(k_walk<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node, 0, m->capacity + 1, d_err);
         }
@@ -1012,7 +1012,7 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
             e = hipMemsetAsync(g->v.pool, 0, g->pool_cap, ctx->stream);
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(k_pj_emit<W>, dim3(ggrid(ctx, std::max<u64>(n_active, nE))), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node,
-                                   active, n_active, nxtA, dA, d_err);
+                                   active, n_active, stA, d_err);
                 e = hipGetLastError();
             }
             if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream);
