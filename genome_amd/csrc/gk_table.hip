@@ -494,12 +494,18 @@ static int read_occ_counter(gk_map *m, uint64_t *occ) {
 // Direct path: ~130 B of HBM traffic per occurrence (one 64-B sector read + one 64-B atomic,
 // profiles/r01/pmc_count_reads_v2.json).  Partitioned path: ~40 B per occurrence per key word of
 // streaming plus the table itself streamed out (and in, unless it is known to be empty).
+// The pipeline's scatter passes are calibrated on batches of up to ~2.7e8 windows; beyond that their cost per
+// window grows with the batch (P2 + P4 at 4.8e8 windows: 1.6x per key; a 1.9e9-window batch into C3's 29.5 GB
+// table took 2.6x the direct path's time), which the estimate has to know — splitting the batch instead would pay
+// one more pass over the table per piece (measured: 19 vs 11.5 ms for 4.8e8 windows into an empty table).
 static bool use_partitioned(const gk_map *m, u64 occ) {
     if (m->insert_path == 1 || !part_supported(m)) return false;
     if (m->insert_path == 2) return true;
+    const double calibrated = 2.7e8;
+    const double growth = occ > calibrated ? 1.0 + 0.77 * ((double)occ / calibrated - 1.0) : 1.0;
     const double tb = (double)m->capacity * (double)slot_bytes(m->W);
     const double cost_direct = (double)occ * 130.0 + (m->pending_clear ? tb : 0.0);
-    const double cost_part = (double)occ * 40.0 * m->W + tb * (m->pending_clear ? 1.0 : 2.0) + 3e8;
+    const double cost_part = (double)occ * 40.0 * m->W * growth + tb * (m->pending_clear ? 1.0 : 2.0) + 3e8;
     return cost_part < cost_direct;
 }
 
