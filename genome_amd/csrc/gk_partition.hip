@@ -69,12 +69,22 @@ struct PartArrays {
     // [b * cap, (b + 1) * cap) of the key buffer and whatever does not fit goes to the spill list
     int op;
     unsigned long long cap1, cap2;  // keys per L1 region / per segment region
+    u32 stripe_nb1;                 // over-provisioned mode: number of L1 regions interleaved in bufA (see l1_slot)
     u64 *spill;                     // [spill_cap * W]
     unsigned long long *nspill;
     unsigned long long spill_cap;
     u32 *overflow;                  // spill list itself overflowed: abandon the pipeline (scratch only so far)
 };
-__device__ __forceinline__ u64 l1_begin(const PartArrays &a, u32 b) { return a.op ? (u64)b * a.cap1 : a.l1_base[b]; }
+__device__ __forceinline__ u64 l1_begin(const PartArrays &a, u32 b) { return a.op ? 0ull : a.l1_base[b]; }
+// Over-provisioned mode: where key number `pos` of L1 region `b` lives in bufA.  The regions are INTERLEAVED in
+// blocks of L1_BLK keys (stripe s = block s of every region), not laid end to end: every tile of P2 appends to all
+// regions at once and all regions fill at the same pace, so the pages being written are the current stripe or two
+// (a couple of MB) instead of one page per region spread over the whole buffer — with 3.8 GB of regions laid end
+// to end 73 % of P2's address translations missed the per-CU TLB and the kernel took twice the time per key.
+static constexpr u32 L1_BLK = 512;
+__device__ __forceinline__ u64 l1_slot(const PartArrays &a, u32 b, u64 pos) {
+    return ((pos / L1_BLK) * a.stripe_nb1 + b) * L1_BLK + (pos % L1_BLK);
+}
 __device__ __forceinline__ u64 l1_count(const PartArrays &a, u32 b) {
     return a.op ? min(a.cursor1[b], a.cap1) : a.l1_base[b + 1] - a.l1_base[b];
 }
@@ -235,7 +245,8 @@ __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u64 be
 #pragma unroll
     for (int j = 0; j < KEYS_PER_THREAD; j++) {
         const u32 i = threadIdx.x + j * PBLOCK;
-        key[j] = load_key<W>(in, begin + (i < cnt ? i : cnt - 1));
+        const u64 src = begin + (i < cnt ? i : cnt - 1);
+        key[j] = load_key<W>(in, LEVEL == 2 && a.op ? l1_slot(a, (u32)(bin0 / nbins), src) : src);
     }
 #pragma unroll
     for (int j = 0; j < KEYS_PER_THREAD; j++) {
@@ -258,7 +269,7 @@ __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u64 be
                                                      : (unsigned long long)atomicAdd(&a.cursor2[bin0 + b], c);
             if (a.op) {
                 const unsigned long long cap = LEVEL == 1 ? a.cap1 : a.cap2;
-                gb[b] = (bin0 + b) * cap + at;
+                gb[b] = LEVEL == 1 ? at : (bin0 + b) * cap + at;        // level 1: position inside the region (l1_slot maps it)
                 fit = at >= cap ? 0u : (u32)min((unsigned long long)c, cap - at);
             } else {
                 gb[b] = (LEVEL == 1 ? a.l1_base[b] : a.fine_base[bin0 + b]) + at;
@@ -282,7 +293,7 @@ __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u64 be
     for (u32 i = threadIdx.x; i < cnt; i += PBLOCK) {          // linear, coalesced write-out
         const u32 b = binof[i], j = i - off[b];
         const Kmer<W> x = load_key<W>(sorted, i);
-        if (j < lim[b]) store_key<W>(out, gb[b] + j, x);
+        if (j < lim[b]) store_key<W>(out, LEVEL == 1 && a.op ? l1_slot(a, b, gb[b] + j) : gb[b] + j, x);
         else if constexpr (W == 1) spill_key<1>(a, x.lo, 0);
         else spill_key<2>(a, x.lo, x.hi);
     }
@@ -368,7 +379,7 @@ __global__ __launch_bounds__(PBLOCK) void k_op_scatter1_reads(const uint8_t *__r
             u32 fit = 0;
             if (c) {
                 const unsigned long long at = atomicAdd(&a.cursor1[threadIdx.x], (unsigned long long)c);
-                gb[threadIdx.x] = (unsigned long long)threadIdx.x * a.cap1 + at;
+                gb[threadIdx.x] = at;                               // position inside the region (l1_slot maps it)
                 fit = at >= a.cap1 ? 0u : (u32)min((unsigned long long)c, a.cap1 - at);
             }
             lim[threadIdx.x] = fit;
@@ -380,7 +391,7 @@ __global__ __launch_bounds__(PBLOCK) void k_op_scatter1_reads(const uint8_t *__r
             if (b == 0xffff) continue;
             const u32 j = atomicAdd(&rank[b], 1u);
             const Kmer<W> x = load_key<W>(flat, i);
-            if (j < lim[b]) store_key<W>(out, gb[b] + j, x);
+            if (j < lim[b]) store_key<W>(out, l1_slot(a, b, gb[b] + j), x);
             else if constexpr (W == 1) spill_key<1>(a, x.lo, 0);
             else spill_key<2>(a, x.lo, x.hi);
         }
@@ -734,7 +745,7 @@ static int part_prepare(gk_map *m, PartScratch *ps, u64 nkeys, bool op, PartArra
         ps->W = m->W;
     }
     arr->op = op ? 1 : 0;
-    arr->cap1 = arr->cap2 = 0; arr->spill_cap = 0;
+    arr->cap1 = arr->cap2 = 0; arr->spill_cap = 0; arr->stripe_nb1 = 0;
     u64 wantA = nkeys, wantB = nkeys, wantS = 0;
     if (op) {
         // Bucket sizes of hashed keys concentrate (binomial): mean + 8 sigma + slack never overflows
@@ -744,7 +755,8 @@ static int part_prepare(gk_map *m, PartScratch *ps, u64 nkeys, bool op, PartArra
         arr->cap1 = (u64)(m1 + 8.0 * std::sqrt(m1) + 1024.0);
         arr->cap2 = (u64)(m2 + 8.0 * std::sqrt(m2) + 64.0);
         arr->spill_cap = nkeys / 16 + 65536;
-        wantA = nb1 * arr->cap1; wantB = nseg * arr->cap2; wantS = arr->spill_cap;
+        arr->stripe_nb1 = (u32)nb1;
+        wantA = (arr->cap1 + L1_BLK - 1) / L1_BLK * L1_BLK * nb1; wantB = nseg * arr->cap2; wantS = arr->spill_cap;
     }
     if (int rc = grow_buf(ctx, &ps->bufA, &ps->bufA_keys, wantA, m->W)) return rc;
     if (int rc = grow_buf(ctx, &ps->bufB, &ps->bufB_keys, wantB, m->W)) return rc;

@@ -494,10 +494,13 @@ static int read_occ_counter(gk_map *m, uint64_t *occ) {
 // Direct path: ~130 B of HBM traffic per occurrence (one 64-B sector read + one 64-B atomic,
 // profiles/r01/pmc_count_reads_v2.json).  Partitioned path: ~40 B per occurrence per key word of
 // streaming plus the table itself streamed out (and in, unless it is known to be empty).
-// The pipeline's scatter passes are calibrated on batches of up to ~2.7e8 windows; beyond that their cost per
-// window grows with the batch (P2 + P4 at 4.8e8 windows: 1.6x per key; a 1.9e9-window batch into C3's 29.5 GB
-// table took 2.6x the direct path's time), which the estimate has to know — splitting the batch instead would pay
-// one more pass over the table per piece (measured: 19 vs 11.5 ms for 4.8e8 windows into an empty table).
+// The pipeline is calibrated on batches of up to ~2.7e8 windows into a table of about their own size.  Much larger
+// batches go with larger tables, where P4 has more fine buckets per chunk (1.2x the time per key at 4.8e8 windows, 1.8x
+// at 9.6e8) and where the windows are usually repeats of far fewer k-mers: the over-provisioned regions are sized for
+// near-distinct keys, repeats over-disperse the bucket sizes and spill (C3 fed in 1.9e9-window batches through the
+// pipeline: 0.62 s against 0.24 s on the direct path, whose repeats hit cached slots).  The growth factor below is
+// that experience, not a model of it; splitting a big batch instead would pay a pass over the table per piece
+// (measured: 19 vs 11.5 ms for 4.8e8 windows into an empty table).
 static bool use_partitioned(const gk_map *m, u64 occ) {
     if (m->insert_path == 1 || !part_supported(m)) return false;
     if (m->insert_path == 2) return true;
