@@ -8,6 +8,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import shutil
 import sys
 
@@ -18,7 +19,7 @@ PIPE = ("k_op_scatter1_reads", "k_part_hist1_reads", "k_part_scatter1_reads", "k
 
 
 def load(kind):
-    f = glob.glob(f"gpurun_out/{tag}_pmc_{kind}/*/*counter_collection.csv")[0]
+    f = max(glob.glob(f"gpurun_out/{tag}_pmc_{kind}/*/*counter_collection.csv"), key=os.path.getmtime)      # newest run of that tag
     shutil.copy(f, f"{out_dir}/pmc_{tag}_{kind}_counter_collection.csv")
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
@@ -46,6 +47,6 @@ doc = {"command": f"scripts/profile_round.sh {tag} auto  (rocprofv3 --pmc <group
 json.dump(doc, open(f"{out_dir}/pmc_pipeline_{tag}.json", "w"), indent=1)
 ks = glob.glob(f"gpurun_out/{tag}_stats/*/*kernel_stats.csv")
 if ks:
-    shutil.copy(ks[0], f"{out_dir}/bench_n1_{tag}_kernel_stats.csv")
+    shutil.copy(max(ks, key=os.path.getmtime), f"{out_dir}/bench_n1_{tag}_kernel_stats.csv")
 shutil.copy(f"gpurun_out/{tag}_bench.json", f"{out_dir}/bench_n1_{tag}.json")
 print(json.dumps({k: {a: b for a, b in v.items() if "bytes" in a} for k, v in per_kernel.items()}, indent=1), total)
