@@ -79,10 +79,11 @@ __device__ __forceinline__ u64 l1_begin(const PartArrays &a, u32 b) { return a.o
 // Over-provisioned mode: where key number `pos` of L1 region `b` lives in bufA.  The regions are INTERLEAVED in
 // blocks of L1_BLK keys (stripe s = block s of every region), not laid end to end: every tile of P2 appends to all
 // regions at once and all regions fill at the same pace, so the pages being written are the current stripe or two
-// (a couple of MB) instead of one page per region spread over the whole buffer — with 3.8 GB of regions laid end
+// (8-16 MB) instead of one page per region spread over the whole buffer — with 3.8 GB of regions laid end
 // to end 73 % of P2's address translations missed the per-CU TLB and the kernel took twice the time per key.
-static constexpr u32 L1_BLK = 512;
+static constexpr u32 L1_BLK = 4096;         // = one P4 chunk (TILE2), so that a chunk is still one contiguous 32/64 KiB read
 __device__ __forceinline__ u64 l1_slot(const PartArrays &a, u32 b, u64 pos) {
+    if (!a.stripe_nb1) return (u64)b * a.cap1 + pos;         // small buffer: end to end (no TLB pressure, and 3 % faster at C2)
     return ((pos / L1_BLK) * a.stripe_nb1 + b) * L1_BLK + (pos % L1_BLK);
 }
 __device__ __forceinline__ u64 l1_count(const PartArrays &a, u32 b) {
@@ -755,8 +756,12 @@ static int part_prepare(gk_map *m, PartScratch *ps, u64 nkeys, bool op, PartArra
         arr->cap1 = (u64)(m1 + 8.0 * std::sqrt(m1) + 1024.0);
         arr->cap2 = (u64)(m2 + 8.0 * std::sqrt(m2) + 64.0);
         arr->spill_cap = nkeys / 16 + 65536;
-        arr->stripe_nb1 = (u32)nb1;
-        wantA = (arr->cap1 + L1_BLK - 1) / L1_BLK * L1_BLK * nb1; wantB = nseg * arr->cap2; wantS = arr->spill_cap;
+        // interleave the L1 regions (l1_slot) once the buffer is big enough for P2 to thrash the TLB (measured: fine at
+        // 0.96 GB, 73 % translation misses at 3.8 GB)
+        const bool striped = nb1 * arr->cap1 * 8ull * m->W >= (3ull << 29);
+        arr->stripe_nb1 = striped ? (u32)nb1 : 0u;
+        wantA = striped ? (arr->cap1 + L1_BLK - 1) / L1_BLK * L1_BLK * nb1 : nb1 * arr->cap1;
+        wantB = nseg * arr->cap2; wantS = arr->spill_cap;
     }
     if (int rc = grow_buf(ctx, &ps->bufA, &ps->bufA_keys, wantA, m->W)) return rc;
     if (int rc = grow_buf(ctx, &ps->bufB, &ps->bufB_keys, wantB, m->W)) return rc;
