@@ -76,8 +76,8 @@ struct PartArrays {
     u32 *overflow;                  // spill list itself overflowed: abandon the pipeline (scratch only so far)
 };
 __device__ __forceinline__ u64 l1_begin(const PartArrays &a, u32 b) { return a.op ? 0ull : a.l1_base[b]; }
-// Over-provisioned mode: where key number `pos` of L1 region `b` lives in bufA.  The regions are INTERLEAVED in
-// blocks of L1_BLK keys (stripe s = block s of every region), not laid end to end: every tile of P2 appends to all
+// Over-provisioned mode: where key number `pos` of L1 region `b` lives in bufA.  From 1.5 GB up (part_prepare sets
+// stripe_nb1) the regions are INTERLEAVED in blocks of L1_BLK keys (stripe s = block s of every region), not laid end to end: every tile of P2 appends to all
 // regions at once and all regions fill at the same pace, so the pages being written are the current stripe or two
 // (8-16 MB) instead of one page per region spread over the whole buffer — with 3.8 GB of regions laid end
 // to end 73 % of P2's address translations missed the per-CU TLB and the kernel took twice the time per key.
