@@ -311,6 +311,27 @@ def test_partitioned_path_heavy_hitters_and_tiny_batches(ctx):
     m.close()
 
 
+@pytest.mark.parametrize("k,n,mode", [(55, 1100000, "G")])
+def test_interleaved_key_buffer(ctx, k, n, mode):
+    """Batches whose level-1 key buffer reaches 1.5 GB interleave the 256 regions in chunk-sized blocks (l1_slot in
+    gk_partition.hip) so that P2 does not thrash the TLB.  Too big for the CPU oracle in test time: the partitioned
+    result must equal the direct kernels' (which the oracle tests pin) and the window count must be exact."""
+    L_ = 150
+    d = ctx.alloc(n * synth.record_stride(L_) + 64)
+    ctx.synth_reads(d, n, L_, mode, 31, 0, 3_000_000, 0.0005)    # ~1e7 distinct k-mers: the export stays small
+    tables = []
+    for path in ("direct", "partitioned"):
+        m = HipDNAMap(ctx, k, n * (L_ - k + 1))
+        m.set_insert_path(path)
+        assert m.count_reads_dev(d, n, L_) == n * (L_ - k + 1)
+        assert (m.stats()["partitioned_launches"] > 0) == (path == "partitioned")
+        tables.append(m.sorted_items())
+        m.close()
+    assert_same_table(tables[1], tables[0])
+    assert int(tables[0][2].astype(np.int64).sum()) == n * (L_ - k + 1)
+    ctx.free(d)
+
+
 @pytest.mark.parametrize("k", [31, 47])
 def test_failed_segments_are_replayed(ctx, k, monkeypatch):
     """P5 hands a segment that fills up back to the host (grow + replay through the direct path).  Hashed keys do not
