@@ -32,6 +32,7 @@ struct gk_map {
     uint64_t tombstones = 0;
     uint64_t total_occurrences = 0;
     uint64_t grows = 0;
+    bool skewed = false;         // a batch overflowed the pipeline's regions and spill list: auto mode stays on the direct path
     float last_count_ms = 0.f;
     uint64_t last_count_occ = 0;
     // staging buffer reused by host-fed count_reads

@@ -504,6 +504,7 @@ static int read_occ_counter(gk_map *m, uint64_t *occ) {
 static bool use_partitioned(const gk_map *m, u64 occ) {
     if (m->insert_path == 1 || !part_supported(m)) return false;
     if (m->insert_path == 2) return true;
+    if (m->skewed) return false;          // this map's data has already defeated the over-provisioned regions once
     const double calibrated = 2.7e8;
     const double growth = occ > calibrated ? 1.0 + 0.77 * ((double)occ / calibrated - 1.0) : 1.0;
     const double tb = (double)m->capacity * (double)slot_bytes(m->W);
@@ -523,6 +524,7 @@ static int launch_partitioned(gk_map *m, const uint8_t *d_rec, u64 nreads, const
     if (prc < 0) return prc;
     if (prc == PART_RETRY_DIRECT) {        // extreme skew: nothing but scratch (or a table that was being rebuilt from empty) was touched
         m->pending_clear = from_empty;
+        m->skewed = true;
         if (from_empty) m->size = 0;
         if (int rc = map_materialize(m)) return rc;
         if (int rc = map_reserve(m, bound)) return rc;
