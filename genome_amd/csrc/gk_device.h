@@ -300,6 +300,33 @@ GK_D int seg_add(Slot<2> *seg, u32 pos, Kmer<2> key, u32 add, CAS cas, ADD addf,
     }
     return -1;
 }
+// Claim a slot for a key KNOWN to be absent and inserted by nobody else (rehash: the old table holds every key
+// once): the index inside the segment, or -1 if the segment is full.  The caller then writes the value with a
+// plain store — no second atomic.
+GK_D i64 seg_claim_unique(Slot<1> *seg, u32 pos, Kmer<1> key, u32 = 0u) {
+    constexpr u32 smask = (1u << SegBits<1>::value) - 1u;
+    u32 i = pos;
+    for (u32 n = 0; n <= smask; ++n) {
+        if (seg[i].w0 == KEY_EMPTY && cas64(&seg[i].w0, KEY_EMPTY, key.lo) == KEY_EMPTY) return (i64)i;
+        i = (i + 1) & smask;
+    }
+    return -1;
+}
+GK_D i64 seg_claim_unique(Slot<2> *seg, u32 pos, Kmer<2> key, u32 tagged = 0u) {
+    constexpr u32 smask = (1u << SegBits<2>::value) - 1u;
+    const Stored<2> k = to_stored(key);
+    const u32 step = tagged ? 4u : 1u;
+    u32 i = tagged ? ((pos & ~3u) | key_tag(key)) : pos;
+    for (u32 n = 0; n <= smask; n += step) {
+        // w0 decides the slot (the key is unique, so nobody races for w1 of a slot whose w0 is ours... except a key
+        // sharing w0: it sees w0 == its own w0 and goes for w1 too — so w1 is claimed with a CAS as in seg_add)
+        u64 c0 = seg[i].w0;
+        if (c0 == KEY_EMPTY) { c0 = cas64(&seg[i].w0, KEY_EMPTY, k.w0); if (c0 == KEY_EMPTY) c0 = k.w0; }
+        if (c0 == k.w0 && seg[i].w1 == KEY_EMPTY && cas64(&seg[i].w1, KEY_EMPTY, k.w1) == KEY_EMPTY) return (i64)i;
+        i = (i + step) & smask;
+    }
+    return -1;
+}
 struct GlobalCas { GK_D u64 operator()(u64 *p, u64 e, u64 v) const { return cas64(p, e, v); } };
 struct GlobalAdd { GK_D void operator()(u32 *p, u32 v) const { add32_noret(p, v); } };
 

@@ -123,7 +123,12 @@ __global__ __launch_bounds__(BLOCK) void k_rehash(const Slot<W> *__restrict__ ol
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < ncap; i += (u64)gridDim.x * BLOCK) {
         if (!slot_live(&old[i])) continue;
         Kmer<W> key = slot_key(old, i, t.tagged);
-        table_add(t, key, slot_count(&old[i]), &err);
+        // every key of the old table is unique: one CAS claims its new slot, the count goes in with a plain store
+        const u64 h = slot_hash(key);
+        Slot<W> *seg = t.slots + ((u64)seg_of(t, h) << SegBits<W>::value);
+        const i64 at = seg_claim_unique(seg, seg_pos<W>(h), key, t.tagged);
+        if (at < 0) { err = 1; continue; }
+        seg[at].extra = old[i].extra;
     }
     if (err) ctr->error = 1;
 }
