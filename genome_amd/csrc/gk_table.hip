@@ -655,9 +655,12 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
         u64 occ = 0;
         const u64 occ_limit = reads_per_launch(m, 1);
         offs.clear();
+        int first_len = -1;
+        bool uniform = true;            // every record of the chunk has the same length: fixed stride, no offset table
         while (r < nreads) {
             if (pos >= nbytes) return fail(ctx, GK_E_FORMAT, "truncated .bin stream: record " + std::to_string(r) + " starts past the end");
             int len = bin[pos];
+            if (first_len < 0) first_len = len; else if (len != first_len) uniform = false;
             size_t rb = 1 + (size_t)(len + 3) / 4;
             if (pos + rb > nbytes) return fail(ctx, GK_E_FORMAT, "truncated .bin stream inside record " + std::to_string(r));
             u64 nk = len >= m->k ? (u64)(len - m->k + 1) : 0;
@@ -688,11 +691,19 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
             m->offsets_bytes = offs.size() * sizeof(u32);
         }
         GK_HIP(ctx, hipMemcpyAsync(m->d_stage, bin + chunk_begin, cbytes, hipMemcpyHostToDevice, ctx->stream));
-        GK_HIP(ctx, hipMemcpyAsync(m->d_offsets, offs.data(), offs.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+        // a chunk of equal-length records (the usual case: one sequencing run) is a fixed-stride array: no offset
+        // table to upload, and the partitioned path can take its one-extraction form
+        const u32 *d_off = nullptr;
+        u32 stride = 0;
+        if (uniform && first_len >= 0 && !getenv("GK_HOST_RAGGED")) stride = 1 + (u32)(first_len + 3) / 4;   // (env: A/B hook)
+        else {
+            GK_HIP(ctx, hipMemcpyAsync(m->d_offsets, offs.data(), offs.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+            d_off = (const u32 *)m->d_offsets;
+        }
         if (partitioned) {
-            if (int rc = launch_partitioned(m, (const uint8_t *)m->d_stage, creads, (const u32 *)m->d_offsets, 0, nullptr, 0, occ)) return rc;
+            if (int rc = launch_partitioned(m, (const uint8_t *)m->d_stage, creads, d_off, stride, nullptr, 0, occ)) return rc;
         } else {
-            if (int rc = launch_count(m, (const uint8_t *)m->d_stage, creads, (const u32 *)m->d_offsets, 0)) return rc;
+            if (int rc = launch_count(m, (const uint8_t *)m->d_stage, creads, d_off, stride)) return rc;
         }
     }
     uint64_t occ = 0;

@@ -15,4 +15,4 @@ for name, f in (("device-resident", lambda: m.count_reads_dev(d, n, L)), ("host 
     best = 1e9
     for _ in range(5):
         m.clear(); ctx.sync(); t0 = time.perf_counter(); occ = f(); ctx.sync(); best = min(best, time.perf_counter() - t0)
-    print(f"{name}: {best * 1e3:.2f} ms per {occ} windows = {m.size() / best:.3e} distinct k-mers/s; stats {m.stats()['partitioned_launches']} partitioned launches so far")
+    print(f"{name}: {best * 1e3:.2f} ms per {occ} windows = {m.size() / best:.3e} distinct k-mers/s; device pipeline phases {[round(x, 3) for x in m.last_phase_ms()]} ms")
