@@ -657,7 +657,28 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
         offs.clear();
         int first_len = -1;
         bool uniform = true;            // every record of the chunk has the same length: fixed stride, no offset table
-        while (r < nreads) {
+        // Fast prefix: a run of equal-length records (one sequencing run) is recognised by comparing one byte per
+        // record, with no offset table built; it becomes a chunk of its own when it is long enough to be worth it.
+        bool fast_prefix = false;
+        if (pos < nbytes) {
+            const int len0 = bin[pos];
+            const size_t rb0 = 1 + (size_t)(len0 + 3) / 4;
+            const u64 nk0 = len0 >= m->k ? (u64)(len0 - m->k + 1) : 0;
+            u64 cap = std::min<u64>(nreads - r, (nbytes - pos) / rb0);
+            cap = std::min<u64>(cap, std::max<u64>(1, MAX_STAGE / rb0));
+            if (nk0) cap = std::min<u64>(cap, std::max<u64>(1, occ_limit / nk0));
+            const uint8_t *p0 = bin + pos;
+            u64 run = 0;
+            while (run < cap && p0[run * rb0] == (uint8_t)len0) run++;
+            if (run >= 4096 || (run == nreads - r && run > 0)) {
+                fast_prefix = true;
+                first_len = len0;
+                pos += run * rb0;
+                occ = run * nk0;
+                r += run;
+            }
+        }
+        while (!fast_prefix && r < nreads) {
             if (pos >= nbytes) return fail(ctx, GK_E_FORMAT, "truncated .bin stream: record " + std::to_string(r) + " starts past the end");
             int len = bin[pos];
             if (first_len < 0) first_len = len; else if (len != first_len) uniform = false;
@@ -670,7 +691,7 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
             occ += nk;
             r++;
         }
-        offs.push_back((u32)(pos - chunk_begin));
+        if (!offs.empty()) offs.push_back((u32)(pos - chunk_begin));
         const size_t cbytes = pos - chunk_begin;
         const u64 creads = r - r_begin;
         const bool partitioned = occ && use_partitioned(m, occ);
