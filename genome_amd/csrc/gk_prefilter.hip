@@ -216,7 +216,7 @@ int pf_ensure_stage(gk_prefilter *pf, size_t bytes, size_t noffs) {
 }
 
 // Walk a host `.bin` stream (PairedEndData.scala:24-31) in chunks bounded in bytes and in windows;
-// f(d_records, nreads_in_chunk, d_offsets, windows_in_chunk) runs once per staged chunk.
+// f(d_records, nreads_in_chunk, d_offsets or nullptr, fixed stride or 0, windows_in_chunk) runs once per staged chunk.
 template <class F>
 int pf_for_each_host_chunk(gk_prefilter *pf, const uint8_t *bin, size_t nbytes, u64 nreads, u64 max_windows, F f) {
     gk_ctx *ctx = pf->ctx;
@@ -229,7 +229,28 @@ int pf_for_each_host_chunk(gk_prefilter *pf, const uint8_t *bin, size_t nbytes, 
         const u64 r_begin = r;
         u64 occ = 0;
         offs.clear();
-        while (r < nreads) {
+        // a run of equal-length records: one byte compare per record, no offset table (as in gk_map_count_reads)
+        bool fast_prefix = false;
+        u32 fixed_stride = 0;
+        if (pos < nbytes) {
+            const int len0 = bin[pos];
+            const size_t rb0 = 1 + (size_t)(len0 + 3) / 4;
+            const u64 nk0 = len0 >= pf->k ? (u64)(len0 - pf->k + 1) : 0;
+            u64 cap = std::min<u64>(nreads - r, (nbytes - pos) / rb0);
+            cap = std::min<u64>(cap, std::max<u64>(1, MAX_STAGE / rb0));
+            if (nk0 && max_windows != ~0ull) cap = std::min<u64>(cap, std::max<u64>(1, max_windows / nk0));
+            const uint8_t *p0 = bin + pos;
+            u64 run = 0;
+            while (run < cap && p0[run * rb0] == (uint8_t)len0) run++;
+            if (run >= 4096 || (run == nreads - r && run > 0)) {
+                fast_prefix = true;
+                fixed_stride = (u32)rb0;
+                pos += run * rb0;
+                occ = run * nk0;
+                r += run;
+            }
+        }
+        while (!fast_prefix && r < nreads) {
             if (pos >= nbytes) return fail(ctx, GK_E_FORMAT, "truncated .bin stream: record " + std::to_string(r) + " starts past the end");
             const int len = bin[pos];
             const size_t rb = 1 + (size_t)(len + 3) / 4;
@@ -239,12 +260,12 @@ int pf_for_each_host_chunk(gk_prefilter *pf, const uint8_t *bin, size_t nbytes, 
             offs.push_back((u32)(pos - chunk_begin));
             pos += rb; occ += nk; r++;
         }
-        offs.push_back((u32)(pos - chunk_begin));
+        if (!fast_prefix) offs.push_back((u32)(pos - chunk_begin));
         const size_t cbytes = pos - chunk_begin;
-        if (int rc = pf_ensure_stage(pf, cbytes, offs.size())) return rc;
+        if (int rc = pf_ensure_stage(pf, cbytes, std::max<size_t>(offs.size(), 1))) return rc;
         GK_HIP(ctx, hipMemcpyAsync(pf->d_stage, bin + chunk_begin, cbytes, hipMemcpyHostToDevice, ctx->stream));
-        GK_HIP(ctx, hipMemcpyAsync(pf->d_offsets, offs.data(), offs.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
-        if (int rc = f((const uint8_t *)pf->d_stage, r - r_begin, (const u32 *)pf->d_offsets, occ)) return rc;
+        if (!fast_prefix) GK_HIP(ctx, hipMemcpyAsync(pf->d_offsets, offs.data(), offs.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+        if (int rc = f((const uint8_t *)pf->d_stage, r - r_begin, fast_prefix ? nullptr : (const u32 *)pf->d_offsets, fixed_stride, occ)) return rc;
         GK_HIP(ctx, hipStreamSynchronize(ctx->stream));      // `offs` and the staging buffer are reused
     }
     return GK_OK;
@@ -314,9 +335,9 @@ int gk_prefilter_add_reads(gk_prefilter *pf, const uint8_t *bin, size_t nbytes, 
     gk_ctx *ctx = pf->ctx;
     if (!bin && nreads) return fail(ctx, GK_E_INVALID, "gk_prefilter_add_reads: null stream");
     GK_HIP(ctx, hipSetDevice(ctx->device));
-    return pf_for_each_host_chunk(pf, bin, nbytes, nreads, ~0ull, [&](const uint8_t *d_rec, u64 n, const u32 *d_off, u64 occ) {
+    return pf_for_each_host_chunk(pf, bin, nbytes, nreads, ~0ull, [&](const uint8_t *d_rec, u64 n, const u32 *d_off, u32 stride, u64 occ) {
         pf->windows_added += occ;
-        return pf_launch_add(pf, d_rec, n, d_off, 0);
+        return pf_launch_add(pf, d_rec, n, d_off, stride);
     });
 }
 
@@ -355,9 +376,10 @@ int gk_map_count_reads_prefiltered(gk_map *m, gk_prefilter *pf, const uint8_t *b
     if (!bin && nreads) return fail(ctx, GK_E_INVALID, "gk_map_count_reads_prefiltered: null stream");
     GK_HIP(ctx, hipSetDevice(ctx->device));
     u64 adm = 0, occ_total = 0;
-    int rc = pf_for_each_host_chunk(pf, bin, nbytes, nreads, PF_CHUNK_WINDOWS, [&](const uint8_t *d_rec, u64 n, const u32 *d_off, u64 occ) {
+    int rc = pf_for_each_host_chunk(pf, bin, nbytes, nreads, PF_CHUNK_WINDOWS, [&](const uint8_t *d_rec, u64 n, const u32 *d_off, u32 stride, u64 occ) {
         occ_total += occ;
-        return occ ? pf_select_and_insert(pf, m, d_rec, n, d_off, 0, occ, (u64)std::max(1, 255 - pf->k + 1), &adm) : GK_OK;
+        const u64 per_read = stride ? occ / std::max<u64>(n, 1) : (u64)std::max(1, 255 - pf->k + 1);
+        return occ ? pf_select_and_insert(pf, m, d_rec, n, d_off, stride, occ, per_read, &adm) : GK_OK;
     });
     if (rc) return rc;
     if (occurrences) *occurrences = occ_total;

@@ -95,6 +95,44 @@ def test_ragged_reads_vs_oracle(ctx, k):
     m.close()
 
 
+@pytest.mark.parametrize("k", [21, 47])
+def test_host_stream_with_long_uniform_runs_and_ragged_stretches(ctx, k):
+    """gk_map_count_reads walks the framing on the host: runs of >= 4096 equal-length records become fixed-stride
+    chunks (no offset table), anything else goes through the ragged form.  Mix both, in both orders, plus records
+    shorter than k and a short uniform tail."""
+    rnd = random.Random(1000 + k)
+    g = "".join(rnd.choice("AGCT") for _ in range(5000))
+
+    def reads(n, ln):
+        return [g[s:s + ln] for s in (rnd.randrange(0, len(g) - ln + 1) for _ in range(n))]
+    stream = reads(5000, 100) + reads(7, 63) + ["", "ACG"] + reads(4500, 120) + reads(300, k + 3) + reads(4096, 90) + reads(5, k - 1 if k > 2 else 1)
+    binb = dna.reads_to_bin(stream)
+    ref = O.PMap(k, 1)
+    occ = ref.count_reads(binb, len(stream))
+    for path in ("auto", "partitioned", "direct"):
+        m = HipDNAMap(ctx, k, 1 << 16)
+        m.set_insert_path(path)
+        assert m.count_reads(binb, len(stream)) == occ
+        assert_same_table(m.sorted_items(), ref.export_sorted())
+        m.close()
+    # the singleton pre-filter walks host streams the same way
+    from genome_amd.prefilter import HipPrefilter
+    pf = HipPrefilter(ctx, k, ref.size())
+    pf.add_reads(binb, len(stream))
+    m = HipDNAMap(ctx, k, 1 << 16)
+    assert pf.count_reads(m, binb, len(stream))[0] == occ
+    m.deleteAll_lt(2)
+    ref.delete_lt(2)
+    assert_same_table(m.sorted_items(), ref.export_sorted())
+    m.close(); pf.close()
+    # truncation inside a uniform run is still reported
+    m = HipDNAMap(ctx, k)
+    with pytest.raises(L.GkError) as e:
+        m.count_reads(binb[:5000 * 26 - 3], 5000)
+    assert e.value.code == L.GK_E_FORMAT
+    m.close()
+
+
 def test_truncated_stream_is_a_format_error(ctx):
     m = HipDNAMap(ctx, 11)
     binb = dna.reads_to_bin(["AGCTAGCTAGCTAGCT"] * 3)
