@@ -50,6 +50,9 @@ SIGNATURES = {
     "gk_last_error": (C.c_char_p, [vp]),
     "gk_ctx_device": (C.c_int, [vp]),
     "gk_ctx_sync": (C.c_int, [vp]),
+    "gk_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
+    "gk_map_verify": (C.c_int, [vp, u64p, u64p, u64p]),
+    "gk_map_set_max_batch_keys": (C.c_int, [vp, C.c_uint64]),
     "gk_dev_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
     "gk_dev_free": (C.c_int, [vp, vp]),
     "gk_dev_upload": (C.c_int, [vp, vp, vp, C.c_size_t]),

@@ -220,6 +220,8 @@ template <int W> struct Table {
     u32 nb2;           // fine buckets per L1 bucket
     u32 lnb1;          // log2(L1 buckets), 0..8
     u32 tagged;        // 1 for k = 64: slot index mod 4 carries the key's last base
+    u32 both;          // 1: the table may hold ANY orientation of a k-mer (keys inserted verbatim through the ABI), not only
+                       // the hash-rule one: strand-agnostic lookups (table_find_either) must probe both, always
     GK_HD u64 nseg() const { return (u64)nb2 << lnb1; }
     GK_HD u64 capacity() const { return nseg() << SegBits<W>::value; }
 };
@@ -232,6 +234,9 @@ struct Counters {      // device-resident, one per map
     unsigned long long size;        // live keys
     unsigned long long occurrences; // windows counted by the last count kernel
     u32 error;                      // 1 = a probe ran a whole segment (capacity exhausted)
+    u32 format;                     // 1 = a device record's length byte exceeded the declared read length (clamped)
+    unsigned long long sample_claims;   // keys the distinct-key sample has admitted since the last clear
+    u32 noncanon;                   // 1 = a key inserted VERBATIM was not the hash-rule orientation of its k-mer (sticky until clear)
     u32 pad;
 };
 
@@ -382,11 +387,15 @@ template <int W> GK_D Kmer<W> slot_key(const Slot<W> *slots, u64 i, u32 tagged) 
 // are filed under rc x and vice versa (FreqFilter.scala:31-32) — then both are probed, the
 // numerically smaller orientation first so that every caller resolves a tie pair to the same slot.
 // Returns the slot (or -1) and whether the stored key is x itself (fwd) or its reverse complement.
+// A table that took verbatim keys (Table::both) can hold either orientation of ANY k-mer — the reference's `contains`
+// probes both unconditionally — so there the two-probe form is the rule, with the same order.
 template <int W> GK_D i64 table_find_either(const Table<W> &t, Kmer<W> x, int k, bool *fwd) {
     Kmer<W> rc = revcomp(x, k);
     i32 hx = ref_hash(x), hr = ref_hash(rc);
-    if (hx < hr) { *fwd = true; return table_find(t, x); }
-    if (hx > hr) { *fwd = false; return table_find(t, rc); }
+    if (!t.both) {
+        if (hx < hr) { *fwd = true; return table_find(t, x); }
+        if (hx > hr) { *fwd = false; return table_find(t, rc); }
+    }
     bool x_first = !kmer_less(rc, x);
     i64 s = table_find(t, x_first ? x : rc);
     if (s >= 0) { *fwd = x_first; return s; }

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(BLOCK) void k_classify(Table<W> t, int k, unsigned 
             const Kmer<W> x = (j & 1) ? append_base(y, j >> 1, k) : prepend_base(j >> 1, y, k);
             const Kmer<W> rc = revcomp(x, k);
             const i32 hx = ref_hash(x), hr = ref_hash(rc);
-            if (hx == hr && !(x == rc)) ties |= 1u << j;            // both strands may be stored: slow path below
+            if ((hx == hr || t.both) && !(x == rc)) ties |= 1u << j;   // both strands may be stored: slow path below
             q[j] = hx < hr ? x : rc;
             const u64 h = slot_hash(q[j]);
             qseg[j] = t.slots + ((u64)seg_of(t, h) << SegBits<W>::value);
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(BLOCK) void k_classify(Table<W> t, int k, unsigned 
         // is marked SECONDARY so the pair yields one pair of nodes
         Kmer<W> rc = revcomp(y, k);
         bool secondary = false;
-        if (ref_hash(y) == ref_hash(rc) && !(y == rc) && kmer_less(rc, y) && table_find(t, rc) >= 0) secondary = true;
+        if ((t.both || ref_hash(y) == ref_hash(rc)) && !(y == rc) && kmer_less(rc, y) && table_find(t, rc) >= 0) secondary = true;
         if (secondary) aux |= AUX_SECONDARY;
         s->aux = aux;
         if (term && !secondary) cnt++;
@@ -931,7 +931,9 @@ static int graph_build_index(gk_graph *g) {
 
 template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
     gk_ctx *ctx = m->ctx;
-    Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u};
+    // (m->dirty: keys were inserted verbatim and at least one was not its k-mer's hash-rule orientation — the reference's
+    //  `contains` probes both strands unconditionally, Graph.scala:270; so does every lookup below then)
+    Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u, m->dirty ? 1u : 0u};
     const int k = m->k;
     unsigned long long *d_cnt = nullptr;     // [0] terminals [1] cursor [2] edges [3] ecursor [4] pool cursor
     u32 *d_err = nullptr, *slot_node = nullptr;
@@ -987,8 +989,7 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
     // 3. unitigs: measure, reserve the sequence pool, emit.  One lane per edge walking base by base
     //    (k_walk) when edges are short; pointer jumping when they are long (see k_pj_* above).
     if (nE) {
-        const char *force = getenv("GK_GRAPH_UNITIGS");        // "walk" | "pj": test hook
-        const bool use_pj = force ? !strcmp(force, "pj") : (m->size / std::max<u64>(nE, 1) >= 16);
+        const bool use_pj = ctx->hook_unitigs ? ctx->hook_unitigs == 2 : (m->size / std::max<u64>(nE, 1) >= 16);   // (hook: gk_ctx_set_option "graph_unitigs")
         PjState *stA = nullptr, *stB = nullptr;
         u64 *active = nullptr;
         u64 n_active = 0;

@@ -15,8 +15,27 @@ struct gk_ctx {
     hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // phase boundaries of the partitioned path
     int cu_count = 256;
     void *skm_counts = nullptr;      // device scratch of gk_shard_superkmers_dev (cursors, counts, overflow flag)
+    uint32_t *d_flags = nullptr;     // [0] = a device record's length byte exceeded the declared read length (kernels without a map)
+    // test / A-B hooks, read from the environment ONCE here (never on a hot path; a stray variable in the host JVM
+    // cannot flip behaviour mid-run): GK_TEST_NO_RESERVE, GK_HOST_RAGGED, GK_PART_EXACT, GK_GRAPH_UNITIGS
+    bool hook_no_reserve = false, hook_host_ragged = false, hook_part_exact = false;
+    int hook_unitigs = 0;            // 0 auto, 1 walk, 2 pointer jumping
     std::string err;
 };
+
+namespace gk {
+// A stream of `.bin` records resident in HBM (PairedEndData.scala:20-36): fixed stride (off == nullptr) or an offset
+// table built by the host while it walked the framing.  max_len = the longest read the buffers downstream are sized
+// for: kernels clamp a larger length byte to it and raise the format flag (gk_tile.h WindowLimits).
+struct ReadSrc {
+    const uint8_t *rec = nullptr;
+    uint64_t nreads = 0;
+    const uint32_t *off = nullptr;
+    uint32_t stride = 0;
+    int group = 64;          // lanes per read in the window loops (64 reads, 32/16 short records)
+    int max_len = 255;
+};
+}
 
 namespace gk { struct PartScratch; }
 
@@ -32,7 +51,19 @@ struct gk_map {
     uint64_t tombstones = 0;
     uint64_t total_occurrences = 0;
     uint64_t grows = 0;
-    bool skewed = false;         // a batch overflowed the pipeline's regions and spill list: auto mode stays on the direct path
+    bool skewed = false;         // a batch overflowed the pipeline's L1 regions and spill list (pathological skew): auto mode stays on the direct path
+    bool dirty = false;          // the table may hold keys that are not the hash-rule orientation of their k-mer (verbatim inserts):
+                                 // Graph.buildGraph's `contains` then probes both strands, as the reference does (Graph.scala:270)
+    bool sample_dirty = false;   // the distinct-key sample holds keys: gk_map_clear must reset it
+    void *d_scratch = nullptr;   // pooled device scratch of the point-query / scan entry points (get_batch, filter_lt, export)
+    size_t scratch_bytes = 0;
+    bool repeats = false;        // over-provisioned segment regions spilled: this data has many repeats, use the exact fine level
+    // distinct-key sample (gk_partition.hip: Sampler): 1/1024 of the distinct keys offered since the last clear
+    uint64_t *d_sample = nullptr;
+    uint64_t sample_mask = 0;
+    uint64_t sample_claims_seen = 0;     // sample claims already accounted for by earlier batches
+    uint64_t est_distinct_last = 0;      // the last batch's estimate of NEW distinct keys (gk_map_stats)
+    uint64_t max_batch_keys = 0;         // 0 = default: windows per partitioned batch when the call's reads exceed the table's room
     float last_count_ms = 0.f;
     uint64_t last_count_occ = 0;
     // staging buffer reused by host-fed count_reads
@@ -88,10 +119,24 @@ int map_reserve(gk_map *m, uint64_t extra_keys);     // grow so that size+extra 
 int map_sync_counters(gk_map *m);                    // refresh m->size, detect device-side error flag
 int map_materialize(gk_map *m);                      // run a deferred clear so that the slots are valid
 int map_add_keys_direct(gk_map *m, const uint64_t *d_keys, uint64_t n);   // k_add_keys on device keys (W words each)
+int map_insert_keys_dev(gk_map *m, const uint64_t *d_keys, uint64_t n, bool verbatim);   // update(key, 1, _+1) for device keys, either path
+void *map_scratch(gk_map *m, size_t bytes);          // pooled scratch (grown, never shrunk); nullptr + error set on failure
 // partitioned path (part_count may return PART_RETRY_DIRECT: take the direct path for this batch)
 constexpr int PART_RETRY_DIRECT = 1;
-int part_count(gk_map *m, PartScratch **pps, const uint8_t *d_rec, uint64_t nreads, const uint32_t *d_off, uint32_t stride, int group,
-               const uint64_t *d_keys, uint64_t nkeys_in, uint64_t nkeys_bound, bool from_empty);
+// estimate: keep the distinct-key sample and wait for it between the two partition levels — the table is then sized for the
+// batch's NEW DISTINCT keys (and may be replaced, same lnb1) instead of having been sized for its windows up front;
+// fine_exact: take the exact (range-matrix) fine level even where over-provisioned segment regions could be tried
+// check_canon: the keys come verbatim from the caller: note in Counters::noncanon if one is not its k-mer's hash-rule orientation
+// grow_ahead: when the table has to grow for this batch, the call still holds (grow_ahead - 1) x as many windows after it:
+// leave room for part of what they will bring, so that the next batch does not rehash what this one just built
+struct PartPlan { bool estimate = false; bool fine_exact = false; bool check_canon = false; double grow_ahead = 1.0; };
+int part_count(gk_map *m, PartScratch **pps, const ReadSrc &src, const uint64_t *d_keys, uint64_t nkeys_in, uint64_t nkeys_bound,
+               bool from_empty, const PartPlan &plan);
+int map_ensure_sample(gk_map *m);                    // allocate the distinct-key sample set on first use
+// if the table cannot take `new_distinct` more keys, grow it (rehash, or plain re-allocation from empty) for `size_for` more
+int map_make_room(gk_map *m, uint64_t new_distinct, uint64_t size_for, bool from_empty);
+uint64_t part_max_slots(int W);                      // largest table the partitioned path can address
+int ctx_check_format(gk_ctx *ctx);                   // GK_E_FORMAT (and reset) if a map-less kernel raised ctx->d_flags[0]
 // lanes per read in the window loops: 64 for reads, 32/16 for short records (super-k-mers)
 inline int lanes_per_read(int max_windows) { return max_windows > 32 ? 64 : max_windows > 16 ? 32 : 16; }
 bool part_supported(const gk_map *m);

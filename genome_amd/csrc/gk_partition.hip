@@ -9,24 +9,33 @@
 // happens in LDS:
 //
 //   P1 k_part_hist1     source -> 256-bin histogram of the L1 bucket (top bits of the slot hash)
-//   -- k_part_prefix1   exclusive scan (1 workgroup): L1 region bases, chunk table for P3/P4
+//   -- k_part_prefix1   exclusive scan (1 workgroup): L1 region bases, chunk / range tables for P3/P4
 //   P2 k_part_scatter1  source -> keys written into their L1 region (tile histogram in LDS, one
 //                       global atomic per (tile, bucket) reserves a run, lanes fill it by LDS rank)
-//   P3 k_part_hist2     L1 region chunks -> per-segment histogram          (skipped if nb2 == 1)
-//   -- k_part_prefix2   per L1 bucket scan -> fine (per-segment) bases
-//   P4 k_part_scatter2  L1 region chunks -> keys in segment order
+//   P3 k_part_hist2r    L1 region, cut into RANGES of <= 16 chunks: per-range histogram of the fine
+//                       bucket (= segment inside the L1 bucket) -> one row of the range matrix
+//   -- k_part_scan2     down every column of the matrix: row r gets the keys of its bin in EARLIER
+//                       ranges, the column total is the segment's key count;  k_part_prefix2: segment bases
+//   P4 k_part_scatter2  L1 region chunks -> keys in segment order.  EXACT fine level: a range keeps a
+//                       running destination per bin in LDS (from the matrix) — no global atomics;
+//                       OVER-PROVISIONED fine level: one returning atomic per (chunk, bin) on a fixed region
 //   P5 k_seg_insert     one workgroup per segment: load the segment into LDS (or start from
 //                       EMPTY when the table is known to be empty), insert the segment's keys with
-//                       LDS atomics (same probe sequence as gk::table_add; an unbounded one-CAS-per-step
-//                       probe when the segment provably keeps a free slot), store it back.
+//                       LDS atomics (same probe sequence as gk::table_add), store it back.
 //
-// Two forms.  EXACT (ragged read streams): all five passes; the histograms size every region
-// exactly.  OVER-PROVISIONED (fixed-stride records, key arrays — the key count is known up front):
-// hashed keys spread binomially, so every L1 bucket and every segment gets a fixed region of
-// mean + 8 sigma + slack keys, P1 and P3 disappear, and P2 (k_op_scatter1_reads) extracts each window
-// ONCE, parking the tile's keys in LDS while it counts and reserves.  Keys that do not fit a region
-// (heavy hitters) go to a spill list replayed through the direct path after P5; if the spill list
-// overflows too, only scratch has been touched and the whole batch takes the direct path.
+// Three forms.
+//   EXACT (ragged read streams): all passes; the histograms size every region exactly.
+//   OVER-PROVISIONED (fixed-stride records, key arrays — the key count is known up front; near-distinct
+//     keys): hashed keys spread binomially, so every L1 bucket and every segment gets a fixed region of
+//     mean + 8 sigma + slack keys, P1 and P3 disappear, and P2 (k_op_scatter1_reads) extracts each window
+//     ONCE, parking the tile's keys in LDS while it counts and reserves.  Keys that do not fit a region
+//     go to a spill list replayed through the direct path after P5.
+//   HYBRID (fixed-stride records / key arrays with many REPEATS — sequencing coverage): L1 regions
+//     over-provisioned (bucket sizes stay balanced: thousands of k-mers per bucket), fine level exact
+//     through P3, because a segment holds a handful of high-multiplicity k-mers and its key count is
+//     anything but binomial.  P2 also keeps a 1/1024 hash SAMPLE of the distinct keys it has seen
+//     (a small device set that lives as long as the map's contents), from which the host learns how many NEW
+//     distinct keys the batch brings and sizes the table for them before P4 — not for its windows.
 //
 // The source is either a `.bin` read stream (extract + canonicalise on the fly, FreqFilter.scala:28-36)
 // or an array of already-routed keys (the owner side of the all-to-all).  Results are identical
@@ -53,30 +62,58 @@ static constexpr int KEYS_PER_THREAD = 8;
 static constexpr int PTILE_READS = 256;     // reads per LDS tile in P1/P2 (runs of ~120 keys per bucket)
 static constexpr int PTILE_WORDS = PTILE_READS * 65 / 4 + 64;
 static constexpr int TILE2 = PBLOCK * KEYS_PER_THREAD;   // keys per chunk in P3/P4
-static constexpr u32 MAX_NB2 = 4096;        // LDS bound in P3/P4 (12 B per fine bucket on top of the sorted chunk)
+static constexpr u32 MAX_NB2 = 4096;        // LDS bound in P3/P4 (16 B per fine bucket on top of the sorted chunk)
+static constexpr u32 MAX_RANGE_CHUNKS = 16; // a range = up to 16 consecutive chunks of one L1 bucket (64 Ki keys)
+
+// The distinct-key SAMPLE: a key belongs to it iff bits 11..20 of its slot hash are zero (1 key in 1024, independent
+// of the bits that pick its segment and its start slot); the set stores the 64-bit slot hash itself (a bijection of
+// the key for k <= 31, a 64-bit fingerprint of it for k >= 34).  Claims since the last gk_map_clear x 1024 estimate
+// the distinct keys the map has been offered.
+static constexpr u32 SAMPLE_SHIFT = 11, SAMPLE_MASK = 1023u;
+struct Sampler {
+    u64 *set;                       // nullptr: sampling off
+    u64 mask;                       // capacity - 1 (power of two)
+    unsigned long long *claims;     // Counters::sample_claims
+};
+__device__ __forceinline__ u32 sample_key(const Sampler &sp, u64 h) {
+    if (!sp.set || ((h >> SAMPLE_SHIFT) & SAMPLE_MASK) != 0u || h == ~0ull) return 0u;
+    u64 i = (h >> 21) & sp.mask;
+    for (u32 n = 0; n < 4096u; n++) {                 // bounded: a full set stops learning (the host then assumes "all distinct")
+        const u64 old = atomicCAS(reinterpret_cast<unsigned long long *>(&sp.set[i]), ~0ull, (unsigned long long)h);
+        if (old == ~0ull) return 1u;
+        if (old == h) return 0u;
+        i = (i + 1) & sp.mask;
+    }
+    return 0u;
+}
 
 struct PartArrays {
     unsigned long long *hist1;      // [256]
-    unsigned long long *l1_base;    // [257]
+    unsigned long long *l1_base;    // [257] dense prefix of the keys kept per L1 bucket (= region bases in exact mode)
     unsigned long long *cursor1;    // [256]
     unsigned long long *cbase;      // [257] chunk prefix
-    u32 *hist2;                     // [nseg]
+    unsigned long long *rbase;      // [257] range prefix
+    u32 *hist2;                     // [nseg] keys per segment (exact fine level)
     unsigned long long *fine_base;  // [nseg + 1]
-    u32 *cursor2;                   // [nseg]
+    u32 *cursor2;                   // [nseg] (over-provisioned fine level)
+    u32 *rmat;                      // [nranges x nb2] range matrix (exact fine level)
     u32 *failed;                    // [nseg] list of segments that overflowed
     u32 *n_failed;
-    // over-provisioned mode (op = 1): no histogram passes; bucket b owns the fixed region
-    // [b * cap, (b + 1) * cap) of the key buffer and whatever does not fit goes to the spill list
-    int op;
+    // op1 = 1: L1 bucket b owns the fixed region [b * cap1, (b + 1) * cap1) of bufA (no P1); op2 = 1: segment s owns
+    // the fixed region [s * cap2, (s + 1) * cap2) of bufB (no P3).  What does not fit goes to the spill list.
+    int op1, op2;
     unsigned long long cap1, cap2;  // keys per L1 region / per segment region
-    u32 stripe_nb1;                 // over-provisioned mode: number of L1 regions interleaved in bufA (see l1_slot)
+    u32 stripe_nb1;                 // op1: number of L1 regions interleaved in bufA (see l1_slot)
+    u32 range_chunks;               // chunks per range (exact fine level)
     u64 *spill;                     // [spill_cap * W]
     unsigned long long *nspill;
     unsigned long long spill_cap;
     u32 *overflow;                  // spill list itself overflowed: abandon the pipeline (scratch only so far)
+    u32 *noncanon;                  // key-array source taken verbatim from the caller: flag keys that are not canonical (nullptr: trusted)
+    int k;
 };
-__device__ __forceinline__ u64 l1_begin(const PartArrays &a, u32 b) { return a.op ? 0ull : a.l1_base[b]; }
-// Over-provisioned mode: where key number `pos` of L1 region `b` lives in bufA.  From 1.5 GB up (part_prepare sets
+__device__ __forceinline__ u64 l1_begin(const PartArrays &a, u32 b) { return a.op1 ? 0ull : a.l1_base[b]; }
+// Over-provisioned L1: where key number `pos` of L1 region `b` lives in bufA.  From 1.5 GB up (part_prepare sets
 // stripe_nb1) the regions are INTERLEAVED in blocks of L1_BLK keys (stripe s = block s of every region), not laid end to end: every tile of P2 appends to all
 // regions at once and all regions fill at the same pace, so the pages being written are the current stripe or two
 // (8-16 MB) instead of one page per region spread over the whole buffer — with 3.8 GB of regions laid end
@@ -86,12 +123,10 @@ __device__ __forceinline__ u64 l1_slot(const PartArrays &a, u32 b, u64 pos) {
     if (!a.stripe_nb1) return (u64)b * a.cap1 + pos;         // small buffer: end to end (no TLB pressure, and 3 % faster at C2)
     return ((pos / L1_BLK) * a.stripe_nb1 + b) * L1_BLK + (pos % L1_BLK);
 }
+// index in bufA of key `pos` of L1 bucket b, whichever way the L1 level was built
+__device__ __forceinline__ u64 l1_key_index(const PartArrays &a, u32 b, u64 pos) { return a.op1 ? l1_slot(a, b, pos) : a.l1_base[b] + pos; }
 __device__ __forceinline__ u64 l1_count(const PartArrays &a, u32 b) {
-    return a.op ? min(a.cursor1[b], a.cap1) : a.l1_base[b + 1] - a.l1_base[b];
-}
-__device__ __forceinline__ u64 fine_begin(const PartArrays &a, u64 s) { return a.op ? s * a.cap2 : a.fine_base[s]; }
-__device__ __forceinline__ u64 fine_count(const PartArrays &a, u64 s) {
-    return a.op ? min((unsigned long long)a.cursor2[s], a.cap2) : a.fine_base[s + 1] - a.fine_base[s];
+    return a.op1 ? min(a.cursor1[b], a.cap1) : a.l1_base[b + 1] - a.l1_base[b];
 }
 // Load a word that is the same for the whole workgroup and was written by an EARLIER kernel through
 // the scalar cache (constant address space): it then counts on lgkmcnt, not vmcnt, so waiting for it
@@ -99,10 +134,10 @@ __device__ __forceinline__ u64 fine_count(const PartArrays &a, u64 s) {
 template <class T> __device__ __forceinline__ T uniform_load(const T *p) {
     return *(const __attribute__((address_space(4))) T *)(p);
 }
-__device__ __forceinline__ u64 fine_begin_u(const PartArrays &a, u64 s) { return a.op ? s * a.cap2 : uniform_load(&a.fine_base[s]); }
+__device__ __forceinline__ u64 fine_begin_u(const PartArrays &a, u64 s) { return a.op2 ? s * a.cap2 : uniform_load(&a.fine_base[s]); }
 __device__ __forceinline__ u64 fine_count_u(const PartArrays &a, u64 s) {
-    return a.op ? min((unsigned long long)uniform_load(&a.cursor2[s]), a.cap2)
-                : uniform_load(&a.fine_base[s + 1]) - uniform_load(&a.fine_base[s]);
+    return a.op2 ? min((unsigned long long)uniform_load(&a.cursor2[s]), a.cap2)
+                 : uniform_load(&a.fine_base[s + 1]) - uniform_load(&a.fine_base[s]);
 }
 template <int W> __device__ __forceinline__ void spill_key(const PartArrays &a, u64 w0, u64 w1) {
     const unsigned long long si = atomicAdd(a.nspill, 1ull);
@@ -142,17 +177,30 @@ __device__ __forceinline__ void block_scan_inplace(u32 *arr, u32 n, u32 *wsum) {
     __syncthreads();
 }
 
+// workgroup total of a per-thread count -> ONE global atomic (hist0: one LDS word the caller no longer needs)
+__device__ __forceinline__ void block_add_global(u32 v, u32 *hist0, unsigned long long *dst) {
+    for (int d = 32; d; d >>= 1) v += __shfl_down(v, d);
+    __syncthreads();
+    if (threadIdx.x == 0) *hist0 = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(hist0, v);
+    __syncthreads();
+    if (threadIdx.x == 0 && *hist0) atomicAdd(dst, (unsigned long long)*hist0);
+}
+
 // ---------------------------------------------------------------------------------------------
 // P1 / P2 from a read stream
 // ---------------------------------------------------------------------------------------------
 template <int W>
 __global__ __launch_bounds__(PBLOCK) void k_part_hist1_reads(const uint8_t *__restrict__ rec, u64 nreads, const u32 *__restrict__ offsets,
-                                                            u32 stride, int k, int group, Table<W> t, unsigned long long *hist1, Counters *ctr) {
+                                                            u32 stride, int k, int group, int max_len, Table<W> t, unsigned long long *hist1,
+                                                            Sampler sp, Counters *ctr) {
     __shared__ __attribute__((aligned(16))) u32 tile[PTILE_WORDS];
     __shared__ u32 hist[256];
     if (threadIdx.x < 256) hist[threadIdx.x] = 0;
-    u32 occ = 0;
+    u32 occ = 0, claims = 0;
     const u64 ntiles = (nreads + PTILE_READS - 1) / PTILE_READS;
+    const WindowLimits lim{max_len, &ctr->format};
     for (u64 tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const u64 r0 = tl * PTILE_READS;
         const int nr = (int)min((u64)PTILE_READS, nreads - r0);
@@ -160,31 +208,28 @@ __global__ __launch_bounds__(PBLOCK) void k_part_hist1_reads(const uint8_t *__re
         __syncthreads();
         const u64 a0 = stage_tile(tile, rec, gb, ge);
         __syncthreads();
-        for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, group, [&](Kmer<W> x) {
-            atomicAdd(&hist[seg_l1(t, slot_hash(canonical(x, k)))], 1u);
+        for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, group, lim, [&](Kmer<W> x) {
+            const u64 h = slot_hash(canonical(x, k));
+            atomicAdd(&hist[seg_l1(t, h)], 1u);
+            claims += sample_key(sp, h);
             occ++;
         });
     }
     __syncthreads();
     if (threadIdx.x < 256 && hist[threadIdx.x]) atomicAdd(&hist1[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
-    // occurrences: wave-reduce, then LDS, then one atomic per workgroup
-    for (int d = 32; d; d >>= 1) occ += __shfl_down(occ, d);
-    __syncthreads();
-    if (threadIdx.x == 0) hist[0] = 0;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0 && occ) atomicAdd(&hist[0], occ);
-    __syncthreads();
-    if (threadIdx.x == 0 && hist[0]) atomicAdd(&ctr->occurrences, (unsigned long long)hist[0]);
+    block_add_global(occ, &hist[0], &ctr->occurrences);
+    if (sp.set) block_add_global(claims, &hist[0], sp.claims);
 }
 
 template <int W>
 __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_reads(const uint8_t *__restrict__ rec, u64 nreads, const u32 *__restrict__ offsets,
-                                                               u32 stride, int k, int group, Table<W> t, const unsigned long long *l1_base,
+                                                               u32 stride, int k, int group, int max_len, Table<W> t, const unsigned long long *l1_base,
                                                                unsigned long long *cursor1, u64 *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) u32 tile[PTILE_WORDS];
     __shared__ u32 hist[256];
     __shared__ unsigned long long base[256];
     const u64 ntiles = (nreads + PTILE_READS - 1) / PTILE_READS;
+    const WindowLimits lim{max_len, nullptr};            // P1 has already reported oversized length bytes
     for (u64 tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const u64 r0 = tl * PTILE_READS;
         const int nr = (int)min((u64)PTILE_READS, nreads - r0);
@@ -193,7 +238,7 @@ __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_reads(const uint8_t *_
         if (threadIdx.x < 256) hist[threadIdx.x] = 0;
         const u64 a0 = stage_tile(tile, rec, gb, ge);
         __syncthreads();
-        for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, group, [&](Kmer<W> x) {
+        for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, group, lim, [&](Kmer<W> x) {
             atomicAdd(&hist[seg_l1(t, slot_hash(canonical(x, k)))], 1u);
         });
         __syncthreads();
@@ -203,7 +248,7 @@ __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_reads(const uint8_t *_
             hist[threadIdx.x] = 0;          // becomes the rank counter
         }
         __syncthreads();
-        for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, group, [&](Kmer<W> x) {
+        for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, group, lim, [&](Kmer<W> x) {
             const Kmer<W> y = canonical(x, k);
             const u32 b = seg_l1(t, slot_hash(y));
             store_key<W>(out, base[b] + atomicAdd(&hist[b], 1u), y);
@@ -232,10 +277,13 @@ __global__ __launch_bounds__(BLOCK) void k_part_hist1_keys(const u64 *__restrict
 // kernel was bound by exactly that, whatever the run length), while a sorted write-out touches a
 // handful of lines per instruction.  LDS (dynamic): sorted keys [TILE2 * W], bin of each sorted
 // position [TILE2] u16, per-bin offset [nbins] u32, per-bin destination [nbins] u64.
-template <int W, int LEVEL>
-__device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u64 begin, u32 cnt, const Table<W> &t, u32 nbins,
+// RANGED (level 2, exact fine level): gb[] already holds this range's running destination of every bin (from the
+// range matrix), so nothing is reserved — no global atomic at all — and gb[] advances by the chunk's counts.
+template <int W, int LEVEL, bool RANGED>
+__device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u32 b1, u64 begin, u32 cnt, const Table<W> &t, u32 nbins,
                                               u64 *sorted, uint16_t *binof, u32 *off, u32 *lim, unsigned long long *gb, u32 *wsum,
-                                              const PartArrays &a, u64 bin0, u64 *__restrict__ out, GK_TARGS_DECL) {
+                                              const PartArrays &a, u64 bin0, u64 *__restrict__ out, const Sampler &sp, u32 &claims,
+                                              GK_TARGS_DECL) {
     Kmer<W> key[KEYS_PER_THREAD];
     u32 bin[KEYS_PER_THREAD], rank[KEYS_PER_THREAD];
     for (u32 b = threadIdx.x; b < nbins; b += PBLOCK) off[b] = 0;
@@ -247,7 +295,7 @@ __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u64 be
     for (int j = 0; j < KEYS_PER_THREAD; j++) {
         const u32 i = threadIdx.x + j * PBLOCK;
         const u64 src = begin + (i < cnt ? i : cnt - 1);
-        key[j] = load_key<W>(in, LEVEL == 2 && a.op ? l1_slot(a, (u32)(bin0 / nbins), src) : src);
+        key[j] = load_key<W>(in, LEVEL == 2 ? l1_key_index(a, b1, src) : src);
     }
 #pragma unroll
     for (int j = 0; j < KEYS_PER_THREAD; j++) {
@@ -257,6 +305,10 @@ __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u64 be
             const u64 h = slot_hash(key[j]);
             bin[j] = LEVEL == 1 ? seg_l1(t, h) : seg_fine(t, h);
             rank[j] = atomicAdd(&off[bin[j]], 1u);             // rank inside its bin
+            if (LEVEL == 1) {
+                claims += sample_key(sp, h);
+                if (a.noncanon && !(canonical(key[j], a.k) == key[j])) *a.noncanon = 1u;
+            }
         }
     }
     GK_TICK(1);
@@ -265,15 +317,15 @@ __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u64 be
     for (u32 b = threadIdx.x; b < nbins; b += PBLOCK) {        // reserve the bin's run in the output
         const u32 c = off[b];
         u32 fit = c;
-        if (c) {
+        if (c && !RANGED) {
             const unsigned long long at = LEVEL == 1 ? atomicAdd(&a.cursor1[b], (unsigned long long)c)
                                                      : (unsigned long long)atomicAdd(&a.cursor2[bin0 + b], c);
-            if (a.op) {
+            if (LEVEL == 1 ? a.op1 : a.op2) {
                 const unsigned long long cap = LEVEL == 1 ? a.cap1 : a.cap2;
                 gb[b] = LEVEL == 1 ? at : (bin0 + b) * cap + at;        // level 1: position inside the region (l1_slot maps it)
                 fit = at >= cap ? 0u : (u32)min((unsigned long long)c, cap - at);
             } else {
-                gb[b] = (LEVEL == 1 ? a.l1_base[b] : a.fine_base[bin0 + b]) + at;
+                gb[b] = a.l1_base[b] + at;                              // level 1, exact
             }
         }
         lim[b] = fit;
@@ -294,12 +346,15 @@ __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u64 be
     for (u32 i = threadIdx.x; i < cnt; i += PBLOCK) {          // linear, coalesced write-out
         const u32 b = binof[i], j = i - off[b];
         const Kmer<W> x = load_key<W>(sorted, i);
-        if (j < lim[b]) store_key<W>(out, LEVEL == 1 && a.op ? l1_slot(a, b, gb[b] + j) : gb[b] + j, x);
+        if (j < lim[b]) store_key<W>(out, LEVEL == 1 && a.op1 ? l1_slot(a, b, gb[b] + j) : gb[b] + j, x);
         else if constexpr (W == 1) spill_key<1>(a, x.lo, 0);
         else spill_key<2>(a, x.lo, x.hi);
     }
     GK_TICK(6);
     __syncthreads();
+    if (RANGED) {                                              // the range's next chunk continues where this one ended
+        for (u32 b = threadIdx.x; b < nbins; b += PBLOCK) gb[b] += lim[b];
+    }
     GK_TICK(7);
 }
 
@@ -319,19 +374,21 @@ template <int W> struct ScatterLds {
 
 template <int W>
 __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_keys(const u64 *__restrict__ keys, u64 n, Table<W> t, PartArrays a,
-                                                               u64 *__restrict__ out) {
+                                                               u64 *__restrict__ out, Sampler sp) {
     extern __shared__ unsigned long long lds_dyn1[];
     ScatterLds<W> L(lds_dyn1, 256u);
     const u64 nchunks = (n + TILE2 - 1) / TILE2;
+    u32 claims = 0;
     GK_T0();
     for (u64 c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const u64 begin = c * TILE2;
         const u32 cnt = (u32)min((u64)TILE2, n - begin);
-        scatter_chunk<W, 1>(keys, begin, cnt, t, 256u, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a, 0, out, GK_TARGS);
+        scatter_chunk<W, 1, false>(keys, 0u, begin, cnt, t, 256u, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a, 0, out, sp, claims, GK_TARGS);
     }
+    if (sp.set) block_add_global(claims, &L.off[0], sp.claims);
 }
 
-// P2 of the over-provisioned mode for fixed-stride records: ONE window-extraction pass.  The tile's
+// P2 of the over-provisioned L1 level for fixed-stride records: ONE window-extraction pass.  The tile's
 // canonical keys and their L1 buckets are parked in LDS while the per-bucket counts are built, the
 // bucket regions are reserved (one global atomic per (tile, bucket)), then the keys go out.  No P1.
 #ifndef GK_OP_CAP
@@ -342,15 +399,17 @@ static constexpr int OP_TILE_READS = 128;
 static constexpr int OP_TILE_WORDS = OP_TILE_READS * 65 / 4 + 64;
 template <int W>
 __global__ __launch_bounds__(PBLOCK) void k_op_scatter1_reads(const uint8_t *__restrict__ rec, u64 nreads, u32 stride, int k, int group,
-                                                              int rs /* reads per tile */, int nk_max, Table<W> t, PartArrays a,
-                                                              Counters *ctr, u64 *__restrict__ out) {
+                                                              int rs /* reads per tile */, int max_len, Table<W> t, PartArrays a,
+                                                              Sampler sp, Counters *ctr, u64 *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) u32 tile[OP_TILE_WORDS];
     __shared__ u64 flat[OP_CAP];
     __shared__ uint16_t fbin[OP_CAP / W];      // 0xffff = hole (bucket ids use all 256 byte values)
     __shared__ u32 hist[256], rank[256], lim[256];
     __shared__ unsigned long long gb[256];
-    u32 occ = 0;
+    u32 occ = 0, claims = 0;
+    const int nk_max = max_len - k + 1;         // the host sized rs so that rs * nk_max keys fit `flat`; lengths are clamped to max_len
     const u64 ntiles = (nreads + rs - 1) / rs;
+    const WindowLimits wl{max_len, &ctr->format};
     GK_T0();
     for (u64 tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const u64 r0 = tl * rs;
@@ -363,13 +422,15 @@ __global__ __launch_bounds__(PBLOCK) void k_op_scatter1_reads(const uint8_t *__r
         const u64 a0 = stage_tile(tile, rec, r0 * stride, (r0 + nr) * stride);
         __syncthreads();
         GK_TICK(0);
-        for_each_window_at<W>(tile, a0, r0, nr, stride, k, group, [&](int r, int p, Kmer<W> x) {
+        for_each_window_at<W>(tile, a0, r0, nr, stride, k, group, wl, [&](int r, int p, Kmer<W> x) {
             const Kmer<W> y = canonical(x, k);
-            const u32 b = seg_l1(t, slot_hash(y));
+            const u64 h = slot_hash(y);
+            const u32 b = seg_l1(t, h);
             const u32 i = (u32)(r * nk_max + p);
             store_key<W>(flat, i, y);
             fbin[i] = (uint16_t)b;
             atomicAdd(&hist[b], 1u);
+            claims += sample_key(sp, h);
             occ++;
         });
         GK_TICK(1);
@@ -399,36 +460,34 @@ __global__ __launch_bounds__(PBLOCK) void k_op_scatter1_reads(const uint8_t *__r
         GK_TICK(4);
     }
     GK_TFLUSH(0);
-    for (int d = 32; d; d >>= 1) occ += __shfl_down(occ, d);
-    __syncthreads();
-    if (threadIdx.x == 0) hist[0] = 0;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0 && occ) atomicAdd(&hist[0], occ);
-    __syncthreads();
-    if (threadIdx.x == 0 && hist[0]) atomicAdd(&ctr->occurrences, (unsigned long long)hist[0]);
+    block_add_global(occ, &hist[0], &ctr->occurrences);
+    if (sp.set) block_add_global(claims, &hist[0], sp.claims);
 }
 
-// exclusive scan of the 256 L1 counts; chunk table for P3/P4 (chunks never straddle L1 buckets)
+// exclusive scan of the 256 L1 counts; chunk and range tables for P3/P4 (chunks and ranges never straddle L1 buckets)
 __global__ __launch_bounds__(256) void k_part_prefix1(PartArrays a, u32 nb1) {
-    __shared__ unsigned long long s[256], c[256];
+    __shared__ unsigned long long s[256], c[256], r[256];
     const u32 i = threadIdx.x;
-    s[i] = i < nb1 ? (a.op ? min(a.cursor1[i], a.cap1) : a.hist1[i]) : 0;
+    s[i] = i < nb1 ? (a.op1 ? min(a.cursor1[i], a.cap1) : a.hist1[i]) : 0;
     c[i] = (s[i] + TILE2 - 1) / TILE2;
+    r[i] = (c[i] + a.range_chunks - 1) / a.range_chunks;
     __syncthreads();
     if (i == 0) {
-        unsigned long long acc = 0, cacc = 0;
+        unsigned long long acc = 0, cacc = 0, racc = 0;
         for (u32 b = 0; b < 256; b++) {
-            const unsigned long long v = s[b], cv = c[b];
-            if (!a.op) a.l1_base[b] = acc;
+            const unsigned long long v = s[b], cv = c[b], rv = r[b];
+            a.l1_base[b] = acc;
             a.cbase[b] = cacc;
-            acc += v; cacc += cv;
+            a.rbase[b] = racc;
+            acc += v; cacc += cv; racc += rv;
         }
-        if (!a.op) a.l1_base[256] = acc;
+        a.l1_base[256] = acc;
         a.cbase[256] = cacc;
+        a.rbase[256] = racc;
     }
 }
 
-// which L1 bucket does chunk `c` belong to (binary search over the 257-entry chunk prefix)
+// which L1 bucket does chunk / range `c` belong to (binary search over a 257-entry prefix)
 __device__ __forceinline__ u32 chunk_bucket(const unsigned long long *cbase, u64 c) {
     u32 lo = 0, hi = 256;
     while (hi - lo > 1) {
@@ -438,34 +497,71 @@ __device__ __forceinline__ u32 chunk_bucket(const unsigned long long *cbase, u64
     return lo;
 }
 
+// ---------------------------------------------------------------------------------------------
+// P3 (exact fine level): per-RANGE histogram of the fine bucket -> one row of the range matrix
+// ---------------------------------------------------------------------------------------------
+struct RangeGeom { u32 b1; u64 begin; u32 cnt; };      // L1 bucket, first key inside it, number of keys
+__device__ __forceinline__ RangeGeom range_geom(const unsigned long long *s_rbase, const unsigned long long *s_l1n, u64 r, u32 range_chunks) {
+    RangeGeom g;
+    g.b1 = chunk_bucket(s_rbase, r);
+    g.begin = (r - s_rbase[g.b1]) * (u64)range_chunks * TILE2;
+    g.cnt = (u32)min((u64)range_chunks * TILE2, s_l1n[g.b1] - g.begin);
+    return g;
+}
+
 template <int W>
-__global__ __launch_bounds__(PBLOCK) void k_part_hist2(const u64 *__restrict__ bufA, Table<W> t, PartArrays a, u64 max_chunks) {
+__global__ __launch_bounds__(PBLOCK) void k_part_hist2r(const u64 *__restrict__ bufA, Table<W> t, PartArrays a, u64 max_ranges) {
     extern __shared__ u32 lds_hist[];
-    const u64 total_chunks = a.cbase[256];
-    for (u64 c = blockIdx.x; c < total_chunks && c < max_chunks; c += gridDim.x) {
-        const u32 b1 = chunk_bucket(a.cbase, c);
-        const u64 bsize = l1_count(a, b1);
-        const u64 begin = (c - a.cbase[b1]) * TILE2;
-        const u32 cnt = (u32)min((u64)TILE2, bsize - begin);
+    __shared__ unsigned long long s_rbase[257], s_l1n[256];
+    for (u32 b = threadIdx.x; b < 257u; b += PBLOCK) s_rbase[b] = a.rbase[b];
+    for (u32 b = threadIdx.x; b < 256u; b += PBLOCK) s_l1n[b] = b < (1u << t.lnb1) ? l1_count(a, b) : 0ull;
+    __syncthreads();
+    const u64 total = min((u64)s_rbase[256], max_ranges);
+    for (u64 r = blockIdx.x; r < total; r += gridDim.x) {
+        const RangeGeom g = range_geom(s_rbase, s_l1n, r, a.range_chunks);
         for (u32 b = threadIdx.x; b < t.nb2; b += PBLOCK) lds_hist[b] = 0;
         __syncthreads();
-        {
+        for (u32 cb = 0; cb < g.cnt; cb += TILE2) {
+            const u32 cnt = min((u32)TILE2, g.cnt - cb);
             Kmer<W> key[KEYS_PER_THREAD];
-            const u64 kb = l1_begin(a, b1) + begin;
 #pragma unroll
             for (int j = 0; j < KEYS_PER_THREAD; j++) {
                 const u32 i = threadIdx.x + j * PBLOCK;
-                key[j] = load_key<W>(bufA, kb + (i < cnt ? i : cnt - 1));
+                key[j] = load_key<W>(bufA, l1_key_index(a, g.b1, g.begin + cb + (i < cnt ? i : cnt - 1)));
             }
 #pragma unroll
             for (int j = 0; j < KEYS_PER_THREAD; j++)
                 if (threadIdx.x + j * PBLOCK < cnt) atomicAdd(&lds_hist[seg_fine(t, slot_hash(key[j]))], 1u);
         }
         __syncthreads();
-        for (u32 b = threadIdx.x; b < t.nb2; b += PBLOCK)
-            if (lds_hist[b]) atomicAdd(&a.hist2[(u64)b1 * t.nb2 + b], lds_hist[b]);
+        u32 *row = a.rmat + r * t.nb2;
+        for (u32 b = threadIdx.x; b < t.nb2; b += PBLOCK) row[b] = lds_hist[b];
         __syncthreads();
     }
+}
+
+// down every column (L1 bucket b1 = blockIdx.y, fine bucket b) of the range matrix: each row gets the keys of its
+// bin that EARLIER ranges hold (its write offset inside the segment's run), the total is the segment's key count
+__global__ __launch_bounds__(256) void k_part_scan2(PartArrays a, u32 nb2) {
+    const u32 b1 = blockIdx.y, b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nb2) return;
+    const u64 r0 = a.rbase[b1], r1 = a.rbase[b1 + 1];
+    u32 run = 0;
+    u64 r = r0;
+    for (; r + 4 <= r1; r += 4) {                     // four independent loads in flight per step
+        u32 *p = a.rmat + r * nb2 + b;
+        const u32 v0 = p[0], v1 = p[nb2], v2 = p[2ull * nb2], v3 = p[3ull * nb2];
+        p[0] = run; run += v0;
+        p[nb2] = run; run += v1;
+        p[2ull * nb2] = run; run += v2;
+        p[3ull * nb2] = run; run += v3;
+    }
+    for (; r < r1; r++) {
+        u32 *p = a.rmat + r * nb2 + b;
+        const u32 v = *p;
+        *p = run; run += v;
+    }
+    a.hist2[(u64)b1 * nb2 + b] = run;
 }
 
 // one workgroup per L1 bucket: fine_base[seg] = l1_base[b1] + exclusive scan of hist2 inside b1
@@ -494,29 +590,43 @@ __global__ __launch_bounds__(256) void k_part_prefix2(PartArrays a, u32 nb1, u32
     if (b1 == nb1 - 1 && threadIdx.x == 0) a.fine_base[(u64)nb1 * nb2] = s_carry;
 }
 
-template <int W>
-__global__ __launch_bounds__(PBLOCK) void k_part_scatter2(const u64 *__restrict__ bufA, Table<W> t, PartArrays a, u64 max_chunks,
+// ---------------------------------------------------------------------------------------------
+// P4: L1 regions -> keys in segment order
+// ---------------------------------------------------------------------------------------------
+template <int W, bool RANGED>
+__global__ __launch_bounds__(PBLOCK) void k_part_scatter2(const u64 *__restrict__ bufA, Table<W> t, PartArrays a, u64 max_units,
                                                           u64 *__restrict__ bufB) {
     extern __shared__ unsigned long long lds_dyn[];
     ScatterLds<W> L(lds_dyn, t.nb2);
-    // chunk table and L1 bucket extents: LDS copies (the binary search below was eight dependent global
+    // chunk / range table and L1 bucket extents: LDS copies (the binary search below was eight dependent global
     // loads per chunk: 16 % of the kernel by the phase timers)
-    __shared__ unsigned long long s_cbase[257], s_l1n[256], s_l1b[256];
-    for (u32 b = threadIdx.x; b < 257u; b += PBLOCK) s_cbase[b] = a.cbase[b];
-    for (u32 b = threadIdx.x; b < 256u; b += PBLOCK) {
-        const bool live = b < (1u << t.lnb1);
-        s_l1n[b] = live ? l1_count(a, b) : 0ull;
-        s_l1b[b] = live ? l1_begin(a, b) : 0ull;
-    }
+    __shared__ unsigned long long s_ubase[257], s_l1n[256];
+    for (u32 b = threadIdx.x; b < 257u; b += PBLOCK) s_ubase[b] = RANGED ? a.rbase[b] : a.cbase[b];
+    for (u32 b = threadIdx.x; b < 256u; b += PBLOCK) s_l1n[b] = b < (1u << t.lnb1) ? l1_count(a, b) : 0ull;
     __syncthreads();
-    const u64 total_chunks = s_cbase[256];
+    const u64 total = min((u64)s_ubase[256], max_units);
+    const Sampler nosp{nullptr, 0, nullptr};
+    u32 noclaims = 0;
     GK_T0();
-    for (u64 c = blockIdx.x; c < total_chunks && c < max_chunks; c += gridDim.x) {
-        const u32 b1 = chunk_bucket(s_cbase, c);
-        const u64 begin = (c - s_cbase[b1]) * TILE2;
-        const u32 cnt = (u32)min((u64)TILE2, s_l1n[b1] - begin);
-        scatter_chunk<W, 2>(bufA, s_l1b[b1] + begin, cnt, t, t.nb2, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a,
-                            (u64)b1 * t.nb2, bufB, GK_TARGS);
+    if constexpr (RANGED) {
+        for (u64 r = blockIdx.x; r < total; r += gridDim.x) {
+            const RangeGeom g = range_geom(s_ubase, s_l1n, r, a.range_chunks);
+            const u64 bin0 = (u64)g.b1 * t.nb2;
+            const u32 *row = a.rmat + r * t.nb2;
+            for (u32 b = threadIdx.x; b < t.nb2; b += PBLOCK) L.gb[b] = a.fine_base[bin0 + b] + row[b];
+            for (u32 cb = 0; cb < g.cnt; cb += TILE2)          // (scatter_chunk opens with a barrier: gb[] is visible)
+                scatter_chunk<W, 2, true>(bufA, g.b1, g.begin + cb, min((u32)TILE2, g.cnt - cb), t, t.nb2, L.sorted, L.binof, L.off, L.lim,
+                                          L.gb, L.wsum, a, bin0, bufB, nosp, noclaims, GK_TARGS);
+            __syncthreads();
+        }
+    } else {
+        for (u64 c = blockIdx.x; c < total; c += gridDim.x) {
+            const u32 b1 = chunk_bucket(s_ubase, c);
+            const u64 begin = (c - s_ubase[b1]) * TILE2;
+            const u32 cnt = (u32)min((u64)TILE2, s_l1n[b1] - begin);
+            scatter_chunk<W, 2, false>(bufA, b1, begin, cnt, t, t.nb2, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a,
+                                       (u64)b1 * t.nb2, bufB, nosp, noclaims, GK_TARGS);
+        }
     }
     GK_TFLUSH(8);
 }
@@ -565,6 +675,47 @@ __device__ __forceinline__ u32 lds_add_unbounded(Slot<2> *seg, u32 pos, Kmer<2> 
         i = (i + 1) & smask;
     }
 }
+// The bounded form for segments that receive more keys than they have free slots — necessarily REPEATS of far fewer
+// k-mers (sequencing coverage): look first (a plain LDS read of a hot slot is a broadcast; a failed ds_cmpst on it
+// would serialise the lanes twice, once for the compare-and-swap and once for the add), CAS only on an empty slot.
+// Key words are write-once during an insert phase, so what a plain read shows is either final or EMPTY.
+// 1 = claimed a new slot, 0 = the key was there, -1 = the segment is full.
+__device__ __forceinline__ int lds_add_look(Slot<1> *seg, u32 pos, Kmer<1> key) {
+    constexpr u32 smask = (1u << SegBits<1>::value) - 1u;
+    u32 i = pos;
+    for (u32 n = 0; n <= smask; ++n) {
+        u64 cur = seg[i].w0;
+        if (cur == KEY_EMPTY) {
+            cur = atomicCAS(reinterpret_cast<unsigned long long *>(&seg[i].w0), (unsigned long long)KEY_EMPTY, (unsigned long long)key.lo);
+            if (cur == KEY_EMPTY) return 1;
+        }
+        if (cur == key.lo) { atomicAdd(&seg[i].extra, 1u); return 0; }
+        i = (i + 1) & smask;
+    }
+    return -1;
+}
+__device__ __forceinline__ int lds_add_look(Slot<2> *seg, u32 pos, Kmer<2> key) {
+    constexpr u32 smask = (1u << SegBits<2>::value) - 1u;
+    const Stored<2> k = to_stored(key);
+    u32 i = pos;
+    for (u32 n = 0; n <= smask; ++n) {
+        u64 c0 = seg[i].w0;
+        if (c0 == KEY_EMPTY) {
+            c0 = atomicCAS(reinterpret_cast<unsigned long long *>(&seg[i].w0), (unsigned long long)KEY_EMPTY, (unsigned long long)k.w0);
+            if (c0 == KEY_EMPTY) c0 = k.w0;
+        }
+        if (c0 == k.w0) {
+            u64 c1 = seg[i].w1;
+            if (c1 == KEY_EMPTY) {
+                c1 = atomicCAS(reinterpret_cast<unsigned long long *>(&seg[i].w1), (unsigned long long)KEY_EMPTY, (unsigned long long)k.w1);
+                if (c1 == KEY_EMPTY) return 1;
+            }
+            if (c1 == k.w1) { atomicAdd(&seg[i].extra, 1u); return 0; }
+        }
+        i = (i + 1) & smask;
+    }
+    return -1;
+}
 
 #ifndef GK_SBLOCK
 #define GK_SBLOCK (GK_SEG_BITS1 <= 10 ? 256 : 512)
@@ -576,6 +727,7 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W> t, const u64 
     constexpr u32 S = 1u << SegBits<W>::value;
     constexpr u32 NVEC = S * sizeof(Slot<W>) / 16;
     constexpr int KPT = (int)(S / SBLOCK);                          // keys preloaded per thread
+    constexpr u32 KBLK = (u32)SBLOCK * KPT;                         // keys per register block (= S)
     Slot<W> *seg = reinterpret_cast<Slot<W> *>(lds_raw);
     u32 *flags = reinterpret_cast<u32 *>(lds_raw + NVEC);         // [0] claims, [1] overflow, [2] free slots found while loading
     const u64 nseg = t.nseg();
@@ -591,21 +743,23 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W> t, const u64 
         b = fine_begin_u(a, sc);
         n = s2 < nseg ? (u32)min(cnt, (u64)0xffffffffu) : 0u;
     };
-    auto request_keys = [&](Kmer<W> (&kk)[KPT], u64 b, u32 n) {
-        const u32 nk = min(n, (u32)(SBLOCK * KPT));
+    // block `blk` of a segment's keys into registers (indices clamped: branch-free, one round trip)
+    auto request_keys = [&](Kmer<W> (&kk)[KPT], u64 b, u32 n, u32 blk) {
+        const u32 first = blk * KBLK;
+        const u32 nk = n > first ? min(n - first, KBLK) : 0u;
 #pragma unroll
         for (int j = 0; j < KPT; j++) {
             const u32 i = threadIdx.x + j * SBLOCK;
-            kk[j] = load_key<W>(keys, nk ? b + (i < nk ? i : nk - 1) : 0);
+            kk[j] = load_key<W>(keys, nk ? b + first + (i < nk ? i : nk - 1) : 0);
         }
     };
     u64 kb, kbn; u32 cnt, cntn;
-    // one segment; `cur` holds its keys (requested one step earlier), `nxt` receives the next one's.
+    // one segment; `cur` holds its first key block (requested one step earlier), `nxt` receives the next segment's.
     // The two register sets swap roles from step to step (a copy would have to wait for the loads).
     auto step = [&](u64 s, Kmer<W> (&cur)[KPT], Kmer<W> (&nxt)[KPT]) {
         u64 kbnn; u32 cntnn;
         range_of(s + 2ull * gridDim.x, kbnn, cntnn);                  // two ahead: its key range
-        request_keys(nxt, kbn, cntn);                                 // one ahead: its keys
+        request_keys(nxt, kbn, cntn, 0u);                             // one ahead: its first keys
         uint4 *gseg = reinterpret_cast<uint4 *>(t.slots + (s << SegBits<W>::value));
         if (cnt == 0) {
             if (from_empty) {       // materialise the pending clear of a segment that gets no key
@@ -618,7 +772,6 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W> t, const u64 
         } else {
             __syncthreads();
             if (threadIdx.x < 3) flags[threadIdx.x] = 0;
-            const u32 nk = min(cnt, (u32)(SBLOCK * KPT));
             if (from_empty) {
 #pragma unroll
                 for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) {
@@ -640,23 +793,31 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W> t, const u64 
             __syncthreads();
             u32 claims = 0;
             bool overflow = false;
-            if (!t.tagged && cnt < (from_empty ? S : flags[2])) {     // fewer keys than free slots: cannot fill up
-#pragma unroll
-                for (int j = 0; j < KPT; j++)
-                    if (threadIdx.x + j * SBLOCK < nk) claims += lds_add_unbounded(seg, seg_pos<W>(slot_hash(cur[j])), cur[j]);
-            } else {
+            // fewer keys than free slots: cannot fill up -> unbounded one-CAS probe; more keys than that are repeats
+            // (or the table is too small): bounded look-first probe; k = 64 keeps the general tagged form
+            const int mode = t.tagged ? 2 : (cnt < (from_empty ? S : flags[2]) ? 0 : 1);
+            auto insert_block = [&](Kmer<W> (&kk)[KPT], u32 nk) {
 #pragma unroll
                 for (int j = 0; j < KPT; j++) {
-                    if (threadIdx.x + j * SBLOCK < nk) {
-                        const int r = seg_add(seg, seg_pos<W>(slot_hash(cur[j])), cur[j], 1u, LdsCas(), LdsAdd(), t.tagged);
-                        if (r < 0) overflow = true; else claims += (u32)r;
-                    }
+                    if (threadIdx.x + j * SBLOCK >= nk) continue;
+                    const u32 pos = seg_pos<W>(slot_hash(kk[j]));
+                    if (mode == 0) { claims += lds_add_unbounded(seg, pos, kk[j]); continue; }
+                    const int r = mode == 1 ? lds_add_look(seg, pos, kk[j]) : seg_add(seg, pos, kk[j], 1u, LdsCas(), LdsAdd(), t.tagged);
+                    if (r < 0) overflow = true; else claims += (u32)r;
                 }
-            }
-            for (u64 i = kb + (u64)SBLOCK * KPT + threadIdx.x; i < kb + cnt; i += SBLOCK) {   // heavy buckets (repeats)
-                const Kmer<W> kx = load_key<W>(keys, i);
-                const int r = seg_add(seg, seg_pos<W>(slot_hash(kx)), kx, 1u, LdsCas(), LdsAdd(), t.tagged);
-                if (r < 0) overflow = true; else claims += (u32)r;
+            };
+            insert_block(cur, min(cnt, KBLK));
+            if (cnt > KBLK) {                                   // heavy segments (repeats): further blocks, each requested a block ahead
+                Kmer<W> ta[KPT], tb[KPT];
+                const u32 nblk = (cnt + KBLK - 1) / KBLK;
+                request_keys(ta, kb, cnt, 1u);
+                for (u32 blk = 1; blk < nblk; blk += 2) {
+                    request_keys(tb, kb, cnt, blk + 1);         // (past the end: nk = 0, a harmless load of keys[0])
+                    insert_block(ta, min(cnt - blk * KBLK, KBLK));
+                    if (blk + 1 >= nblk) break;
+                    request_keys(ta, kb, cnt, blk + 2);
+                    insert_block(tb, min(cnt - (blk + 1) * KBLK, KBLK));
+                }
             }
             for (int d = 32; d; d >>= 1) claims += __shfl_down(claims, d);
             if ((threadIdx.x & 63) == 0 && claims) atomicAdd(&flags[0], claims);
@@ -683,7 +844,7 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W> t, const u64 
     u64 s = blockIdx.x;
     range_of(s, kb, cnt);
     range_of(s + gridDim.x, kbn, cntn);
-    request_keys(keyA, kb, cnt);
+    request_keys(keyA, kb, cnt, 0u);
     while (s < nseg) {
         step(s, keyA, keyB);
         s += gridDim.x;
@@ -700,8 +861,12 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W> t, const u64 
 namespace gk {
 
 struct PartScratch {
-    void *blob = nullptr;        // all the small arrays
+    void *blob = nullptr;        // the small per-batch arrays of the L1 level
     size_t blob_bytes = 0;
+    void *fblob = nullptr;       // the per-segment arrays of the fine level (sized after the table's final geometry is known)
+    size_t fblob_bytes = 0;
+    u32 *rmat = nullptr;         // range matrix
+    u64 rmat_words = 0;
     u64 *bufA = nullptr, *bufB = nullptr, *spill = nullptr;
     u64 bufA_keys = 0, bufB_keys = 0, spill_keys = 0;     // capacities in keys
     int W = 1;
@@ -714,146 +879,190 @@ static int grow_buf(gk_ctx *ctx, u64 **buf, u64 *have, u64 want, int W) {
     if (*have >= want) return GK_OK;
     if (*buf) GK_HIP(ctx, hipFree(*buf));
     *buf = nullptr; *have = 0;
-    GK_HIP(ctx, hipMalloc((void **)buf, std::max<u64>(want, 1) * 8 * W));
+    hipError_t e = hipMalloc((void **)buf, std::max<u64>(want, 1) * 8 * W);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ctx, GK_E_CAPACITY, "partitioned insert: cannot allocate " + std::to_string(want * 8 * W) + " bytes of key scratch: " + hipGetErrorString(e));
+    }
+    *have = want;
+    return GK_OK;
+}
+static int grow_raw(gk_ctx *ctx, void **buf, size_t *have, size_t want) {
+    if (*have >= want) return GK_OK;
+    if (*buf) GK_HIP(ctx, hipFree(*buf));
+    *buf = nullptr; *have = 0;
+    GK_HIP(ctx, hipMalloc(buf, std::max<size_t>(want, 256)));
     *have = want;
     return GK_OK;
 }
 
-static int part_prepare(gk_map *m, PartScratch *ps, u64 nkeys, bool op, PartArrays *arr) {
+// L1 level: small arrays, the key buffer bufA and the spill list
+static int part_prepare_l1(gk_map *m, PartScratch *ps, u64 nkeys, bool op1, PartArrays *arr) {
     gk_ctx *ctx = m->ctx;
-    const u64 nseg = (u64)m->nb2 << m->lnb1, nb1 = 1ull << m->lnb1;
+    const u64 nb1 = 1ull << m->lnb1;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    const size_t o_hist1 = take(256 * 8), o_l1 = take(257 * 8), o_cur1 = take(256 * 8), o_cb = take(257 * 8);
-    const size_t o_hist2 = take(nseg * 4), o_fine = take((nseg + 1) * 8), o_cur2 = take(nseg * 4), o_failed = take(nseg * 4),
+    const size_t o_hist1 = take(256 * 8), o_l1 = take(257 * 8), o_cur1 = take(256 * 8), o_cb = take(257 * 8), o_rb = take(257 * 8),
                  o_nf = take(4), o_nsp = take(8), o_ovf = take(4);
-    if (ps->blob_bytes < off) {
-        if (ps->blob) GK_HIP(ctx, hipFree(ps->blob));
-        ps->blob = nullptr; ps->blob_bytes = 0;
-        GK_HIP(ctx, hipMalloc(&ps->blob, off));
-        ps->blob_bytes = off;
-    }
+    if (int rc = grow_raw(ctx, &ps->blob, &ps->blob_bytes, off)) return rc;
     GK_HIP(ctx, hipMemsetAsync(ps->blob, 0, off, ctx->stream));
     char *b = (char *)ps->blob;
     arr->hist1 = (unsigned long long *)(b + o_hist1); arr->l1_base = (unsigned long long *)(b + o_l1);
     arr->cursor1 = (unsigned long long *)(b + o_cur1); arr->cbase = (unsigned long long *)(b + o_cb);
-    arr->hist2 = (u32 *)(b + o_hist2); arr->fine_base = (unsigned long long *)(b + o_fine);
-    arr->cursor2 = (u32 *)(b + o_cur2); arr->failed = (u32 *)(b + o_failed); arr->n_failed = (u32 *)(b + o_nf);
-    arr->nspill = (unsigned long long *)(b + o_nsp); arr->overflow = (u32 *)(b + o_ovf);
+    arr->rbase = (unsigned long long *)(b + o_rb);
+    arr->n_failed = (u32 *)(b + o_nf); arr->nspill = (unsigned long long *)(b + o_nsp); arr->overflow = (u32 *)(b + o_ovf);
+    arr->hist2 = nullptr; arr->fine_base = nullptr; arr->cursor2 = nullptr; arr->failed = nullptr; arr->rmat = nullptr;
     if (ps->W != m->W) {     // key width changed: drop the buffers
         for (u64 **bp : {&ps->bufA, &ps->bufB, &ps->spill}) { if (*bp) GK_HIP(ctx, hipFree(*bp)); *bp = nullptr; }
         ps->bufA_keys = ps->bufB_keys = ps->spill_keys = 0;
         ps->W = m->W;
     }
-    arr->op = op ? 1 : 0;
+    arr->op1 = op1 ? 1 : 0;
+    arr->op2 = 0;
+    arr->noncanon = nullptr;
+    arr->k = m->k;
     arr->cap1 = arr->cap2 = 0; arr->spill_cap = 0; arr->stripe_nb1 = 0;
-    u64 wantA = nkeys, wantB = nkeys, wantS = 0;
-    if (op) {
-        // Bucket sizes of hashed keys concentrate (binomial): mean + 8 sigma + slack never overflows
-        // for distinct-ish keys; heavy hitters (one k-mer repeated thousands of times) do, and go to
-        // the spill list, which the direct path absorbs after the segments are built.
-        const double m1 = (double)nkeys / (double)nb1, m2 = (double)nkeys / (double)nseg;
-        arr->cap1 = (u64)(m1 + 8.0 * std::sqrt(m1) + 1024.0);
-        arr->cap2 = (u64)(m2 + 8.0 * std::sqrt(m2) + 64.0);
+    // a range = up to MAX_RANGE_CHUNKS chunks, fewer when the batch is small (enough ranges to fill the chip)
+    const u64 nchunks = nkeys / TILE2 + 1;
+    arr->range_chunks = (u32)std::min<u64>(MAX_RANGE_CHUNKS, std::max<u64>(1, nchunks / ((u64)ctx->cu_count * 6)));
+    u64 wantA = nkeys, wantS = 0;
+    if (op1) {
+        // Bucket sizes of hashed keys concentrate: binomial for distinct keys (mean + 8 sigma never overflows); with
+        // repeats (coverage c: every k-mer c times) the spread is that of mean/c heavy items — a bucket holds thousands
+        // of k-mers, so 1/8 of the mean on top covers multiplicities into the thousands.  What still does not fit (a single
+        // k-mer repeated millions of times) goes to the spill list, which the direct path absorbs after the segments are built.
+        const double m1 = (double)nkeys / (double)nb1;
+        arr->cap1 = (u64)(m1 * 1.125 + 8.0 * std::sqrt(m1) + 1024.0);
         arr->spill_cap = nkeys / 16 + 65536;
         // interleave the L1 regions (l1_slot) once the buffer is big enough for P2 to thrash the TLB (measured: fine at
         // 0.96 GB, 73 % translation misses at 3.8 GB)
         const bool striped = nb1 * arr->cap1 * 8ull * m->W >= (3ull << 29);
         arr->stripe_nb1 = striped ? (u32)nb1 : 0u;
         wantA = striped ? (arr->cap1 + L1_BLK - 1) / L1_BLK * L1_BLK * nb1 : nb1 * arr->cap1;
-        wantB = nseg * arr->cap2; wantS = arr->spill_cap;
+        wantS = arr->spill_cap;
     }
     if (int rc = grow_buf(ctx, &ps->bufA, &ps->bufA_keys, wantA, m->W)) return rc;
-    if (int rc = grow_buf(ctx, &ps->bufB, &ps->bufB_keys, wantB, m->W)) return rc;
     if (int rc = grow_buf(ctx, &ps->spill, &ps->spill_keys, wantS, m->W)) return rc;
     arr->spill = ps->spill;
     return GK_OK;
 }
 
+// fine level: per-segment arrays for the table's FINAL geometry, bufB, and the range matrix (exact) / regions (op2)
+static int part_prepare_fine(gk_map *m, PartScratch *ps, u64 nkeys, bool op2, PartArrays *arr) {
+    gk_ctx *ctx = m->ctx;
+    const u64 nseg = (u64)m->nb2 << m->lnb1;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_hist2 = take(nseg * 4), o_fine = take((nseg + 1) * 8), o_cur2 = take(nseg * 4), o_failed = take(nseg * 4);
+    if (int rc = grow_raw(ctx, &ps->fblob, &ps->fblob_bytes, off)) return rc;
+    // hist2 is fully written by k_part_scan2, fine_base by k_part_prefix2; only the cursors need zeroes
+    char *b = (char *)ps->fblob;
+    arr->hist2 = (u32 *)(b + o_hist2); arr->fine_base = (unsigned long long *)(b + o_fine);
+    arr->cursor2 = (u32 *)(b + o_cur2); arr->failed = (u32 *)(b + o_failed);
+    arr->op2 = op2 ? 1 : 0;
+    u64 wantB = nkeys;
+    if (op2) {
+        GK_HIP(ctx, hipMemsetAsync(arr->cursor2, 0, nseg * 4, ctx->stream));
+        const double m2 = (double)nkeys / (double)nseg;
+        arr->cap2 = (u64)(m2 + 8.0 * std::sqrt(m2) + 64.0);
+        wantB = nseg * arr->cap2;
+    } else {
+        const u64 max_ranges = (nkeys / TILE2 + 257) / arr->range_chunks + 257;
+        const u64 words = max_ranges * m->nb2;
+        if (ps->rmat_words < words) {
+            if (ps->rmat) GK_HIP(ctx, hipFree(ps->rmat));
+            ps->rmat = nullptr; ps->rmat_words = 0;
+            GK_HIP(ctx, hipMalloc((void **)&ps->rmat, words * 4));
+            ps->rmat_words = words;
+        }
+        arr->rmat = ps->rmat;
+    }
+    return grow_buf(ctx, &ps->bufB, &ps->bufB_keys, wantB, m->W);
+}
+
 void part_scratch_free(PartScratch *ps) {
     if (!ps) return;
-    if (ps->blob) (void)hipFree(ps->blob);
-    if (ps->bufA) (void)hipFree(ps->bufA);
-    if (ps->bufB) (void)hipFree(ps->bufB);
-    if (ps->spill) (void)hipFree(ps->spill);
+    for (void *p : {ps->blob, ps->fblob, (void *)ps->rmat, (void *)ps->bufA, (void *)ps->bufB, (void *)ps->spill})
+        if (p) (void)hipFree(p);
     delete ps;
 }
 
 // returns GK_OK, an error (< 0), or PART_RETRY_DIRECT: the over-provisioned regions and the spill
 // list overflowed (extreme skew); nothing but scratch was touched, the caller takes the direct path
 template <int W>
-static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads, const u32 *d_off, u32 stride, int group,
-                    const u64 *d_keys, u64 nkeys_in, u64 nkeys_bound, bool from_empty) {
+static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d_keys, u64 nkeys_in, u64 nkeys_bound, bool from_empty,
+                    const PartPlan &plan) {
     gk_ctx *ctx = m->ctx;
     Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u};
     PartArrays a;
-    // fixed-stride records and key arrays: their key count is known exactly, so regions can be sized
-    // up front and the two histogram passes (P1, P3) dropped; ragged streams keep the exact pipeline
-    const int max_windows = d_rec && !d_off ? std::max(0, (int)(stride - 1) * 4 - m->k + 1) : 0;
-    const bool op = !d_off && !getenv("GK_PART_EXACT") && (d_keys || (max_windows > 0 && max_windows <= OP_CAP / W));
-    if (int rc = part_prepare(m, ps, nkeys_bound, op, &a)) return rc;
+    const uint8_t *d_rec = src.rec;
+    const u32 *d_off = src.off;
+    // fixed-stride records and key arrays: their key count is known exactly, so the L1 regions can be sized
+    // up front and the histogram pass P1 dropped; ragged streams keep the exact pipeline
+    const int max_windows = d_rec && !d_off ? std::max(0, src.max_len - m->k + 1) : 0;
+    const bool op1 = !d_off && !ctx->hook_part_exact && (d_keys || (max_windows > 0 && max_windows <= OP_CAP / W));
+    if (int rc = part_prepare_l1(m, ps, nkeys_bound, op1, &a)) return rc;
     const u32 nb1 = 1u << m->lnb1;
-    const u64 nseg = t.nseg();
     const int cu8 = ctx->cu_count * 8;
     const size_t lds = ((size_t)1 << SegBits<W>::value) * sizeof(Slot<W>) + 16;
     if (!ps->lds_attr_set) {
-        GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<W>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<W, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)ScatterLds<W>::bytes(MAX_NB2)));
+        GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)ScatterLds<W>::bytes(MAX_NB2)));
         GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter1_keys<W>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)ScatterLds<W>::bytes(256u)));
         GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_seg_insert<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ps->lds_attr_set = true;
     }
-    // P1 + prefix + P2
+    if (plan.estimate) { if (int rc = map_ensure_sample(m)) return rc; }
+    if (m->d_sample) m->sample_dirty = true;
+    if (plan.check_canon && d_keys) a.noncanon = &m->d_ctr->noncanon;
+    // (the sample keeps learning whenever it exists, also in batches whose estimate nobody waits for: a key it has not
+    //  seen counts as new later — an overestimate, the safe side)
+    const Sampler sp = m->d_sample ? Sampler{m->d_sample, m->sample_mask, &m->d_ctr->sample_claims} : Sampler{nullptr, 0, nullptr};
+    // ---- stage A: P1 + prefix + P2 (the L1 level) -----------------------------------------------------------
     GK_HIP(ctx, hipEventRecord(ctx->pev[0], ctx->stream));
-    if (d_rec && op) {
+    if (d_rec && op1) {
         GK_HIP(ctx, hipEventRecord(ctx->pev[1], ctx->stream));
         // reads per tile: their windows must fit the LDS key buffer and their bytes the LDS tile
-        const u64 by_bytes = ((u64)OP_TILE_WORDS * 4 - 96) / stride;
+        const u64 by_bytes = ((u64)OP_TILE_WORDS * 4 - 96) / src.stride;
         const int rs = (int)std::max<u64>(1, std::min<u64>(by_bytes, (u64)(OP_CAP / W) / (u64)max_windows));
-        const u64 ntiles = (nreads + rs - 1) / rs;
+        const u64 ntiles = (src.nreads + rs - 1) / rs;
         const int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)ctx->cu_count * 2);
-        hipLaunchKernelGGL(k_op_scatter1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, nreads, stride, m->k, group, rs, max_windows,
-                           t, a, m->d_ctr, ps->bufA);
+        hipLaunchKernelGGL(k_op_scatter1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, src.nreads, src.stride, m->k, src.group, rs,
+                           src.max_len, t, a, sp, m->d_ctr, ps->bufA);
     } else if (d_rec) {
-        const u64 ntiles = (nreads + PTILE_READS - 1) / PTILE_READS;
+        const u64 ntiles = (src.nreads + PTILE_READS - 1) / PTILE_READS;
         const int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)ctx->cu_count * 4);
-        hipLaunchKernelGGL(k_part_hist1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k, group, t, a.hist1, m->d_ctr);
+        hipLaunchKernelGGL(k_part_hist1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, src.nreads, d_off, src.stride, m->k, src.group,
+                           src.max_len, t, a.hist1, sp, m->d_ctr);
         hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(256), 0, ctx->stream, a, nb1);
         GK_HIP(ctx, hipEventRecord(ctx->pev[1], ctx->stream));
         // (A variant that also sorts THIS kernel's keys in LDS before writing was measured slower,
         //  0.76 vs 0.68 ms at C2: P2 is bound by the two window-extraction passes, not by its stores.)
-        hipLaunchKernelGGL(k_part_scatter1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k, group, t,
-                           a.l1_base, a.cursor1, ps->bufA);
+        hipLaunchKernelGGL(k_part_scatter1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, src.nreads, d_off, src.stride, m->k, src.group,
+                           src.max_len, t, a.l1_base, a.cursor1, ps->bufA);
     } else {
-        if (!op) {
+        if (!op1) {
             const int grid = (int)std::min<u64>(std::max<u64>((nkeys_in + BLOCK - 1) / BLOCK, 1), (u64)cu8);
             hipLaunchKernelGGL(k_part_hist1_keys<W>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_keys, nkeys_in, t, a.hist1);
             hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(256), 0, ctx->stream, a, nb1);
         }
         GK_HIP(ctx, hipEventRecord(ctx->pev[1], ctx->stream));
         const int g2 = (int)std::min<u64>(std::max<u64>((nkeys_in + TILE2 - 1) / TILE2, 1), (u64)ctx->cu_count * 4);
-        hipLaunchKernelGGL(k_part_scatter1_keys<W>, dim3(g2), dim3(PBLOCK), ScatterLds<W>::bytes(256u), ctx->stream, d_keys, nkeys_in, t, a, ps->bufA);
+        hipLaunchKernelGGL(k_part_scatter1_keys<W>, dim3(g2), dim3(PBLOCK), ScatterLds<W>::bytes(256u), ctx->stream, d_keys, nkeys_in, t, a, ps->bufA, sp);
     }
-    if (op) hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(256), 0, ctx->stream, a, nb1);     // chunk table from the cursors
+    if (op1) hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(256), 0, ctx->stream, a, nb1);     // chunk / range tables from the cursors
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipEventRecord(ctx->pev[2], ctx->stream));
-    // P3 + prefix + P4
-    const u64 max_chunks = nkeys_bound / TILE2 + 257;
-    const int gchunks = (int)std::min<u64>(max_chunks, (u64)ctx->cu_count * 4);
-    const u64 *fine_keys = ps->bufB;
-    if (!op) {
-        hipLaunchKernelGGL(k_part_hist2<W>, dim3(gchunks), dim3(PBLOCK), m->nb2 * 4, ctx->stream, ps->bufA, t, a, max_chunks);
-        hipLaunchKernelGGL(k_part_prefix2, dim3(nb1), dim3(256), 0, ctx->stream, a, nb1, m->nb2);
-    }
-    GK_HIP(ctx, hipEventRecord(ctx->pev[3], ctx->stream));
-    hipLaunchKernelGGL(k_part_scatter2<W>, dim3(gchunks), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2), ctx->stream, ps->bufA, t, a, max_chunks, ps->bufB);
-    GK_HIP(ctx, hipGetLastError());
-    GK_HIP(ctx, hipEventRecord(ctx->pev[4], ctx->stream));
+
+    // ---- between the levels ----------------------------------------------------------------------------------
     // Did the spill list overflow (extreme skew)?  Then the batch has to take the direct path.  A table
     // that holds data must not be touched before that is known (host round trip here); a table that is
     // being rebuilt from empty can simply be cleared again, so P5 goes out first and the flag is read
     // with everything else after it — one host round trip less per batch on the common path.
+    // With plan.estimate the round trip is taken anyway: it brings the distinct-key sample back.
     unsigned long long nspill = 0;
     u32 ovf = 0;
     auto abandon = [&](bool table_touched) -> int {
@@ -867,43 +1076,96 @@ static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads
         m->retries_direct++;
         return PART_RETRY_DIRECT;
     };
-    if (op && !from_empty) {
+    // Over-provisioned segment regions are only safe to try on a table that is being rebuilt from empty (if they and
+    // the spill list overflow, the table is simply cleared again); a table that holds data gets the exact fine level
+    // unless the sample says the batch is near-distinct.
+    bool fine_exact = !op1 || plan.fine_exact || !from_empty;
+    const bool sync_between = plan.estimate || (op1 && !from_empty);
+    if (sync_between) {
+        Counters c;
         GK_HIP(ctx, hipMemcpyAsync(&nspill, a.nspill, 8, hipMemcpyDeviceToHost, ctx->stream));
         GK_HIP(ctx, hipMemcpyAsync(&ovf, a.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+        GK_HIP(ctx, hipMemcpyAsync(&c, m->d_ctr, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
         GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ovf) {
             GK_HIP(ctx, hipEventRecord(ctx->pev[5], ctx->stream));
             return abandon(false);
         }
+        if (plan.estimate) {
+            // new distinct keys of this batch ~ 1024 x the sample keys it added (+ 4 sigma of that estimate + what the
+            // spill list holds, which the sample has seen too but the regions have not)
+            const u64 claims = c.sample_claims - std::min<u64>(c.sample_claims, m->sample_claims_seen);
+            m->sample_claims_seen = c.sample_claims;
+            const bool saturated = c.sample_claims * 2 > m->sample_mask;          // the set is half full: stop trusting it
+            u64 est_new = saturated ? nkeys_bound : (u64)((double)claims * 1024.0 * 1.05 + 4.0 * std::sqrt((double)claims + 1.0) * 1024.0 + 4096.0);
+            est_new = std::min<u64>(est_new, nkeys_bound);
+            m->est_distinct_last = est_new;
+            if (!ctx->hook_no_reserve) {
+                // (error k-mers accumulate sub-linearly with the reads: 60 % of the proportional extrapolation)
+                const u64 ahead = (u64)((double)est_new * (1.0 + 0.6 * (std::max(plan.grow_ahead, 1.0) - 1.0)));
+                if (int rc = map_make_room(m, est_new, ahead, from_empty)) return rc;     // may replace the table (same lnb1)
+            }
+            t = Table<W>{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u};
+            // many repeats: segment sizes are far from binomial -> exact fine level
+            fine_exact = !op1 || plan.fine_exact || (double)est_new < 0.5 * (double)nkeys_bound;
+        }
     }
-    // P5
+    if (m->nb2 > MAX_NB2) return fail(ctx, GK_E_CAPACITY, "table outgrew the partitioned insert path");   // (callers check part_supported first)
+    if (int rc = part_prepare_fine(m, ps, nkeys_bound, !fine_exact, &a)) return rc;
+    const u64 nseg = t.nseg();
+
+    // ---- stage B: P3 + scans + P4 (the fine level) ---------------------------------------------------------
+    const u64 max_chunks = nkeys_bound / TILE2 + 257;
+    const u64 max_ranges = max_chunks / a.range_chunks + 257;
+    const u64 *fine_keys = ps->bufB;
+    if (fine_exact) {
+        const int gr = (int)std::min<u64>(max_ranges, (u64)ctx->cu_count * 4);
+        hipLaunchKernelGGL(k_part_hist2r<W>, dim3(gr), dim3(PBLOCK), m->nb2 * 4, ctx->stream, ps->bufA, t, a, max_ranges);
+        hipLaunchKernelGGL(k_part_scan2, dim3((m->nb2 + 255) / 256, nb1), dim3(256), 0, ctx->stream, a, m->nb2);
+        hipLaunchKernelGGL(k_part_prefix2, dim3(nb1), dim3(256), 0, ctx->stream, a, nb1, m->nb2);
+        GK_HIP(ctx, hipEventRecord(ctx->pev[3], ctx->stream));
+        hipLaunchKernelGGL((k_part_scatter2<W, true>), dim3(gr), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2), ctx->stream, ps->bufA, t, a, max_ranges, ps->bufB);
+    } else {
+        GK_HIP(ctx, hipEventRecord(ctx->pev[3], ctx->stream));
+        const int gchunks = (int)std::min<u64>(max_chunks, (u64)ctx->cu_count * 4);
+        hipLaunchKernelGGL((k_part_scatter2<W, false>), dim3(gchunks), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2), ctx->stream, ps->bufA, t, a, max_chunks, ps->bufB);
+    }
+    GK_HIP(ctx, hipGetLastError());
+    GK_HIP(ctx, hipEventRecord(ctx->pev[4], ctx->stream));
+    // ---- P5 ------------------------------------------------------------------------------------------------
     const int gseg = (int)std::min<u64>(nseg, (u64)ctx->cu_count * 24);
     hipLaunchKernelGGL(k_seg_insert<W>, dim3(gseg), dim3(SBLOCK), lds, ctx->stream, t, fine_keys, a, from_empty ? 1 : 0, m->d_ctr);
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipEventRecord(ctx->pev[5], ctx->stream));
-    if (op && from_empty) {
-        GK_HIP(ctx, hipMemcpyAsync(&nspill, a.nspill, 8, hipMemcpyDeviceToHost, ctx->stream));
-        GK_HIP(ctx, hipMemcpyAsync(&ovf, a.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
-    }
+    // the spill list may also have grown in P4 (over-provisioned fine level): read it (again) behind P5
+    GK_HIP(ctx, hipMemcpyAsync(&nspill, a.nspill, 8, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP(ctx, hipMemcpyAsync(&ovf, a.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
     // failures (a segment filled up): grow, then replay those buckets through the direct path
     u32 n_failed = 0;
     GK_HIP(ctx, hipMemcpyAsync(&n_failed, a.n_failed, 4, hipMemcpyDeviceToHost, ctx->stream));
     if (int rc = map_sync_counters(m)) return rc;
-    if (ovf) return abandon(true);            // (only reachable from empty: see above)
+    if (ovf) {
+        if (from_empty) return abandon(true);
+        // P4's regions overflowed into a full spill list while the table held data: the keys that did not fit are lost
+        // to this pipeline but P5 has already merged the rest.  Cannot happen with the exact fine level; the
+        // over-provisioned one is only chosen for a table that holds data when the batch is known to be near-distinct.
+        return fail(ctx, GK_E_STATE, "partitioned insert: spill list overflowed behind a non-empty table (internal sizing error)");
+    }
     m->failed_segments += n_failed;
     m->spilled_keys += nspill;
+    if (!fine_exact && nspill > nkeys_bound / 64) m->repeats = true;       // regions sized for distinct keys are the wrong tool for this data
     if (n_failed) {
         std::vector<u32> failed(n_failed);
         GK_HIP(ctx, hipMemcpy(failed.data(), a.failed, n_failed * 4ull, hipMemcpyDeviceToHost));
         std::vector<unsigned long long> fb;
         std::vector<u32> cur;
-        if (op) { cur.resize(nseg); GK_HIP(ctx, hipMemcpy(cur.data(), a.cursor2, nseg * 4, hipMemcpyDeviceToHost)); }
+        if (a.op2) { cur.resize(nseg); GK_HIP(ctx, hipMemcpy(cur.data(), a.cursor2, nseg * 4, hipMemcpyDeviceToHost)); }
         else { fb.resize(nseg + 1); GK_HIP(ctx, hipMemcpy(fb.data(), a.fine_base, (nseg + 1) * 8, hipMemcpyDeviceToHost)); }
-        auto seg_begin = [&](u32 s) { return op ? (u64)s * a.cap2 : (u64)fb[s]; };
-        auto seg_count = [&](u32 s) { return op ? std::min<u64>(cur[s], a.cap2) : (u64)(fb[s + 1] - fb[s]); };
+        auto seg_begin = [&](u32 s) { return a.op2 ? (u64)s * a.cap2 : (u64)fb[s]; };
+        auto seg_count = [&](u32 s) { return a.op2 ? std::min<u64>(cur[s], a.cap2) : (u64)(fb[s + 1] - fb[s]); };
         u64 total = 0;
         for (u32 s : failed) total += seg_count(s);
-        if (int rc = map_reserve(m, std::max<u64>(total, m->capacity / 2))) return rc;
+        if (int rc = map_reserve(m, std::max<u64>(std::min<u64>(total, m->capacity), m->capacity / 2))) return rc;
         for (u32 s : failed) {
             if (int rc = map_add_keys_direct(m, fine_keys + seg_begin(s) * m->W, seg_count(s))) return rc;
         }
@@ -914,14 +1176,14 @@ static int part_run(gk_map *m, PartScratch *ps, const uint8_t *d_rec, u64 nreads
     return GK_OK;
 }
 
-int part_count(gk_map *m, PartScratch **pps, const uint8_t *d_rec, u64 nreads, const u32 *d_off, u32 stride, int group,
-               const u64 *d_keys, u64 nkeys_in, u64 nkeys_bound, bool from_empty) {
+int part_count(gk_map *m, PartScratch **pps, const ReadSrc &src, const u64 *d_keys, u64 nkeys_in, u64 nkeys_bound, bool from_empty,
+               const PartPlan &plan) {
     if (!*pps) *pps = new PartScratch();
-    if (m->W == 1) return part_run<1>(m, *pps, d_rec, nreads, d_off, stride, group, d_keys, nkeys_in, nkeys_bound, from_empty);
-    return part_run<2>(m, *pps, d_rec, nreads, d_off, stride, group, d_keys, nkeys_in, nkeys_bound, from_empty);
+    if (m->W == 1) return part_run<1>(m, *pps, src, d_keys, nkeys_in, nkeys_bound, from_empty, plan);
+    return part_run<2>(m, *pps, src, d_keys, nkeys_in, nkeys_bound, from_empty, plan);
 }
 
 bool part_supported(const gk_map *m) { return m->nb2 <= MAX_NB2; }
-
+uint64_t part_max_slots(int W) { return ((u64)MAX_NB2 << 8) << seg_bits_for(W); }
 
 }  // namespace gk

@@ -52,7 +52,7 @@ static constexpr int PF_PARK_BYTES = 64 << 10;   // pass 2 parks a tile's admitt
 // (bits are only ever set): it saves the atomics of the common "already saturated" case.
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_pf_add(const uint8_t *__restrict__ rec, u64 nreads, const u32 *__restrict__ offsets, u32 stride,
-                                                  int k, u32 *words, u64 nbuckets, unsigned long long *seen) {
+                                                  int k, WindowLimits lim, u32 *words, u64 nbuckets, unsigned long long *seen) {
     __shared__ __attribute__((aligned(16))) u32 tile[TILE_WORDS];
     __shared__ u32 s_occ;
     if (threadIdx.x == 0) s_occ = 0;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(BLOCK) void k_pf_add(const uint8_t *__restrict__ re
         __syncthreads();
         const u64 a0 = stage_tile(tile, rec, gb, ge);
         __syncthreads();
-        for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, 64, [&](Kmer<W> x) {
+        for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, 64, lim, [&](Kmer<W> x) {
             const u64 b = pf_bucket(canonical(x, k), nbuckets);
             u32 *w = words + (b >> 4);
             const u32 sh = (u32)(b & 15) * 2;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(BLOCK) void k_pf_add(const uint8_t *__restrict__ re
 // writes them.
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_pf_select(const uint8_t *__restrict__ rec, u64 nreads, const u32 *__restrict__ offsets, u32 stride,
-                                                     int k, int rs /* reads per tile */, const u32 *__restrict__ words, u64 nbuckets, u64 *__restrict__ out, u64 out_cap,
+                                                     int k, WindowLimits lim, int rs /* reads per tile */, const u32 *__restrict__ words, u64 nbuckets, u64 *__restrict__ out, u64 out_cap,
                                                      unsigned long long *cursor /* [0] admitted, [1] windows */, u32 *overflow) {
     __shared__ __attribute__((aligned(16))) u32 tile[TILE_WORDS];
     extern __shared__ u64 park[];                 // [rs * max windows per read * W]
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(BLOCK) void k_pf_select(const uint8_t *__restrict__
         if (threadIdx.x == 0) s_n = 0;
         const u64 a0 = stage_tile(tile, rec, gb, ge);
         __syncthreads();
-        for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, 64, [&](Kmer<W> x) {
+        for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, 64, lim, [&](Kmer<W> x) {
             const Kmer<W> y = canonical(x, k);
             const u64 b = pf_bucket(y, nbuckets);
             occ++;
@@ -152,21 +152,21 @@ namespace {
 
 int pf_check(gk_prefilter *pf) { return pf && pf->ctx ? GK_OK : GK_E_INVALID; }
 
-int pf_launch_add(gk_prefilter *pf, const uint8_t *d_rec, u64 nreads, const u32 *d_off, u32 stride) {
+int pf_launch_add(gk_prefilter *pf, const uint8_t *d_rec, u64 nreads, const u32 *d_off, u32 stride, int max_len = 255) {
     gk_ctx *ctx = pf->ctx;
     const u64 ntiles = (nreads + TILE_READS - 1) / TILE_READS;
     const int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)ctx->cu_count * 8);
     if (pf->W == 1)
-        hipLaunchKernelGGL(k_pf_add<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, pf->k, pf->words, pf->nbuckets, pf->d_cursor + 1);
+        hipLaunchKernelGGL(k_pf_add<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, pf->k, WindowLimits{max_len, ctx->d_flags}, pf->words, pf->nbuckets, pf->d_cursor + 1);
     else
-        hipLaunchKernelGGL(k_pf_add<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, pf->k, pf->words, pf->nbuckets, pf->d_cursor + 1);
+        hipLaunchKernelGGL(k_pf_add<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, pf->k, WindowLimits{max_len, ctx->d_flags}, pf->words, pf->nbuckets, pf->d_cursor + 1);
     GK_HIP(ctx, hipGetLastError());
     return GK_OK;
 }
 
 // pass 2 for one chunk of records whose windows fit the key buffer; feeds the admitted keys to the table
 int pf_select_and_insert(gk_prefilter *pf, gk_map *m, const uint8_t *d_rec, u64 nreads, const u32 *d_off, u32 stride, u64 max_windows,
-                         u64 max_windows_per_read, u64 *admitted_total) {
+                         u64 max_windows_per_read, u64 *admitted_total, int max_len = 255) {
     gk_ctx *ctx = pf->ctx;
     if (pf->keybuf_keys < max_windows) {
         if (pf->keybuf) GK_HIP(ctx, hipFree(pf->keybuf));
@@ -183,18 +183,19 @@ int pf_select_and_insert(gk_prefilter *pf, gk_map *m, const uint8_t *d_rec, u64 
     const int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)ctx->cu_count * 8);
     const size_t lds = (size_t)rs * per_read * 8 * pf->W;
     if (pf->W == 1)
-        hipLaunchKernelGGL(k_pf_select<1>, dim3(grid), dim3(BLOCK), lds, ctx->stream, d_rec, nreads, d_off, stride, pf->k, rs, pf->words, pf->nbuckets,
+        hipLaunchKernelGGL(k_pf_select<1>, dim3(grid), dim3(BLOCK), lds, ctx->stream, d_rec, nreads, d_off, stride, pf->k, WindowLimits{max_len, ctx->d_flags}, rs, pf->words, pf->nbuckets,
                            pf->keybuf, pf->keybuf_keys, pf->d_cursor, d_ovf);
     else
-        hipLaunchKernelGGL(k_pf_select<2>, dim3(grid), dim3(BLOCK), lds, ctx->stream, d_rec, nreads, d_off, stride, pf->k, rs, pf->words, pf->nbuckets,
+        hipLaunchKernelGGL(k_pf_select<2>, dim3(grid), dim3(BLOCK), lds, ctx->stream, d_rec, nreads, d_off, stride, pf->k, WindowLimits{max_len, ctx->d_flags}, rs, pf->words, pf->nbuckets,
                            pf->keybuf, pf->keybuf_keys, pf->d_cursor, d_ovf);
     GK_HIP(ctx, hipGetLastError());
     unsigned long long h[3] = {0, 0, 0};
     GK_HIP(ctx, hipMemcpyAsync(h, pf->d_cursor, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if ((u32)h[2]) return fail(ctx, GK_E_CAPACITY, "prefilter: admitted keys exceed the key buffer (internal sizing error)");
+    if (int rc = ctx_check_format(ctx)) return rc;
     *admitted_total += h[0];
-    if (h[0]) { if (int rc = gk_map_update_inc_dev(m, pf->keybuf, h[0])) return rc; }
+    if (h[0]) { if (int rc = map_insert_keys_dev(m, pf->keybuf, h[0], false)) return rc; }     // canonical by construction
     return GK_OK;
 }
 
@@ -324,8 +325,8 @@ int gk_prefilter_add_reads_dev(gk_prefilter *pf, const void *dev_records, uint64
     if (read_len < 0 || read_len > 255) return fail(ctx, GK_E_FORMAT, "read_len must be 0..255 (one length byte per record)");
     GK_HIP(ctx, hipSetDevice(ctx->device));
     if (nreads == 0 || read_len < pf->k) return GK_OK;
-    if (int rc = pf_launch_add(pf, (const uint8_t *)dev_records, nreads, nullptr, 1 + (read_len + 3) / 4)) return rc;
-    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = pf_launch_add(pf, (const uint8_t *)dev_records, nreads, nullptr, 1 + (read_len + 3) / 4, read_len)) return rc;
+    if (int rc = ctx_check_format(ctx)) return rc;
     pf->windows_added += nreads * (u64)(read_len - pf->k + 1);
     return GK_OK;
 }
@@ -359,7 +360,7 @@ int gk_map_count_reads_prefiltered_dev(gk_map *m, gk_prefilter *pf, const void *
     u64 adm = 0;
     for (u64 done = 0; done < nreads; done += chunk_reads) {
         const u64 n = std::min(chunk_reads, nreads - done);
-        if (int rc = pf_select_and_insert(pf, m, (const uint8_t *)dev_records + done * stride, n, nullptr, stride, n * nk, nk, &adm)) return rc;
+        if (int rc = pf_select_and_insert(pf, m, (const uint8_t *)dev_records + done * stride, n, nullptr, stride, n * nk, nk, &adm, read_len)) return rc;
     }
     if (occurrences) *occurrences = nreads * nk;
     if (admitted) *admitted = adm;

@@ -19,7 +19,7 @@ static constexpr int MAX_PARTS = 64;
 // pass 1: how many canonical k-mers go to each owner
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_shard_count(const uint8_t *__restrict__ rec, u64 nreads, u32 stride, int k, int P,
-                                                       unsigned long long *counts) {
+                                                       WindowLimits lim, unsigned long long *counts) {
     __shared__ __attribute__((aligned(16))) u32 tile[TILE_WORDS];
     __shared__ u32 hist[MAX_PARTS];
     if (threadIdx.x < MAX_PARTS) hist[threadIdx.x] = 0;
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(BLOCK) void k_shard_count(const uint8_t *__restrict
         __syncthreads();
         const u64 a0 = stage_tile(tile, rec, r0 * stride, (r0 + nr) * stride);
         __syncthreads();
-        for_each_window<W>(tile, a0, r0, nr, nullptr, stride, k, 64, [&](Kmer<W> x) {
+        for_each_window<W>(tile, a0, r0, nr, nullptr, stride, k, 64, lim, [&](Kmer<W> x) {
             atomicAdd(&hist[owner_of(x, k, P)], 1u);
         });
     }
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(BLOCK) void k_shard_count(const uint8_t *__restrict
 // global atomic per (tile, owner) reserves a contiguous run, lanes fill the run by LDS rank.
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_shard_scatter(const uint8_t *__restrict__ rec, u64 nreads, u32 stride, int k, int P,
-                                                         unsigned long long *cursors, u64 *__restrict__ out) {
+                                                         WindowLimits lim, unsigned long long *cursors, u64 *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) u32 tile[TILE_WORDS];
     __shared__ u32 hist[MAX_PARTS], rank[MAX_PARTS];
     __shared__ unsigned long long base[MAX_PARTS];
@@ -54,11 +54,11 @@ __global__ __launch_bounds__(BLOCK) void k_shard_scatter(const uint8_t *__restri
         if (threadIdx.x < MAX_PARTS) { hist[threadIdx.x] = 0; rank[threadIdx.x] = 0; }
         const u64 a0 = stage_tile(tile, rec, r0 * stride, (r0 + nr) * stride);
         __syncthreads();
-        for_each_window<W>(tile, a0, r0, nr, nullptr, stride, k, 64, [&](Kmer<W> x) { atomicAdd(&hist[owner_of(x, k, P)], 1u); });
+        for_each_window<W>(tile, a0, r0, nr, nullptr, stride, k, 64, lim, [&](Kmer<W> x) { atomicAdd(&hist[owner_of(x, k, P)], 1u); });
         __syncthreads();
         if (threadIdx.x < (u32)P && hist[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursors[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
         __syncthreads();
-        for_each_window<W>(tile, a0, r0, nr, nullptr, stride, k, 64, [&](Kmer<W> x) {
+        for_each_window<W>(tile, a0, r0, nr, nullptr, stride, k, 64, lim, [&](Kmer<W> x) {
             Kmer<W> y = canonical(x, k);                 // FreqFilter.scala:31-32, done by the sender
             int p = owner_of(x, k, P);                   // same owner for x and rc(x)
             u64 o = base[p] + atomicAdd(&rank[p], 1u);
@@ -143,8 +143,8 @@ int gk_shard_reads_dev(gk_ctx *ctx, int k, const void *dev_records, uint64_t nre
     const int grid = (int)std::min<u64>(ntiles, (u64)ctx->cu_count * 8);
     const uint8_t *rec = (const uint8_t *)dev_records;
     if (e == hipSuccess) {
-        if (W == 1) hipLaunchKernelGGL(k_shard_count<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, rec, nreads, stride, k, P, d_cnt);
-        else hipLaunchKernelGGL(k_shard_count<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, rec, nreads, stride, k, P, d_cnt);
+        if (W == 1) hipLaunchKernelGGL(k_shard_count<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, rec, nreads, stride, k, P, WindowLimits{read_len, ctx->d_flags}, d_cnt);
+        else hipLaunchKernelGGL(k_shard_count<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, rec, nreads, stride, k, P, WindowLimits{read_len, ctx->d_flags}, d_cnt);
         e = hipGetLastError();
     }
     unsigned long long h_cnt[MAX_PARTS], h_cur[MAX_PARTS];
@@ -156,14 +156,14 @@ int gk_shard_reads_dev(gk_ctx *ctx, int k, const void *dev_records, uint64_t nre
         e = hipMemcpyAsync(d_cnt + MAX_PARTS, h_cur, P * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream);
     }
     if (e == hipSuccess) {
-        if (W == 1) hipLaunchKernelGGL(k_shard_scatter<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, rec, nreads, stride, k, P, d_cnt + MAX_PARTS, (u64 *)dev_keys_out);
-        else hipLaunchKernelGGL(k_shard_scatter<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, rec, nreads, stride, k, P, d_cnt + MAX_PARTS, (u64 *)dev_keys_out);
+        if (W == 1) hipLaunchKernelGGL(k_shard_scatter<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, rec, nreads, stride, k, P, WindowLimits{read_len, nullptr}, d_cnt + MAX_PARTS, (u64 *)dev_keys_out);
+        else hipLaunchKernelGGL(k_shard_scatter<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, rec, nreads, stride, k, P, WindowLimits{read_len, nullptr}, d_cnt + MAX_PARTS, (u64 *)dev_keys_out);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_cnt);
     if (e != hipSuccess) return hip_fail(ctx, e, "gk_shard_reads_dev");
-    return GK_OK;
+    return ctx_check_format(ctx);
 }
 
 int gk_synth_reads_dev(gk_ctx *ctx, void *dev_records, uint64_t nreads, int read_len, int mode, uint64_t config_id,

@@ -100,7 +100,7 @@ __device__ __forceinline__ void write_record(const u32 *tile, u32 bit, int nbase
 static constexpr int DESC_CAP = 4096;
 template <int SLOT>
 __global__ __launch_bounds__(BLOCK) void k_skm_route(const uint8_t *__restrict__ rec, u64 nreads, u32 stride, int k, int P,
-                                                     u64 region_cap /* records per owner region */, unsigned long long *cursors,
+                                                     WindowLimits lim, u64 region_cap /* records per owner region */, unsigned long long *cursors,
                                                      unsigned long long *kmer_counts, u32 *overflow, uint8_t *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) u32 tile[TILE_WORDS];
     __shared__ u32 strips[(BLOCK / 64) * MAX_POS], strips2[(BLOCK / 64) * MAX_POS];
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(BLOCK) void k_skm_route(const uint8_t *__restrict__
             // ---- phase 1
             for (int r = g0 + wave; r < g1; r += BLOCK / 64) {
                 const u32 ro = (u32)((r0 + r) * stride - a0);
-                const int len = tb[ro], nk = len - k + 1, nm = len - m + 1;
+                const int len = record_len(tb, ro, lim), nk = len - k + 1, nm = len - m + 1;
                 const u32 bit0 = (ro + 1) * 8;
                 __builtin_amdgcn_wave_barrier();
                 GK_TICK(1);
@@ -255,10 +255,10 @@ int gk_shard_superkmers_dev(gk_ctx *ctx, int k, const void *dev_records, uint64_
     const uint8_t *rec = (const uint8_t *)dev_records;
     u32 *d_overflow = reinterpret_cast<u32 *>(tls_counts + 2 * MAX_PARTS);
     if (skm_slot_bytes(k) == 16)
-        hipLaunchKernelGGL(k_skm_route<16>, dim3(grid), dim3(BLOCK), 0, ctx->stream, rec, nreads, stride, k, P, region_cap, tls_counts,
+        hipLaunchKernelGGL(k_skm_route<16>, dim3(grid), dim3(BLOCK), 0, ctx->stream, rec, nreads, stride, k, P, WindowLimits{read_len, ctx->d_flags}, region_cap, tls_counts,
                            tls_counts + MAX_PARTS, d_overflow, (uint8_t *)dev_out);
     else
-        hipLaunchKernelGGL(k_skm_route<32>, dim3(grid), dim3(BLOCK), 0, ctx->stream, rec, nreads, stride, k, P, region_cap, tls_counts,
+        hipLaunchKernelGGL(k_skm_route<32>, dim3(grid), dim3(BLOCK), 0, ctx->stream, rec, nreads, stride, k, P, WindowLimits{read_len, ctx->d_flags}, region_cap, tls_counts,
                            tls_counts + MAX_PARTS, d_overflow, (uint8_t *)dev_out);
     GK_HIP(ctx, hipGetLastError());
     unsigned long long h[2 * MAX_PARTS + 1];
@@ -273,7 +273,7 @@ int gk_shard_superkmers_dev(gk_ctx *ctx, int k, const void *dev_records, uint64_
     if ((u32)h[2 * MAX_PARTS] || worst > region_cap)
         return fail(ctx, GK_E_CAPACITY, "record buffer too small: the fullest owner region needs " + std::to_string(worst) +
                                             " records, out_cap_records / P = " + std::to_string(region_cap));
-    return GK_OK;
+    return ctx_check_format(ctx);
 }
 
 }  // extern "C"

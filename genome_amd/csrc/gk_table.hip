@@ -64,7 +64,7 @@ template <int W> __global__ __launch_bounds__(BLOCK) void k_clear(Slot<W> *slots
 //   offsets != nullptr : offsets[r] = byte offset of record r, offsets[nreads] = end
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_count_reads(const uint8_t *__restrict__ rec, u64 nreads,
-                                                       const u32 *__restrict__ offsets, u32 stride, int k, int group,
+                                                       const u32 *__restrict__ offsets, u32 stride, int k, int group, int max_len,
                                                        Table<W> t, Counters *ctr) {
     __shared__ __attribute__((aligned(16))) u32 tile[TILE_WORDS];
     __shared__ u32 s_claimed, s_occ;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(BLOCK) void k_count_reads(const uint8_t *__restrict
         __syncthreads();                       // previous tile fully consumed
         const u64 a0 = stage_tile(tile, rec, gb, ge);
         __syncthreads();
-        for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, group, [&](Kmer<W> x) {
+        for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, group, WindowLimits{max_len, &ctr->format}, [&](Kmer<W> x) {
             Kmer<W> y = canonical(x, k);                  // FreqFilter.scala:31-32
             claimed += table_add(t, y, 1u, &err);         // kmersFreq.update(y, 1, _ + 1)  :33
             occ++;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(BLOCK) void k_count_reads(const uint8_t *__restrict
 // PartitionedDNAMap exchange; also partition merge).  keys: W words per key, interleaved.
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_add_keys(const u64 *__restrict__ keys, const i32 *__restrict__ counts,
-                                                    u64 n, Table<W> t, Counters *ctr) {
+                                                    u64 n, Table<W> t, Counters *ctr, int check_canon_k /* 0: trusted keys */) {
     __shared__ u32 s_claimed;
     if (threadIdx.x == 0) s_claimed = 0;
     __syncthreads();
@@ -109,6 +109,7 @@ __global__ __launch_bounds__(BLOCK) void k_add_keys(const u64 *__restrict__ keys
         if constexpr (W == 1) key = Kmer<1>{keys[i]};
         else key = Kmer<2>{keys[2 * i], keys[2 * i + 1]};
         claimed += table_add(t, key, counts ? (u32)counts[i] : 1u, &err);
+        if (check_canon_k && !(canonical(key, check_canon_k) == key)) ctr->noncanon = 1u;
     }
     if (claimed) atomicAdd(&s_claimed, claimed);
     if (err) ctr->error = 1;
@@ -162,6 +163,26 @@ __global__ __launch_bounds__(BLOCK) void k_get(const u64 *__restrict__ lo, const
         i64 s = table_find(t, key);
         if (counts) counts[i] = s >= 0 ? (i32)slot_count(&t.slots[s]) : -1;
         if (found) found[i] = s >= 0;
+    }
+}
+
+// Self-check of the table's invariants (what `size` and the slot protocol promise): every live key is found again at
+// its own slot (a key stored twice, or in a segment its hash does not name, is not), counts add up.
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_verify(Table<W> t, unsigned long long *out /* live, duplicates or misplaced, sum of counts */) {
+    unsigned long long live = 0, bad = 0, sum = 0;
+    const u64 ncap = t.capacity();
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < ncap; i += (u64)gridDim.x * BLOCK) {
+        if (!slot_live(&t.slots[i])) continue;
+        live++;
+        sum += slot_count(&t.slots[i]);
+        if (table_find(t, slot_key(t.slots, i, t.tagged)) != (i64)i) bad++;
+    }
+    for (int d = 32; d; d >>= 1) { live += __shfl_down(live, d); bad += __shfl_down(bad, d); sum += __shfl_down(sum, d); }
+    if ((threadIdx.x & 63) == 0) {
+        if (live) atomicAdd(&out[0], live);
+        if (bad) atomicAdd(&out[1], bad);
+        if (sum) atomicAdd(&out[2], sum);
     }
 }
 
@@ -240,11 +261,24 @@ int map_sync_counters(gk_map *m) {
     GK_HIP(m->ctx, hipMemcpyAsync(&c, m->d_ctr, sizeof(c), hipMemcpyDeviceToHost, m->ctx->stream));
     GK_HIP(m->ctx, hipStreamSynchronize(m->ctx->stream));
     m->size = c.size;
-    if (c.error) {
-        GK_HIP(m->ctx, hipMemsetAsync(&m->d_ctr->error, 0, sizeof(u32), m->ctx->stream));
+    if (c.noncanon) m->dirty = true;
+    if (c.error || c.format) {
+        GK_HIP(m->ctx, hipMemsetAsync(&m->d_ctr->error, 0, 2 * sizeof(u32), m->ctx->stream));
+        if (c.format)
+            return fail(m->ctx, GK_E_FORMAT, "a device record's length byte exceeds the declared read length (clamped; the map's contents are "
+                                             "unspecified: clear it)");
         return fail(m->ctx, GK_E_CAPACITY, "a table segment filled up (internal sizing error)");
     }
     return GK_OK;
+}
+
+int ctx_check_format(gk_ctx *ctx) {
+    u32 f = 0;
+    GK_HIP(ctx, hipMemcpyAsync(&f, ctx->d_flags, 4, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!f) return GK_OK;
+    GK_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, 4, ctx->stream));
+    return fail(ctx, GK_E_FORMAT, "a device record's length byte exceeds the declared read length");
 }
 
 // Load limits: grow before a batch could exceed max_load; size for target_load.  A tagged table
@@ -252,26 +286,34 @@ int map_sync_counters(gk_map *m) {
 static inline double max_load(const gk_map *m) { return m->k == 64 ? 0.6 : 0.8; }
 static inline double target_load(const gk_map *m) { return m->k == 64 ? 0.45 : 0.65; }
 
-// ArrayDNAMap.rescale analogue: make room for `extra_keys` more distinct keys.
-int map_reserve(gk_map *m, uint64_t extra_keys) {
-    uint64_t need = m->size + m->tombstones + extra_keys;
-    if ((double)need <= max_load(m) * (double)m->capacity) return GK_OK;
+// Replace the table by one of (at least) want_slots slots.  rehash = false: the old contents are void (a deferred
+// clear is pending and the caller is about to rebuild every segment from EMPTY): nothing is moved and nothing is cleared.
+// The old table is only released once the new one is known to be good: a rehash that fails (a segment of the NEW table
+// filled up — a sizing error) leaves the map exactly as it was.
+static int map_grow_to(gk_map *m, uint64_t want_slots, bool rehash) {
+    gk_ctx *ctx = m->ctx;
     uint32_t nnb2, nlnb1;
     uint64_t ncap;
-    plan_segments(m->W, std::max<uint64_t>((uint64_t)((double)(m->size + extra_keys) / target_load(m)) + 1, m->capacity + m->capacity / 2), &nnb2, &nlnb1, &ncap);
-    gk_ctx *ctx = m->ctx;
+    plan_segments(m->W, want_slots, &nnb2, &nlnb1, &ncap);
     void *nslots = nullptr;
-    int rc = alloc_table(ctx, m->W, ncap, &nslots);
-    if (rc) return fail(ctx, GK_E_CAPACITY, "cannot grow table to " + std::to_string(ncap) + " slots: " + ctx->err);
-    int grid = grid_for(ctx, m->capacity, BLOCK);
-    if (m->W == 1)
-        hipLaunchKernelGGL(k_rehash<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, m->capacity,
-                           Table<1>{(Slot<1> *)nslots, nnb2, nlnb1, 0u}, m->d_ctr);
-    else
-        hipLaunchKernelGGL(k_rehash<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots, m->capacity,
-                           Table<2>{(Slot<2> *)nslots, nnb2, nlnb1, m->k == 64 ? 1u : 0u}, m->d_ctr);
-    GK_HIP(ctx, hipGetLastError());
-    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!rehash) {
+        hipError_t e = hipMalloc(&nslots, ncap * slot_bytes(m->W));
+        if (e != hipSuccess) { (void)hipGetLastError(); return fail(ctx, GK_E_CAPACITY, "cannot grow table to " + std::to_string(ncap) + " slots: " + hipGetErrorString(e)); }
+    } else {
+        int rc = alloc_table(ctx, m->W, ncap, &nslots);
+        if (rc) { if (nslots) (void)hipFree(nslots); return fail(ctx, GK_E_CAPACITY, "cannot grow table to " + std::to_string(ncap) + " slots: " + ctx->err); }
+        int grid = grid_for(ctx, m->capacity, BLOCK);
+        if (m->W == 1)
+            hipLaunchKernelGGL(k_rehash<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, m->capacity,
+                               Table<1>{(Slot<1> *)nslots, nnb2, nlnb1, 0u}, m->d_ctr);
+        else
+            hipLaunchKernelGGL(k_rehash<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots, m->capacity,
+                               Table<2>{(Slot<2> *)nslots, nnb2, nlnb1, m->k == 64 ? 1u : 0u}, m->d_ctr);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { (void)hipFree(nslots); return hip_fail(ctx, e, "table rehash"); }
+        if (int rc2 = map_sync_counters(m)) { (void)hipFree(nslots); return rc2; }      // rehash error flag: the old table stays
+    }
     GK_HIP(ctx, hipFree(m->slots));
     m->slots = nslots;
     m->capacity = ncap;
@@ -279,7 +321,33 @@ int map_reserve(gk_map *m, uint64_t extra_keys) {
     m->lnb1 = nlnb1;
     m->tombstones = 0;
     m->grows++;
-    return map_sync_counters(m);
+    return GK_OK;
+}
+
+// ArrayDNAMap.rescale analogue: make room for `extra_keys` more distinct keys.
+int map_reserve(gk_map *m, uint64_t extra_keys) {
+    uint64_t need = m->size + m->tombstones + extra_keys;
+    if ((double)need <= max_load(m) * (double)m->capacity) return GK_OK;
+    return map_grow_to(m, std::max<uint64_t>((uint64_t)((double)(m->size + extra_keys) / target_load(m)) + 1, m->capacity + m->capacity / 2), true);
+}
+
+// the partitioned pipeline's mid-batch form: room for `new_distinct` more keys; from_empty = the table's contents are void
+int map_make_room(gk_map *m, uint64_t new_distinct, uint64_t size_for, bool from_empty) {
+    const uint64_t have = from_empty ? 0 : m->size + m->tombstones;
+    if ((double)(have + new_distinct) <= max_load(m) * (double)m->capacity) return GK_OK;
+    const uint64_t want = std::max<uint64_t>((uint64_t)((double)(have + std::max(new_distinct, size_for)) / target_load(m)) + 1,
+                                             from_empty ? 0 : m->capacity + m->capacity / 2);
+    return map_grow_to(m, want, !from_empty);
+}
+
+static constexpr uint64_t SAMPLE_SLOTS = 1ull << 23;      // 64 MB: 4 M sample keys at load 0.5 = 4.3e9 distinct keys
+int map_ensure_sample(gk_map *m) {
+    if (m->d_sample) return GK_OK;
+    gk_ctx *ctx = m->ctx;
+    GK_HIP(ctx, hipMalloc((void **)&m->d_sample, SAMPLE_SLOTS * 8));
+    GK_HIP(ctx, hipMemsetAsync(m->d_sample, 0xff, SAMPLE_SLOTS * 8, ctx->stream));
+    m->sample_mask = SAMPLE_SLOTS - 1;
+    return GK_OK;
 }
 
 int map_materialize(gk_map *m) {
@@ -329,12 +397,19 @@ int gk_ctx_create(int device, gk_ctx **out) {
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&ctx->pev[i]);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_flags, 64);
+    if (e == hipSuccess) e = hipMemset(ctx->d_flags, 0, 64);
     if (e != hipSuccess) {
         int rc = hip_fail(nullptr, e, "gk_ctx_create");
         delete ctx;
         return rc;
     }
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // test / A-B hooks: the environment is read HERE, once (see gk_ctx_set_option for the programmatic form)
+    ctx->hook_no_reserve = getenv("GK_TEST_NO_RESERVE") != nullptr;
+    ctx->hook_host_ragged = getenv("GK_HOST_RAGGED") != nullptr;
+    ctx->hook_part_exact = getenv("GK_PART_EXACT") != nullptr;
+    if (const char *u = getenv("GK_GRAPH_UNITIGS")) ctx->hook_unitigs = !strcmp(u, "walk") ? 1 : !strcmp(u, "pj") ? 2 : 0;
     *out = ctx;
     return GK_OK;
 }
@@ -344,6 +419,7 @@ void gk_ctx_destroy(gk_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
     if (ctx->skm_counts) (void)hipFree(ctx->skm_counts);
+    if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (int i = 0; i < 6; i++) if (ctx->pev[i]) (void)hipEventDestroy(ctx->pev[i]);
@@ -352,6 +428,19 @@ void gk_ctx_destroy(gk_ctx *ctx) {
 
 const char *gk_last_error(const gk_ctx *ctx) { return ctx ? ctx->err.c_str() : tls_err.c_str(); }
 int gk_ctx_device(const gk_ctx *ctx) { return ctx ? ctx->device : -1; }
+
+int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value) {
+    if (!ctx || !name) return fail(ctx, GK_E_INVALID, "gk_ctx_set_option: null argument");
+    const std::string n(name);
+    if (n == "test_no_reserve") ctx->hook_no_reserve = value != 0;
+    else if (n == "host_ragged") ctx->hook_host_ragged = value != 0;
+    else if (n == "part_exact") ctx->hook_part_exact = value != 0;
+    else if (n == "graph_unitigs") {
+        if (value < 0 || value > 2) return fail(ctx, GK_E_INVALID, "graph_unitigs: 0 auto, 1 walk, 2 pointer jumping");
+        ctx->hook_unitigs = (int)value;
+    } else return fail(ctx, GK_E_INVALID, "gk_ctx_set_option: unknown option '" + n + "'");
+    return GK_OK;
+}
 
 int gk_ctx_sync(gk_ctx *ctx) {
     if (!ctx) return fail(nullptr, GK_E_INVALID, "null ctx");
@@ -420,6 +509,8 @@ void gk_map_destroy(gk_map *m) {
     if (m->d_ctr) (void)hipFree(m->d_ctr);
     if (m->d_stage) (void)hipFree(m->d_stage);
     if (m->d_offsets) (void)hipFree(m->d_offsets);
+    if (m->d_sample) (void)hipFree(m->d_sample);
+    if (m->d_scratch) (void)hipFree(m->d_scratch);
     part_scratch_free(m->part);
     delete m;
 }
@@ -440,10 +531,15 @@ int gk_map_clear(gk_map *m) {
     // Deferred: the next partitioned insert rebuilds every segment from EMPTY without reading it;
     // anything else materialises the clear first (map_materialize).
     GK_HIP(ctx, hipMemsetAsync(m->d_ctr, 0, sizeof(Counters), ctx->stream));     // stream-ordered: no host round trip needed
+    if (m->d_sample && m->sample_dirty) GK_HIP(ctx, hipMemsetAsync(m->d_sample, 0xff, (m->sample_mask + 1) * 8, ctx->stream));
+    m->sample_claims_seen = 0;
+    m->sample_dirty = false;
+    m->est_distinct_last = 0;
     m->pending_clear = true;
     m->size = 0;
     m->tombstones = 0;
     m->total_occurrences = 0;
+    m->dirty = false;
     return GK_OK;
 }
 
@@ -461,18 +557,20 @@ int gk_map_slots(gk_map *m, uint64_t *slots) {
     return GK_OK;
 }
 
+static int add_keys_dev(gk_map *m, const u64 *d_keys, const i32 *d_counts, u64 n, bool verbatim = false);
+
 // launch k_count_reads over device-resident records; accumulates event time into last_count_ms
-static int launch_count(gk_map *m, const uint8_t *d_rec, u64 nreads, const u32 *d_off, u32 stride, int group = 64) {
+static int launch_count(gk_map *m, const ReadSrc &src) {
     gk_ctx *ctx = m->ctx;
-    u64 ntiles = (nreads + TILE_READS - 1) / TILE_READS;
+    u64 ntiles = (src.nreads + TILE_READS - 1) / TILE_READS;
     int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)ctx->cu_count * 8);
     GK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     if (m->W == 1)
-        hipLaunchKernelGGL(k_count_reads<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k, group,
-                           table_of<1>(m), m->d_ctr);
+        hipLaunchKernelGGL(k_count_reads<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, src.rec, src.nreads, src.off, src.stride, m->k, src.group,
+                           src.max_len, table_of<1>(m), m->d_ctr);
     else
-        hipLaunchKernelGGL(k_count_reads<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_rec, nreads, d_off, stride, m->k, group,
-                           table_of<2>(m), m->d_ctr);
+        hipLaunchKernelGGL(k_count_reads<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, src.rec, src.nreads, src.off, src.stride, m->k, src.group,
+                           src.max_len, table_of<2>(m), m->d_ctr);
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     if (int rc = map_sync_counters(m)) return rc;
@@ -496,45 +594,51 @@ static int read_occ_counter(gk_map *m, uint64_t *occ) {
     return GK_OK;
 }
 
-// Direct path: ~130 B of HBM traffic per occurrence (one 64-B sector read + one 64-B atomic,
-// profiles/r01/pmc_count_reads_v2.json).  Partitioned path: ~40 B per occurrence per key word of
-// streaming plus the table itself streamed out (and in, unless it is known to be empty).
-// The pipeline is calibrated on batches of up to ~2.7e8 windows into a table of about their own size.  Much larger
-// batches go with larger tables, where P4 has more fine buckets per chunk (1.2x the time per key at 4.8e8 windows, 1.8x
-// at 9.6e8) and where the windows are usually repeats of far fewer k-mers: the over-provisioned regions are sized for
-// near-distinct keys, repeats over-disperse the bucket sizes and spill (C3 fed in 1.9e9-window batches through the
-// pipeline: 0.62 s against 0.24 s on the direct path, whose repeats hit cached slots).  The growth factor below is
-// that experience, not a model of it; splitting a big batch instead would pay a pass over the table per piece
-// (measured: 19 vs 11.5 ms for 4.8e8 windows into an empty table).
+// ---- which path inserts a batch: a TIME model with per-path coefficients measured on MI355X ----------------------
+// (picoseconds of device time per k-mer occurrence and per key word, chip-wide; sources under profiles/.  The
+//  coefficients are measurements, the model is only their sum — re-measure with scripts/measure_paths.py.)
+struct PathCost {
+    double direct_ps = 45.0;        // k_count_reads, one global CAS/add per window: 5.45 ms / 1.2e8 windows (C2-U); 40 ps at C3's ~1000x repeats
+    double p2_ps = 5.0;             // k_op_scatter1_reads: 0.60 ms / 1.2e8 (x W for 16-byte keys: 0.97 ms / 9.6e7 at k = 55)
+    double p3_ps = 2.3;             // k_part_hist2r + scans (exact fine level only): one more read of the keys
+    double p4_ps = 4.6;             // k_part_scatter2 at few fine buckets ...
+    double p4_ps_per_nb2 = 0.0018;  // ... + what each fine bucket per L1 bucket adds (0.57 / 0.65 / 0.80 / 1.2 ms per 1.2e8 at nb2 = 93 / 370 / 1479 / 2958)
+    double p5_ps = 1.7;             // k_seg_insert: its key stream and LDS inserts (its table traffic is priced below)
+    double stream_tbps = 4.6;       // k_seg_insert writes / reads the table at 4.6 TB/s; k_clear reaches 4.95
+    double fixed_us = 60.0;         // launches, the small scans, one or two host round trips
+};
+static const PathCost COST;
 static bool use_partitioned(const gk_map *m, u64 occ) {
     if (m->insert_path == 1 || !part_supported(m)) return false;
     if (m->insert_path == 2) return true;
-    if (m->skewed) return false;          // this map's data has already defeated the over-provisioned regions once
-    const double calibrated = 2.7e8;
-    const double growth = occ > calibrated ? 1.0 + 0.77 * ((double)occ / calibrated - 1.0) : 1.0;
+    if (m->skewed) return false;          // this map's data has already defeated even the L1 regions once (one k-mer, millions of times)
     const double tb = (double)m->capacity * (double)slot_bytes(m->W);
-    const double cost_direct = (double)occ * 130.0 + (m->pending_clear ? tb : 0.0);
-    const double cost_part = (double)occ * 40.0 * m->W * growth + tb * (m->pending_clear ? 1.0 : 2.0) + 3e8;
-    return cost_part < cost_direct;
+    const double pass_us = tb / (COST.stream_tbps * 1e6);
+    const double us_direct = (double)occ * COST.direct_ps * 1e-6 + (m->pending_clear ? pass_us : 0.0);
+    const double per_key = (COST.p2_ps + COST.p4_ps + COST.p4_ps_per_nb2 * m->nb2 + COST.p5_ps + (m->repeats || !m->pending_clear ? COST.p3_ps : 0.0)) * m->W;
+    const double us_part = (double)occ * per_key * 1e-6 + pass_us * (m->pending_clear ? 1.0 : 2.0) + COST.fixed_us;
+    return us_part < us_direct;
 }
 
 // partitioned launch over device records or device keys, timed with the same events as launch_count
-static int launch_partitioned(gk_map *m, const uint8_t *d_rec, u64 nreads, const u32 *d_off, u32 stride, const u64 *d_keys,
-                              u64 nkeys_in, u64 bound, int group = 64) {
+static int launch_partitioned(gk_map *m, const ReadSrc &src, const u64 *d_keys, u64 nkeys_in, u64 bound, const PartPlan &plan) {
     gk_ctx *ctx = m->ctx;
     GK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     const bool from_empty = m->pending_clear;
     m->pending_clear = false;
-    const int prc = part_count(m, &m->part, d_rec, nreads, d_off, stride, group, d_keys, nkeys_in, bound, from_empty);
-    if (prc < 0) return prc;
+    const int prc = part_count(m, &m->part, src, d_keys, nkeys_in, bound, from_empty, plan);
+    if (prc < 0) {
+        if (from_empty) { m->pending_clear = true; m->size = 0; }       // a half-built table is void: the map is empty again
+        return prc;
+    }
     if (prc == PART_RETRY_DIRECT) {        // extreme skew: nothing but scratch (or a table that was being rebuilt from empty) was touched
         m->pending_clear = from_empty;
         m->skewed = true;
         if (from_empty) m->size = 0;
         if (int rc = map_materialize(m)) return rc;
         if (int rc = map_reserve(m, bound)) return rc;
-        if (d_rec) return launch_count(m, d_rec, nreads, d_off, stride, group);
-        return map_add_keys_direct(m, d_keys, nkeys_in);
+        if (src.rec) return launch_count(m, src);
+        return add_keys_dev(m, d_keys, nullptr, nkeys_in, plan.check_canon);
     }
     GK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     GK_HIP(ctx, hipEventSynchronize(ctx->ev1));
@@ -550,13 +654,100 @@ static int launch_partitioned(gk_map *m, const uint8_t *d_rec, u64 nreads, const
     return GK_OK;
 }
 
+static double map_room(const gk_map *m) {
+    return max_load(m) * (double)m->capacity - (m->pending_clear ? 0.0 : (double)(m->size + m->tombstones));
+}
 // how many reads (of nk windows each) may go into one launch without risking the load limit
 static u64 reads_per_launch(gk_map *m, u64 nk) {
     if (nk == 0) return ~0ull;
-    double room = max_load(m) * (double)m->capacity - (double)(m->size + m->tombstones);
+    double room = map_room(m);
     u64 floor_occ = std::max<u64>(1ull << 24, m->capacity / 4);
     u64 occ = room > (double)floor_occ ? (u64)room : floor_occ;
     return std::max<u64>(1, occ / nk);
+}
+// how many windows one partitioned batch may hold: bounded by the scratch it needs (two key buffers, the spill list)
+// next to what is free in HBM, and by a default of 2^31 keys (32 GB of 8-byte-key scratch; gk_map_set_max_batch_keys)
+static u64 part_batch_keys(gk_map *m) {
+    u64 cap = m->max_batch_keys ? m->max_batch_keys : (1ull << 31);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const gk::PartScratch *ps = m->part;
+        (void)ps;
+        const double per_key = 8.0 * m->W * (1.125 + 1.0 + 1.0 / 16) + 1.0;      // bufA + bufB + spill (+ range matrix, bounded above)
+        // the scratch a previous batch left allocated is reused, so it counts as available: approximate by a share of the whole card
+        const double avail = std::max((double)free_b, 0.35 * (double)total_b);
+        cap = std::min<u64>(cap, (u64)(0.5 * avail / per_key));
+    }
+    return std::max<u64>(cap, 1ull << 20);
+}
+
+// One batch of windows (device records) or keys: pick the path, make room, insert.  `bound` = the batch's windows.
+// A batch that FITS the table's room even if every window were a new key goes in as before.  One that does not is, on
+// sequencing data, mostly repeats: the partitioned pipeline then runs with the distinct-key sample (PartPlan::estimate)
+// and sizes the table between its two levels for what the batch really brings.
+static int insert_batch(gk_map *m, const ReadSrc &src, const u64 *d_keys, u64 nkeys_in, u64 bound, bool verbatim = false, double grow_ahead = 1.0) {
+    gk_ctx *ctx = m->ctx;
+    if (bound && use_partitioned(m, bound)) {
+        PartPlan plan;
+        plan.grow_ahead = grow_ahead;
+        plan.fine_exact = m->repeats;
+        plan.check_canon = verbatim;
+        const bool fits = (double)bound <= map_room(m);
+        if (!fits) {
+            plan.estimate = true;
+            // the L1 bucket of a key must survive a mid-batch growth: only tables of >= 256 segments (lnb1 = 8) keep theirs
+            if (m->lnb1 < 8 && !ctx->hook_no_reserve) {
+                const u64 want = (u64)(256.0 * (double)(1ull << seg_bits_for(m->W)) * target_load(m));
+                const u64 have = m->pending_clear ? 0 : m->size + m->tombstones;
+                const u64 more = std::max<u64>(want, have) - have + 1;
+                if (int rc = map_make_room(m, more, more, m->pending_clear)) return rc;
+            }
+            if (m->lnb1 < 8) plan.estimate = false;
+            if (!plan.estimate && !m->pending_clear && !ctx->hook_no_reserve) { if (int rc = map_reserve(m, bound)) return rc; }
+        }
+        return launch_partitioned(m, src, d_keys, nkeys_in, bound, plan);
+    }
+    if (int rc = map_materialize(m)) return rc;
+    if (int rc = map_reserve(m, bound)) return rc;
+    if (src.rec) return launch_count(m, src);
+    GK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    if (int rc = add_keys_dev(m, d_keys, nullptr, nkeys_in, verbatim)) return rc;
+    GK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    GK_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    GK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    m->last_count_ms += ms;
+    m->direct_launches++;
+    return GK_OK;
+}
+
+static void reset_call_stats(gk_map *m) {
+    m->last_count_ms = 0.f;
+    m->last_count_occ = 0;
+    for (float &x : m->phase_ms) x = 0.f;
+}
+
+// fixed-stride device records, nk_max windows per record at most: cut into batches and insert
+static int count_fixed_records(gk_map *m, ReadSrc src, u64 nk, u64 windows_total /* exact if known, else 0 */) {
+    const uint8_t *rec = src.rec;
+    const u64 nreads = src.nreads;
+    u64 done = 0;
+    while (done < nreads) {
+        const u64 left = nreads - done;
+        // candidate: everything that is left as ONE partitioned batch (bounded by its scratch); the direct path
+        // instead takes what the table has room for
+        u64 chunk = std::min<u64>(left, std::max<u64>(1, part_batch_keys(m) / std::max<u64>(nk, 1)));
+        u64 bound = windows_total && chunk == nreads ? windows_total : chunk * nk;
+        if (!(nk && use_partitioned(m, bound))) {
+            chunk = std::min(left, reads_per_launch(m, nk));
+            bound = windows_total && chunk == nreads ? windows_total : chunk * nk;
+        }
+        src.rec = rec + done * src.stride;
+        src.nreads = chunk;
+        if (int rc = insert_batch(m, src, nullptr, 0, bound, false, (double)left / (double)chunk)) return rc;
+        done += chunk;
+    }
+    return GK_OK;
 }
 
 int gk_map_count_reads_dev(gk_map *m, const void *dev_records, uint64_t nreads, int read_len, uint64_t *occurrences) {
@@ -565,30 +756,16 @@ int gk_map_count_reads_dev(gk_map *m, const void *dev_records, uint64_t nreads, 
     if (occurrences) *occurrences = 0;
     if (!dev_records && nreads) return fail(ctx, GK_E_INVALID, "gk_map_count_reads_dev: null records");
     if (read_len < 0 || read_len > 255) return fail(ctx, GK_E_FORMAT, "read_len must be 0..255 (one length byte per record)");
-    m->last_count_ms = 0.f;
-    m->last_count_occ = 0;
-    for (float &x : m->phase_ms) x = 0.f;
+    reset_call_stats(m);
     if (nreads == 0) return GK_OK;
-    const u32 stride = 1 + (read_len + 3) / 4;
+    ReadSrc src;
+    src.rec = (const uint8_t *)dev_records;
+    src.nreads = nreads;
+    src.stride = 1 + (read_len + 3) / 4;
+    src.max_len = read_len;
     const u64 nk = read_len >= m->k ? (u64)(read_len - m->k + 1) : 0;
     if (int rc = reset_occ_counter(m)) return rc;
-    const uint8_t *rec = (const uint8_t *)dev_records;
-    u64 done = 0;
-    while (done < nreads) {
-        u64 chunk = std::min(nreads - done, reads_per_launch(m, nk));
-        if (nk && use_partitioned(m, chunk * nk)) {
-            // (GK_TEST_NO_RESERVE: test hook — leave the table too small on purpose so that segments fill up in P5
-            //  and the failed-segment replay runs; hashed keys never get there on their own)
-            const bool no_reserve = getenv("GK_TEST_NO_RESERVE") != nullptr;
-            if (!m->pending_clear && !no_reserve) { if (int rc = map_reserve(m, chunk * nk)) return rc; }
-            if (int rc = launch_partitioned(m, rec + done * stride, chunk, nullptr, stride, nullptr, 0, chunk * nk)) return rc;
-        } else {
-            if (int rc = map_materialize(m)) return rc;
-            if (int rc = map_reserve(m, chunk * nk)) return rc;
-            if (int rc = launch_count(m, rec + done * stride, chunk, nullptr, stride)) return rc;
-        }
-        done += chunk;
-    }
+    if (int rc = count_fixed_records(m, src, nk, 0)) return rc;
     uint64_t occ = 0;
     if (int rc = read_occ_counter(m, &occ)) return rc;
     m->last_count_occ = occ;
@@ -604,25 +781,26 @@ int gk_map_count_superkmers_dev(gk_map *m, const void *dev_records, uint64_t nre
     gk_ctx *ctx = m->ctx;
     if (occurrences) *occurrences = 0;
     if (!dev_records && nrecords) return fail(ctx, GK_E_INVALID, "gk_map_count_superkmers_dev: null records");
-    m->last_count_ms = 0.f;
-    m->last_count_occ = 0;
-    for (float &x : m->phase_ms) x = 0.f;
+    reset_call_stats(m);
     if (nrecords == 0) return GK_OK;
-    const u32 stride = m->k <= 31 ? 16u : 32u;
-    const u64 max_run = (u64)((stride - 1) * 4 - m->k + 1);
+    ReadSrc src;
+    src.rec = (const uint8_t *)dev_records;
+    src.nreads = nrecords;
+    src.stride = m->k <= 31 ? 16u : 32u;
+    src.max_len = (int)(src.stride - 1) * 4;
+    const u64 max_run = (u64)(src.max_len - m->k + 1);
     if (kmers_total > nrecords * max_run) return fail(ctx, GK_E_INVALID, "kmers_total exceeds what the records can hold");
     if (int rc = reset_occ_counter(m)) return rc;
-    const uint8_t *rec = (const uint8_t *)dev_records;
     // a record holds <= max_run windows but typically a minimizer's reach, ~(k-m+2)/2: pick the lane
     // group that keeps the wave full
-    const int group = lanes_per_read(std::min<int>((int)max_run, std::max(8, (m->k - 9) * 3 / 4)));
-    if (use_partitioned(m, kmers_total)) {
-        if (!m->pending_clear) { if (int rc = map_reserve(m, kmers_total)) return rc; }
-        if (int rc = launch_partitioned(m, rec, nrecords, nullptr, stride, nullptr, 0, kmers_total, group)) return rc;
+    src.group = lanes_per_read(std::min<int>((int)max_run, std::max(8, (m->k - 9) * 3 / 4)));
+    // The announced total sizes the pipeline's regions; records that hold MORE than announced (a peer that lies) can only
+    // overflow capped regions into the spill list and are reported below.  The exact-L1 test form has no caps: give it the hard bound.
+    const u64 bound = ctx->hook_part_exact ? nrecords * max_run : kmers_total;
+    if (part_batch_keys(m) >= bound) {
+        if (int rc = insert_batch(m, src, nullptr, 0, bound)) return rc;
     } else {
-        if (int rc = map_materialize(m)) return rc;
-        if (int rc = map_reserve(m, kmers_total)) return rc;
-        if (int rc = launch_count(m, rec, nrecords, nullptr, stride, group)) return rc;
+        if (int rc = count_fixed_records(m, src, max_run, 0)) return rc;       // (huge exchange: batches bounded by what their slots can hold)
     }
     uint64_t occ = 0;
     if (int rc = read_occ_counter(m, &occ)) return rc;
@@ -638,9 +816,7 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
     gk_ctx *ctx = m->ctx;
     if (occurrences) *occurrences = 0;
     if (!bin && nreads) return fail(ctx, GK_E_INVALID, "gk_map_count_reads: null stream");
-    m->last_count_ms = 0.f;
-    m->last_count_occ = 0;
-    for (float &x : m->phase_ms) x = 0.f;
+    reset_call_stats(m);
     if (nreads == 0) return GK_OK;
     if (int rc = reset_occ_counter(m)) return rc;
     // Walk the record framing once on the host (one length byte per record, PairedEndData.scala:24-31),
@@ -694,9 +870,6 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
         if (!offs.empty()) offs.push_back((u32)(pos - chunk_begin));
         const size_t cbytes = pos - chunk_begin;
         const u64 creads = r - r_begin;
-        const bool partitioned = occ && use_partitioned(m, occ);
-        if (!partitioned) { if (int rc = map_materialize(m)) return rc; }
-        if (!(partitioned && m->pending_clear)) { if (int rc = map_reserve(m, occ)) return rc; }
         if (m->stage_bytes < cbytes + 64) {
             if (m->d_stage) GK_HIP(ctx, hipFree(m->d_stage));
             m->d_stage = nullptr;
@@ -714,18 +887,18 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
         GK_HIP(ctx, hipMemcpyAsync(m->d_stage, bin + chunk_begin, cbytes, hipMemcpyHostToDevice, ctx->stream));
         // a chunk of equal-length records (the usual case: one sequencing run) is a fixed-stride array: no offset
         // table to upload, and the partitioned path can take its one-extraction form
-        const u32 *d_off = nullptr;
-        u32 stride = 0;
-        if (uniform && first_len >= 0 && !getenv("GK_HOST_RAGGED")) stride = 1 + (u32)(first_len + 3) / 4;   // (env: A/B hook)
-        else {
-            GK_HIP(ctx, hipMemcpyAsync(m->d_offsets, offs.data(), offs.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
-            d_off = (const u32 *)m->d_offsets;
-        }
-        if (partitioned) {
-            if (int rc = launch_partitioned(m, (const uint8_t *)m->d_stage, creads, d_off, stride, nullptr, 0, occ)) return rc;
+        ReadSrc src;
+        src.rec = (const uint8_t *)m->d_stage;
+        src.nreads = creads;
+        if (uniform && first_len >= 0 && !ctx->hook_host_ragged) {
+            src.stride = 1 + (u32)(first_len + 3) / 4;
+            src.max_len = first_len;
         } else {
-            if (int rc = launch_count(m, (const uint8_t *)m->d_stage, creads, d_off, stride)) return rc;
+            GK_HIP(ctx, hipMemcpyAsync(m->d_offsets, offs.data(), offs.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+            src.off = (const u32 *)m->d_offsets;
+            src.max_len = 255;             // the host has walked this framing: every length byte is what the offsets say
         }
+        if (int rc = insert_batch(m, src, nullptr, 0, occ)) return rc;
     }
     uint64_t occ = 0;
     if (int rc = read_occ_counter(m, &occ)) return rc;
@@ -735,7 +908,7 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
     return GK_OK;
 }
 
-static int add_keys_dev(gk_map *m, const u64 *d_keys, const i32 *d_counts, u64 n) {
+static int add_keys_dev(gk_map *m, const u64 *d_keys, const i32 *d_counts, u64 n, bool verbatim) {
     gk_ctx *ctx = m->ctx;
     u64 done = 0;
     while (done < n) {
@@ -744,10 +917,10 @@ static int add_keys_dev(gk_map *m, const u64 *d_keys, const i32 *d_counts, u64 n
         int grid = grid_for(ctx, chunk, BLOCK);
         if (m->W == 1)
             hipLaunchKernelGGL(k_add_keys<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_keys + done,
-                               d_counts ? d_counts + done : nullptr, chunk, table_of<1>(m), m->d_ctr);
+                               d_counts ? d_counts + done : nullptr, chunk, table_of<1>(m), m->d_ctr, verbatim ? m->k : 0);
         else
             hipLaunchKernelGGL(k_add_keys<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_keys + 2 * done,
-                               d_counts ? d_counts + done : nullptr, chunk, table_of<2>(m), m->d_ctr);
+                               d_counts ? d_counts + done : nullptr, chunk, table_of<2>(m), m->d_ctr, verbatim ? m->k : 0);
         GK_HIP(ctx, hipGetLastError());
         if (int rc = map_sync_counters(m)) return rc;
         done += chunk;
@@ -761,35 +934,29 @@ int map_add_keys_direct(gk_map *m, const uint64_t *d_keys, uint64_t n) { return 
 }
 extern "C" {
 
+}  // extern "C"
+namespace gk {
+int map_insert_keys_dev(gk_map *m, const uint64_t *keys, uint64_t n, bool verbatim) {
+    reset_call_stats(m);
+    m->last_count_occ = n;
+    const ReadSrc none;
+    u64 done = 0;
+    while (done < n) {
+        u64 chunk = std::min<u64>(n - done, part_batch_keys(m));
+        if (!use_partitioned(m, chunk)) chunk = std::min(n - done, reads_per_launch(m, 1));
+        if (int rc = insert_batch(m, none, keys + done * m->W, chunk, chunk, verbatim)) return rc;
+        done += chunk;
+    }
+    return GK_OK;
+}
+}
+extern "C" {
+
 int gk_map_update_inc_dev(gk_map *m, const void *dev_keys, uint64_t n) {
     if (int rc = check_map_lazy(m)) return rc;
     if (!dev_keys && n) return fail(m->ctx, GK_E_INVALID, "gk_map_update_inc_dev: null keys");
     if (n == 0) return GK_OK;
-    m->last_count_ms = 0.f;
-    m->last_count_occ = n;
-    for (float &x : m->phase_ms) x = 0.f;
-    const u64 *keys = (const u64 *)dev_keys;
-    u64 done = 0;
-    while (done < n) {
-        const u64 chunk = std::min(n - done, reads_per_launch(m, 1));
-        if (use_partitioned(m, chunk)) {
-            if (!m->pending_clear) { if (int rc = map_reserve(m, chunk)) return rc; }
-            if (int rc = launch_partitioned(m, nullptr, 0, nullptr, 0, keys + done * m->W, chunk, chunk)) return rc;
-        } else {
-            if (int rc = map_materialize(m)) return rc;
-            gk_ctx *ctx = m->ctx;
-            GK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-            if (int rc = add_keys_dev(m, keys + done * m->W, nullptr, chunk)) return rc;
-            GK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-            GK_HIP(ctx, hipEventSynchronize(ctx->ev1));
-            float ms = 0.f;
-            GK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-            m->last_count_ms += ms;
-            m->direct_launches++;
-        }
-        done += chunk;
-    }
-    return GK_OK;
+    return map_insert_keys_dev(m, (const u64 *)dev_keys, n, true);       // verbatim: non-canonical keys are noticed (gk_graph_build)
 }
 
 // validate that every key fits in 2k bits — the C-ABI form of `assert(key.length == k)`
@@ -805,18 +972,24 @@ static int check_key_bits(const gk_map *m, const uint64_t *lo, const uint64_t *h
     return GK_OK;
 }
 
-static int upload_keys(gk_map *m, const uint64_t *lo, const uint64_t *hi, uint64_t n, u64 **d_keys) {
+}  // extern "C"
+namespace gk {
+// Pooled scratch of the point-query / scan entry points: grown on demand, kept with the map — `apply()` from the
+// Scala adapter is one gk_map_get_batch per call, and a hipMalloc/hipFree pair per call is two implicit device syncs.
+void *map_scratch(gk_map *m, size_t bytes) {
+    if (m->scratch_bytes >= bytes) return m->d_scratch;
     gk_ctx *ctx = m->ctx;
-    std::vector<u64> inter((size_t)n * m->W);
-    for (uint64_t i = 0; i < n; i++) {
-        if (m->W == 1) inter[i] = lo[i];
-        else { inter[2 * i] = lo[i]; inter[2 * i + 1] = hi[i]; }
-    }
-    GK_HIP(ctx, hipMalloc((void **)d_keys, inter.size() * sizeof(u64) + 8));
-    GK_HIP(ctx, hipMemcpyAsync(*d_keys, inter.data(), inter.size() * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
-    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return GK_OK;
+    if (m->d_scratch) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(m->d_scratch); }
+    m->d_scratch = nullptr; m->scratch_bytes = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 4, 1 << 16);
+    hipError_t e = hipMalloc(&m->d_scratch, want);
+    if (e != hipSuccess) { (void)hipGetLastError(); (void)fail(ctx, GK_E_CAPACITY, std::string("scratch allocation failed: ") + hipGetErrorString(e)); return nullptr; }
+    m->scratch_bytes = want;
+    return m->d_scratch;
 }
+}
+extern "C" {
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 int gk_map_add_counts(gk_map *m, const uint64_t *lo, const uint64_t *hi, const int32_t *counts, uint64_t n) {
     if (int rc = check_map(m)) return rc;
@@ -824,72 +997,77 @@ int gk_map_add_counts(gk_map *m, const uint64_t *lo, const uint64_t *hi, const i
     if (n == 0) return GK_OK;
     if (!lo || (m->W == 2 && !hi)) return fail(ctx, GK_E_INVALID, "null key array");
     if (int rc = check_key_bits(m, lo, hi, n)) return rc;
-    u64 *d_keys = nullptr;
-    i32 *d_counts = nullptr;
-    int rc = upload_keys(m, lo, hi, n, &d_keys);
-    if (rc == GK_OK && counts) {
-        hipError_t e = hipMalloc((void **)&d_counts, n * sizeof(i32));
-        if (e == hipSuccess) e = hipMemcpyAsync(d_counts, counts, n * sizeof(i32), hipMemcpyHostToDevice, ctx->stream);
-        if (e != hipSuccess) rc = hip_fail(ctx, e, "gk_map_add_counts");
+    const size_t kb = al256(n * 8 * m->W);
+    char *base = (char *)map_scratch(m, kb + al256(n * 4));
+    if (!base) return GK_E_CAPACITY;
+    u64 *d_keys = (u64 *)base;
+    i32 *d_counts = counts ? (i32 *)(base + kb) : nullptr;
+    if (m->W == 1) {
+        GK_HIP(ctx, hipMemcpyAsync(d_keys, lo, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        std::vector<u64> inter((size_t)n * 2);
+        for (uint64_t i = 0; i < n; i++) { inter[2 * i] = lo[i]; inter[2 * i + 1] = hi[i]; }
+        GK_HIP(ctx, hipMemcpyAsync(d_keys, inter.data(), inter.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        GK_HIP(ctx, hipStreamSynchronize(ctx->stream));          // `inter` dies with this scope
     }
-    if (rc == GK_OK) rc = add_keys_dev(m, d_keys, d_counts, n);
-    if (d_keys) (void)hipFree(d_keys);
-    if (d_counts) (void)hipFree(d_counts);
-    return rc;
+    if (counts) GK_HIP(ctx, hipMemcpyAsync(d_counts, counts, n * sizeof(i32), hipMemcpyHostToDevice, ctx->stream));
+    return add_keys_dev(m, d_keys, d_counts, n, true);      // host keys are taken verbatim
 }
 
 int gk_map_update_inc(gk_map *m, const uint64_t *lo, const uint64_t *hi, uint64_t n) {
     return gk_map_add_counts(m, lo, hi, nullptr, n);
 }
 
+// replace the table by one sized for its live keys (after deleteAll: the reference rescales too, ArrayDNAMap.scala:214)
+static int map_compact(gk_map *m) {
+    gk_ctx *ctx = m->ctx;
+    uint32_t nnb2, nlnb1;
+    uint64_t ncap;
+    plan_segments(m->W, (uint64_t)((double)m->size / target_load(m)) + 1, &nnb2, &nlnb1, &ncap);
+    if (ncap > m->capacity) { nnb2 = m->nb2; nlnb1 = m->lnb1; ncap = m->capacity; }
+    void *nslots = nullptr;
+    if (alloc_table(ctx, m->W, ncap, &nslots) != GK_OK) { if (nslots) (void)hipFree(nslots); return GK_OK; }   // keep tombstones if memory is short
+    int g2 = grid_for(ctx, m->capacity, BLOCK);
+    if (m->W == 1)
+        hipLaunchKernelGGL(k_rehash<1>, dim3(g2), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, m->capacity,
+                           Table<1>{(Slot<1> *)nslots, nnb2, nlnb1, 0u}, m->d_ctr);
+    else
+        hipLaunchKernelGGL(k_rehash<2>, dim3(g2), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots, m->capacity,
+                           Table<2>{(Slot<2> *)nslots, nnb2, nlnb1, m->k == 64 ? 1u : 0u}, m->d_ctr);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(nslots); return hip_fail(ctx, e, "table compaction"); }
+    if (int rc = map_sync_counters(m)) { (void)hipFree(nslots); return rc; }       // a failed rehash leaves the old table in place
+    GK_HIP(ctx, hipFree(m->slots));
+    m->slots = nslots;
+    m->capacity = ncap;
+    m->nb2 = nnb2;
+    m->lnb1 = nlnb1;
+    m->tombstones = 0;
+    return GK_OK;
+}
+
 int gk_map_filter_lt(gk_map *m, int32_t rounds) {
     if (int rc = check_map(m)) return rc;
     gk_ctx *ctx = m->ctx;
-    unsigned long long *d_removed = nullptr;
-    GK_HIP(ctx, hipMalloc((void **)&d_removed, sizeof(unsigned long long)));
+    unsigned long long *d_removed = (unsigned long long *)map_scratch(m, 256);
+    if (!d_removed) return GK_E_CAPACITY;
     GK_HIP(ctx, hipMemsetAsync(d_removed, 0, sizeof(unsigned long long), ctx->stream));
     int grid = grid_for(ctx, m->capacity, BLOCK * 4);
     if (m->W == 1) hipLaunchKernelGGL(k_filter_lt<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (Slot<1> *)m->slots, m->capacity, rounds, d_removed);
     else hipLaunchKernelGGL(k_filter_lt<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (Slot<2> *)m->slots, m->capacity, rounds, d_removed);
-    hipError_t e = hipGetLastError();
+    GK_HIP(ctx, hipGetLastError());
     unsigned long long removed = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&removed, d_removed, sizeof(removed), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_removed);
-    if (e != hipSuccess) return hip_fail(ctx, e, "gk_map_filter_lt");
+    GK_HIP(ctx, hipMemcpyAsync(&removed, d_removed, sizeof(removed), hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     m->size -= removed;
     m->tombstones += removed;
     unsigned long long sz = m->size;
     GK_HIP(ctx, hipMemcpyAsync(&m->d_ctr->size, &sz, sizeof(sz), hipMemcpyHostToDevice, ctx->stream));
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    // The reference rescales after deleteAll (ArrayDNAMap.scala:214).  Here: rebuild into a table
-    // sized for the survivors whenever tombstones exist, so that the read-only graph phase probes a
-    // clean, cache-friendlier table.
-    if (m->tombstones) {
-        uint32_t nnb2, nlnb1;
-        uint64_t ncap;
-        plan_segments(m->W, (uint64_t)((double)m->size / target_load(m)) + 1, &nnb2, &nlnb1, &ncap);
-        if (ncap > m->capacity) { nnb2 = m->nb2; nlnb1 = m->lnb1; ncap = m->capacity; }
-        void *nslots = nullptr;
-        if (alloc_table(ctx, m->W, ncap, &nslots) != GK_OK) return GK_OK;   // keep tombstones if memory is short
-        int g2 = grid_for(ctx, m->capacity, BLOCK);
-        if (m->W == 1)
-            hipLaunchKernelGGL(k_rehash<1>, dim3(g2), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, m->capacity,
-                               Table<1>{(Slot<1> *)nslots, nnb2, nlnb1, 0u}, m->d_ctr);
-        else
-            hipLaunchKernelGGL(k_rehash<2>, dim3(g2), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots, m->capacity,
-                               Table<2>{(Slot<2> *)nslots, nnb2, nlnb1, m->k == 64 ? 1u : 0u}, m->d_ctr);
-        GK_HIP(ctx, hipGetLastError());
-        GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        GK_HIP(ctx, hipFree(m->slots));
-        m->slots = nslots;
-        m->capacity = ncap;
-        m->nb2 = nnb2;
-        m->lnb1 = nlnb1;
-        m->tombstones = 0;
-        return map_sync_counters(m);
-    }
-    return GK_OK;
+    // Rebuild into a table sized for the survivors whenever tombstones exist, so that the read-only graph
+    // phase probes a clean, cache-friendlier table.
+    return m->tombstones ? map_compact(m) : GK_OK;
 }
 
 int gk_map_get_batch(gk_map *m, const uint64_t *lo, const uint64_t *hi, uint64_t n, int32_t *counts_out, uint8_t *found_out) {
@@ -898,28 +1076,21 @@ int gk_map_get_batch(gk_map *m, const uint64_t *lo, const uint64_t *hi, uint64_t
     if (n == 0) return GK_OK;
     if (!lo || (m->W == 2 && !hi)) return fail(ctx, GK_E_INVALID, "null key array");
     if (int rc = check_key_bits(m, lo, hi, n)) return rc;
-    u64 *d_lo = nullptr, *d_hi = nullptr;
-    i32 *d_cnt = nullptr;
-    uint8_t *d_found = nullptr;
-    hipError_t e = hipMalloc((void **)&d_lo, n * 8);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_lo, lo, n * 8, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && m->W == 2) {
-        e = hipMalloc((void **)&d_hi, n * 8);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_hi, hi, n * 8, hipMemcpyHostToDevice, ctx->stream);
-    }
-    if (e == hipSuccess && counts_out) e = hipMalloc((void **)&d_cnt, n * 4);
-    if (e == hipSuccess && found_out) e = hipMalloc((void **)&d_found, n);
-    if (e == hipSuccess) {
-        int grid = grid_for(ctx, n, BLOCK);
-        if (m->W == 1) hipLaunchKernelGGL(k_get<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_lo, d_hi, n, table_of<1>(m), d_cnt, d_found);
-        else hipLaunchKernelGGL(k_get<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_lo, d_hi, n, table_of<2>(m), d_cnt, d_found);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess && counts_out) e = hipMemcpyAsync(counts_out, d_cnt, n * 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && found_out) e = hipMemcpyAsync(found_out, d_found, n, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_lo); (void)hipFree(d_hi); (void)hipFree(d_cnt); (void)hipFree(d_found);
-    if (e != hipSuccess) return hip_fail(ctx, e, "gk_map_get_batch");
+    const size_t b8 = al256(n * 8), b4 = al256(n * 4), b1 = al256(n);
+    char *base = (char *)map_scratch(m, 2 * b8 + b4 + b1);
+    if (!base) return GK_E_CAPACITY;
+    u64 *d_lo = (u64 *)base, *d_hi = m->W == 2 ? (u64 *)(base + b8) : nullptr;
+    i32 *d_cnt = counts_out ? (i32 *)(base + 2 * b8) : nullptr;
+    uint8_t *d_found = found_out ? (uint8_t *)(base + 2 * b8 + b4) : nullptr;
+    GK_HIP(ctx, hipMemcpyAsync(d_lo, lo, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (d_hi) GK_HIP(ctx, hipMemcpyAsync(d_hi, hi, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    int grid = grid_for(ctx, n, BLOCK);
+    if (m->W == 1) hipLaunchKernelGGL(k_get<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_lo, d_hi, n, table_of<1>(m), d_cnt, d_found);
+    else hipLaunchKernelGGL(k_get<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_lo, d_hi, n, table_of<2>(m), d_cnt, d_found);
+    GK_HIP(ctx, hipGetLastError());
+    if (counts_out) GK_HIP(ctx, hipMemcpyAsync(counts_out, d_cnt, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (found_out) GK_HIP(ctx, hipMemcpyAsync(found_out, d_found, n, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GK_OK;
 }
 
@@ -931,29 +1102,48 @@ int gk_map_export(gk_map *m, uint64_t *lo, uint64_t *hi, int32_t *counts, uint64
     if (m->size == 0) return GK_OK;
     if (!lo || !counts || (m->W == 2 && !hi)) return fail(ctx, GK_E_INVALID, "null export buffer");
     const u64 cnt = m->size;
-    u64 *d_lo = nullptr, *d_hi = nullptr;
-    i32 *d_cnt = nullptr;
-    unsigned long long *d_cursor = nullptr;
-    hipError_t e = hipMalloc((void **)&d_lo, cnt * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_hi, cnt * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_cnt, cnt * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_cursor, 8);
-    if (e == hipSuccess) e = hipMemsetAsync(d_cursor, 0, 8, ctx->stream);
-    if (e == hipSuccess) {
-        int grid = grid_for(ctx, m->capacity, BLOCK);
-        if (m->W == 1) hipLaunchKernelGGL(k_export<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, m->capacity, 0u, d_lo, d_hi, d_cnt, d_cursor);
-        else hipLaunchKernelGGL(k_export<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots, m->capacity, m->k == 64 ? 1u : 0u, d_lo, d_hi, d_cnt, d_cursor);
-        e = hipGetLastError();
-    }
+    const size_t b8 = al256(cnt * 8), b4 = al256(cnt * 4);
+    char *base = (char *)map_scratch(m, 2 * b8 + b4 + 256);
+    if (!base) return GK_E_CAPACITY;
+    u64 *d_lo = (u64 *)base, *d_hi = (u64 *)(base + b8);
+    i32 *d_cnt = (i32 *)(base + 2 * b8);
+    unsigned long long *d_cursor = (unsigned long long *)(base + 2 * b8 + b4);
+    GK_HIP(ctx, hipMemsetAsync(d_cursor, 0, 8, ctx->stream));
+    int grid = grid_for(ctx, m->capacity, BLOCK);
+    if (m->W == 1) hipLaunchKernelGGL(k_export<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, m->capacity, 0u, d_lo, d_hi, d_cnt, d_cursor);
+    else hipLaunchKernelGGL(k_export<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots, m->capacity, m->k == 64 ? 1u : 0u, d_lo, d_hi, d_cnt, d_cursor);
+    GK_HIP(ctx, hipGetLastError());
     unsigned long long written = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&written, d_cursor, 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(lo, d_lo, cnt * 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess && hi) e = hipMemcpyAsync(hi, d_hi, cnt * 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(counts, d_cnt, cnt * 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_lo); (void)hipFree(d_hi); (void)hipFree(d_cnt); (void)hipFree(d_cursor);
-    if (e != hipSuccess) return hip_fail(ctx, e, "gk_map_export");
+    GK_HIP(ctx, hipMemcpyAsync(&written, d_cursor, 8, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP(ctx, hipMemcpyAsync(lo, d_lo, cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (hi) GK_HIP(ctx, hipMemcpyAsync(hi, d_hi, cnt * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP(ctx, hipMemcpyAsync(counts, d_cnt, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (written != cnt) return fail(ctx, GK_E_STATE, "export wrote " + std::to_string(written) + " entries, size says " + std::to_string(cnt));
+    return GK_OK;
+}
+
+int gk_map_verify(gk_map *m, uint64_t *live, uint64_t *bad_slots, uint64_t *sum_counts) {
+    if (int rc = check_map(m)) return rc;
+    gk_ctx *ctx = m->ctx;
+    unsigned long long *d = (unsigned long long *)map_scratch(m, 256), h[3] = {0, 0, 0};
+    if (!d) return GK_E_CAPACITY;
+    GK_HIP(ctx, hipMemsetAsync(d, 0, 24, ctx->stream));
+    int grid = grid_for(ctx, m->capacity, BLOCK);
+    if (m->W == 1) hipLaunchKernelGGL(k_verify<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, table_of<1>(m), d);
+    else hipLaunchKernelGGL(k_verify<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, table_of<2>(m), d);
+    GK_HIP(ctx, hipGetLastError());
+    GK_HIP(ctx, hipMemcpyAsync(h, d, 24, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (live) *live = h[0];
+    if (bad_slots) *bad_slots = h[1];
+    if (sum_counts) *sum_counts = h[2];
+    return GK_OK;
+}
+
+int gk_map_set_max_batch_keys(gk_map *m, uint64_t keys) {
+    if (int rc = check_map_lazy(m)) return rc;
+    m->max_batch_keys = keys;
     return GK_OK;
 }
 
@@ -964,13 +1154,15 @@ int gk_map_stats(gk_map *m, char *json, size_t cap) {
                      "{\"k\":%d,\"key_words\":%d,\"slot_bytes\":%zu,\"slots\":%llu,\"size\":%llu,\"tombstones\":%llu,"
                      "\"load\":%.6f,\"occurrences\":%llu,\"grows\":%llu,\"last_count_kernel_ms\":%.6f,"
                      "\"last_count_occurrences\":%llu,\"partitioned_launches\":%llu,\"direct_launches\":%llu,"
-                     "\"spilled_keys\":%llu,\"failed_segments\":%llu,\"retries_direct\":%llu,\"device\":%d,\"cu_count\":%d}",
+                     "\"spilled_keys\":%llu,\"failed_segments\":%llu,\"retries_direct\":%llu,\"est_new_distinct_last_batch\":%llu,"
+                     "\"noncanonical_keys\":%s,\"repeat_heavy\":%s,\"device\":%d,\"cu_count\":%d}",
                      m->k, m->W, slot_bytes(m->W), (unsigned long long)m->capacity, (unsigned long long)m->size,
                      (unsigned long long)m->tombstones, m->capacity ? (double)m->size / (double)m->capacity : 0.0,
                      (unsigned long long)m->total_occurrences, (unsigned long long)m->grows, m->last_count_ms,
                      (unsigned long long)m->last_count_occ, (unsigned long long)m->part_launches,
                      (unsigned long long)m->direct_launches, (unsigned long long)m->spilled_keys,
-                     (unsigned long long)m->failed_segments, (unsigned long long)m->retries_direct, m->ctx->device, m->ctx->cu_count);
+                     (unsigned long long)m->failed_segments, (unsigned long long)m->retries_direct, (unsigned long long)m->est_distinct_last,
+                     m->dirty ? "true" : "false", m->repeats ? "true" : "false", m->ctx->device, m->ctx->cu_count);
     if (w < 0 || (size_t)w >= cap) return fail(m->ctx, GK_E_CAPACITY, "stats buffer too small");
     return GK_OK;
 }

@@ -49,28 +49,46 @@ __device__ __forceinline__ u64 stage_tile(u32 *tile, const uint8_t *rec, u64 gb,
 // A wave is cut into 64/G groups of G lanes (G = 64, 32 or 16); each group takes one read and its
 // lanes take window positions, so short records (super-k-mers hold ~10 windows) still fill the wave.
 // offsets == nullptr: fixed stride.
+// max_len: the longest read the caller's buffers were sized for (the declared read_len of a `_dev`
+// call, what the record slot can hold for super-k-mers, 255 for host streams whose framing the host
+// has walked).  A device record is untrusted input: a length byte above max_len is CLAMPED — LDS
+// arrays and key regions downstream are sized from max_len — and reported through *bad
+// (-> GK_E_FORMAT), never followed.
+struct WindowLimits {
+    int max_len;     // bases
+    u32 *bad;        // device flag, may be nullptr
+};
+__device__ __forceinline__ int record_len(const uint8_t *tb, u32 ro, const WindowLimits &lim) {
+    int len = (int)tb[ro];                            // [len:u8]
+    if (len > lim.max_len) {
+        len = lim.max_len;
+        if (lim.bad) *lim.bad = 1u;
+    }
+    return len;
+}
 template <int W, class F>
 __device__ __forceinline__ void for_each_window(const u32 *tile, u64 a0, u64 r0, int nr, const u32 *offsets, u32 stride, int k,
-                                                int G, F f) {
+                                                int G, WindowLimits lim, F f) {
     const uint8_t *tb = reinterpret_cast<const uint8_t *>(tile);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int per_wave = 64 / G, sub = lane / G, gl = lane & (G - 1);
     for (int r = wave * per_wave + sub; r < nr; r += nwaves * per_wave) {
         const u32 ro = (u32)((offsets ? (u64)offsets[r0 + r] : (r0 + r) * stride) - a0);
-        const int nk = (int)tb[ro] - k + 1;           // [len:u8]; reads shorter than k are skipped
+        const int nk = record_len(tb, ro, lim) - k + 1;     // reads shorter than k are skipped
         const u32 bit0 = (ro + 1) * 8;
         for (int p = gl; p < nk; p += G) f(tile_kmer(tile, bit0 + 2 * p, k, (Kmer<W> *)nullptr));
     }
 }
 // same walk, but the callback also gets the tile-local read index and the window position
 template <int W, class F>
-__device__ __forceinline__ void for_each_window_at(const u32 *tile, u64 a0, u64 r0, int nr, u32 stride, int k, int G, F f) {
+__device__ __forceinline__ void for_each_window_at(const u32 *tile, u64 a0, u64 r0, int nr, u32 stride, int k, int G,
+                                                   WindowLimits lim, F f) {
     const uint8_t *tb = reinterpret_cast<const uint8_t *>(tile);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int per_wave = 64 / G, sub = lane / G, gl = lane & (G - 1);
     for (int r = wave * per_wave + sub; r < nr; r += nwaves * per_wave) {
         const u32 ro = (u32)((r0 + r) * stride - a0);
-        const int nk = (int)tb[ro] - k + 1;
+        const int nk = record_len(tb, ro, lim) - k + 1;
         const u32 bit0 = (ro + 1) * 8;
         for (int p = gl; p < nk; p += G) f(r, p, tile_kmer(tile, bit0 + 2 * p, k, (Kmer<W> *)nullptr));
     }

@@ -37,6 +37,10 @@ class Context:
         except Exception:
             pass
 
+    def set_option(self, name: str, value: int):
+        """Test / A-B switches (include/genome_amd.h: gk_ctx_set_option)."""
+        L.check(L.lib().gk_ctx_set_option(self.h, name.encode(), int(value)), self.h)
+
     def sync(self):
         """Wait for everything queued on the context's stream."""
         L.check(L.lib().gk_ctx_sync(self.h), self.h)
@@ -217,6 +221,15 @@ class HipDNAMap:
 
     def clear(self):
         L.check(L.lib().gk_map_clear(self.h), self.ctx.h)
+
+    def verify(self):
+        """-> (live slots, bad slots, sum of counts): the table's invariants, checked on the device."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        L.check(L.lib().gk_map_verify(self.h, C.byref(a), C.byref(b), C.byref(c)), self.ctx.h)
+        return a.value, b.value, c.value
+
+    def set_max_batch_keys(self, keys: int):
+        L.check(L.lib().gk_map_set_max_batch_keys(self.h, int(keys)), self.ctx.h)
 
     def slots(self) -> int:
         n = C.c_uint64()

@@ -59,6 +59,11 @@ void gk_ctx_destroy(gk_ctx *ctx);
 const char *gk_last_error(const gk_ctx *ctx);    /* ctx may be NULL: last error of the calling thread */
 int gk_ctx_device(const gk_ctx *ctx);
 int gk_ctx_sync(gk_ctx *ctx);                    /* hipStreamSynchronize on the context stream */
+/* Test / A-B switches (never needed in production).  Their defaults are read from the environment ONCE, in
+ * gk_ctx_create (GK_TEST_NO_RESERVE, GK_HOST_RAGGED, GK_PART_EXACT, GK_GRAPH_UNITIGS=walk|pj); no entry point
+ * consults the environment afterwards.  Names: "test_no_reserve", "host_ragged", "part_exact" (0/1),
+ * "graph_unitigs" (0 auto, 1 one lane per edge, 2 pointer jumping). */
+int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value);
 /* raw device memory helpers for callers without their own allocator (tests, the C++ host side) */
 int gk_dev_alloc(gk_ctx *ctx, size_t nbytes, void **dev_ptr);
 int gk_dev_free(gk_ctx *ctx, void *dev_ptr);
@@ -79,19 +84,33 @@ int gk_map_clear(gk_map *m);                               /* back to an empty t
 int gk_map_set_insert_path(gk_map *m, int path);
 int gk_map_size(gk_map *m, uint64_t *n);                   /* DNAMap.size :50 (live keys) */
 int gk_map_slots(gk_map *m, uint64_t *slots);              /* current table capacity in slots */
+/* Invariants of the table, checked on the device (the reference prints `nodeMap.size` next to the expected total,
+ * Graph.scala:117): *live = live slots (== gk_map_size), *bad_slots = keys that are stored twice or in a segment
+ * their hash does not name (must be 0), *sum_counts = sum of all counts (== occurrences inserted).  Any may be NULL. */
+int gk_map_verify(gk_map *m, uint64_t *live, uint64_t *bad_slots, uint64_t *sum_counts);
+/* Upper bound on the k-mer windows one partitioned insert batch holds when a call brings more windows than the
+ * table has room for (the batch's key scratch is ~17 x W x 8 bytes per window); 0 = default (2^31, or what HBM allows). */
+int gk_map_set_max_batch_keys(gk_map *m, uint64_t keys);
 
 /* FreqFilter.add over a stream of reads (S/data/FreqFilter.scala:28-36, 44-48):
  * for every read with len >= k, every window in order -> reverse complement -> orientation with
  * the smaller signed hashCode (tie: reverse complement) -> update(y, 1, _+1).
  * `bin` is the reference `.bin` record stream [len:u8][ceil(len/4) bytes] x nreads
- * (S/data/PairedEndData.scala:20-36); *occurrences (may be NULL) = number of windows counted. */
+ * (S/data/PairedEndData.scala:20-36); *occurrences (may be NULL) = number of windows counted.
+ * The table grows as needed.  A call whose windows exceed the table's room is not assumed to bring that many NEW
+ * keys (sequencing coverage: mostly repeats): the insert pipeline samples the distinct keys it sees and sizes the
+ * table for those (gk_map_stats: "est_new_distinct_last_batch"). */
 int gk_map_count_reads(gk_map *m, const uint8_t *bin_host, size_t nbytes, uint64_t nreads, uint64_t *occurrences);
-/* same, records already in HBM and all of one length (fixed stride 1+ceil(read_len/4)) */
+/* same, records already in HBM at a fixed stride 1+ceil(read_len/4); read_len = the LONGEST record (shorter ones
+ * are fine).  Device records are untrusted input: a length byte above read_len is clamped, never followed, and
+ * the call then fails with GK_E_FORMAT (the map's contents are unspecified: clear it). */
 int gk_map_count_reads_dev(gk_map *m, const void *dev_records, uint64_t nreads, int read_len, uint64_t *occurrences);
 
 /* DNAMap.update(key, 1, _+1) for a batch of keys taken verbatim (no canonicalisation):
  * PartitionedDNAMap's owner-side insert (Messages.update1, ArrayDNAMap.scala:39).  Keys are
- * W = 1 (k<=32) or 2 (k>32) uint64 each. */
+ * W = 1 (k<=32) or 2 (k>32) uint64 each.  The map notices when a verbatim key is not the hash-rule orientation of
+ * its k-mer (FreqFilter.scala:31-32): gk_graph_build then probes both strands for every `contains`, exactly as
+ * Graph.scala:270 does, instead of the one probe a canonically filled table needs. */
 int gk_map_update_inc(gk_map *m, const uint64_t *lo, const uint64_t *hi, uint64_t n);
 /* device keys, interleaved W words per key ([lo] or [lo,hi]) as gk_shard_reads_dev emits them */
 int gk_map_update_inc_dev(gk_map *m, const void *dev_keys, uint64_t n);

@@ -1,0 +1,209 @@
+"""GPU parity tests of the insert pipeline on REPEAT-HEAVY input (sequencing coverage) and of the boundary's
+hardening (-m gpu): a call that brings far more windows than the table has room for must size the table for
+the DISTINCT keys it really holds (the distinct-key sample), the exact fine level (range matrix, no global
+atomics) and the heavy-segment loop of k_seg_insert must give the oracle's table bit for bit, a corrupt device
+record must be refused, and a table filled with verbatim non-canonical keys must still build the reference's
+graph (Graph.scala:270 probes both strands).
+"""
+import random
+
+import numpy as np
+import pytest
+
+from genome_amd import _lib as L
+from genome_amd import dna, synth
+from genome_amd.dnamap import Context, HipDNAMap
+from genome_amd.graph import buildGraph
+from oracle import oracle as O
+from oracle import pyref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def assert_same_table(got, want):
+    for name, a, b in zip(("lo", "hi", "count"), got, want):
+        assert a.shape == b.shape, f"{name}: {a.shape} vs {b.shape}"
+        assert np.array_equal(a, b), name
+
+
+def oracle_canonical(og):
+    k = og.k
+    nlo, nhi = og.nodes()
+    nodes = [dna.unpack(int(a), int(b), k) for a, b in zip(nlo, nhi)]
+    e = og.edges()
+    edges = []
+    for i in range(len(e["len"])):
+        seq = synth.bases_to_str(e["bases"][e["off"][i]:e["off"][i] + e["len"][i]])
+        edges.append((dna.unpack(int(e["slo"][i]), int(e["shi"][i]), k), dna.unpack(int(e["elo"][i]), int(e["ehi"][i]), k), seq))
+    return nodes, edges
+
+
+@pytest.mark.parametrize("k,L_", [(21, 100), (31, 150), (47, 150), (63, 150)])
+@pytest.mark.parametrize("path", ["auto", "partitioned"])
+def test_high_coverage_batch_sizes_table_for_distinct_keys(ctx, k, L_, path):
+    """60 000 reads over a 3 kbp genome (coverage in the thousands): 5-8 million windows, a few 10^4 distinct k-mers,
+    into a table created with no hint.  One call; the table must end up sized for the distinct keys (not for the
+    windows), through the estimator, the exact fine level and segments that receive more keys than they have slots."""
+    n, G = 60000, 3000
+    rec = synth.reads_mode_g(n, L_, G, 0.001, config_id=900 + k)
+    d = ctx.alloc(rec.size + 64)
+    ctx.upload(d, rec)
+    ref = O.PMap(k, 1)
+    occ = ref.count_reads(rec.tobytes(), n)
+    m = HipDNAMap(ctx, k, 0)
+    m.set_insert_path(path)
+    assert m.count_reads_dev(d, n, L_) == occ
+    st = m.stats()
+    assert st["partitioned_launches"] >= 1, st
+    assert st["size"] == ref.size()
+    # sized for what it holds: the estimate may be generous, the windows are 50-100x the distinct keys
+    assert st["slots"] < 8 * max(ref.size(), 1 << 19), st
+    assert 0 < st["est_new_distinct_last_batch"] < occ // 4, st
+    live, bad, total = m.verify()
+    assert (live, bad, total) == (ref.size(), 0, occ)
+    assert_same_table(m.sorted_items(), ref.export_sorted())
+    # a second call on top of the content (table read back into LDS, estimate of NEW keys ~ 0): counts double
+    assert m.count_reads_dev(d, n, L_) == occ
+    lo, hi, cnt = ref.export_sorted()
+    assert_same_table(m.sorted_items(), (lo, hi, cnt * 2))
+    assert m.stats()["slots"] == st["slots"], "no new keys: the table must not have grown"
+    m.close(); ctx.free(d)
+
+
+@pytest.mark.parametrize("k", [31, 55])
+def test_batches_bounded_by_scratch(ctx, k):
+    """gk_map_set_max_batch_keys: the same call cut into several partitioned batches (table rebuilt from empty by the
+    first, merged into by the others) gives the same table."""
+    n, L_, G = 40000, 120, 20000
+    rec = synth.reads_mode_g(n, L_, G, 0.01, config_id=77 + k)
+    d = ctx.alloc(rec.size + 64)
+    ctx.upload(d, rec)
+    ref = O.PMap(k, 1)
+    occ = ref.count_reads(rec.tobytes(), n)
+    m = HipDNAMap(ctx, k, 1 << 16)
+    m.set_insert_path("partitioned")
+    m.set_max_batch_keys(1 << 20)
+    assert m.count_reads_dev(d, n, L_) == occ
+    st = m.stats()
+    assert st["partitioned_launches"] >= 3, st
+    assert m.verify() == (ref.size(), 0, occ)
+    assert_same_table(m.sorted_items(), ref.export_sorted())
+    m.close(); ctx.free(d)
+
+
+@pytest.mark.parametrize("k", [21, 47])
+def test_exact_fine_level_on_ragged_stream_many_ranges(ctx, k):
+    """Ragged host stream (exact pipeline: P1, P2, range matrix P3, atomics-free P4) big enough for several ranges per
+    L1 bucket and with repeats."""
+    rnd = random.Random(5 + k)
+    g = "".join(rnd.choice("AGCT") for _ in range(40000))
+    reads = []
+    for _ in range(30000):
+        ln = rnd.randint(k, min(255, k + 100))
+        s = rnd.randrange(0, len(g) - ln + 1)
+        r = g[s:s + ln]
+        reads.append(R.rev_comp(r) if rnd.random() < 0.5 else r)
+    binb = dna.reads_to_bin(reads)
+    ref = O.PMap(k, 1)
+    occ = ref.count_reads(binb, len(reads))
+    m = HipDNAMap(ctx, k, occ)
+    m.set_insert_path("partitioned")
+    assert m.count_reads(binb, len(reads)) == occ
+    assert m.stats()["partitioned_launches"] >= 1
+    assert m.verify() == (ref.size(), 0, occ)
+    assert_same_table(m.sorted_items(), ref.export_sorted())
+    m.close()
+
+
+@pytest.mark.parametrize("k,declared,actual", [(31, 149, 152), (31, 100, 255), (21, 60, 61), (47, 149, 150)])
+def test_oversized_length_byte_is_refused_not_followed(ctx, k, declared, actual):
+    """A device record whose length byte exceeds the declared read_len (same stride or not) used to index past LDS
+    arrays sized from read_len.  Now: clamped in the kernels, GK_E_FORMAT on return — on every path that streams
+    device records."""
+    n = 5000
+    rec = synth.reads_mode_u(n, declared, 3)
+    stride = rec.shape[1]
+    bad = rec.copy()
+    bad[n // 2, 0] = actual
+    d = ctx.alloc(bad.size + 64)
+    ctx.upload(d, bad)
+    for path in ("direct", "partitioned"):
+        m = HipDNAMap(ctx, k, n * 200)
+        m.set_insert_path(path)
+        with pytest.raises(L.GkError) as e:
+            m.count_reads_dev(d, n, declared)
+        assert e.value.code == L.GK_E_FORMAT, (path, e.value)
+        # the handle stays usable: clear, then the clean stream counts as usual
+        m.clear()
+        ctx.upload(d, rec)
+        assert m.count_reads_dev(d, n, declared) == n * max(0, declared - k + 1)
+        ctx.upload(d, bad)
+        m.close()
+    from genome_amd.prefilter import HipPrefilter
+    pf = HipPrefilter(ctx, k, n * 100)
+    with pytest.raises(L.GkError) as e:
+        pf.add_reads_dev(d, n, declared)
+    assert e.value.code == L.GK_E_FORMAT
+    pf.close()
+    out = ctx.alloc(n * 40 * 32)
+    with pytest.raises(L.GkError) as e:
+        ctx.shard_superkmers(k, d, n, declared, 4, out, n * 40)
+    assert e.value.code == L.GK_E_FORMAT
+    ctx.free(out); ctx.free(d)
+    assert stride == synth.record_stride(declared)
+
+
+@pytest.mark.parametrize("k", [15, 31, 34, 55])
+def test_verbatim_noncanonical_keys_still_build_the_reference_graph(ctx, k):
+    """The ABI takes keys verbatim (gk_map_update_inc / add_counts).  Fill a table with the REVERSE COMPLEMENT of every
+    canonical key (and, for a few k-mers, both orientations): the reference's `contains` probes both strands
+    (Graph.scala:270), so its graph is the same as for the canonical table — and so must ours be."""
+    rnd = random.Random(k)
+    g = "".join(rnd.choice("AGCT") for _ in range(1500))
+    reads = []
+    for _ in range(500):
+        ln = rnd.randint(k + 5, min(255, k + 80))
+        s = rnd.randrange(0, len(g) - ln + 1)
+        r = g[s:s + ln]
+        r = "".join(c if rnd.random() >= 0.01 else rnd.choice([x for x in "AGCT" if x != c]) for c in r)
+        reads.append(R.rev_comp(r) if rnd.random() < 0.5 else r)
+    binb = dna.reads_to_bin(reads)
+    ref = O.PMap(k, 1)
+    ref.count_reads(binb, len(reads))
+    ref.delete_lt(2)
+    lo, hi, cnt = ref.export_sorted()
+    want = oracle_canonical(O.Graph(ref))
+    # the oracle's own graph from a reverse-complemented table (its contains() is the reference's, both strands)
+    ref_rc = O.PMap(k, 1)
+    keys = [dna.unpack(int(a), int(b), k) for a, b in zip(lo, hi)]
+    flipped = [R.rev_comp(s) for s in keys]
+    both = set(range(0, len(keys), 17))
+    m = HipDNAMap(ctx, k, len(keys) * 2)
+    ins = [flipped[i] for i in range(len(keys))] + [keys[i] for i in both]
+    for s in ins:
+        plo, phi = dna.pack(s)
+        ref_rc.update_inc(plo, phi)
+    m.update_inc(ins)
+    assert m.stats()["noncanonical_keys"] is True
+    og = O.Graph(ref_rc)
+    got = buildGraph(k, m)
+    assert got.canonical() == oracle_canonical(og)
+    # and it is the canonical table's graph (strand symmetry of the reference's construction)
+    assert got.canonical() == want
+    got.removeBubbles(); og.remove_bubbles(); got.simplifyGraph(); og.simplify()
+    assert got.canonical() == oracle_canonical(og)
+    got.close(); m.close()
+    # a canonically filled table does not pay for it
+    m2 = HipDNAMap(ctx, k)
+    m2.count_reads(binb, len(reads))
+    assert m2.stats()["noncanonical_keys"] is False
+    m2.update_inc(keys[:50])                      # verbatim but canonical keys: still clean
+    assert m2.stats()["noncanonical_keys"] is False
+    m2.close()

@@ -25,6 +25,15 @@ def ctx():
     c.close()
 
 
+@pytest.fixture
+def unitig_mode(ctx):
+    """Force one of the two unitig constructions for the duration of a test (gk_ctx_set_option)."""
+    def _set(mode):
+        ctx.set_option("graph_unitigs", {"auto": 0, "walk": 1, "pj": 2}[mode])
+    yield _set
+    ctx.set_option("graph_unitigs", 0)
+
+
 def oracle_canonical(og):
     k = og.k
     nlo, nhi = og.nodes()
@@ -210,10 +219,10 @@ def test_graph_at_scale_properties(ctx):
 
 @pytest.mark.parametrize("mode", ["walk", "pj"])
 @pytest.mark.parametrize("k,seed,hap", [(11, 2, 2), (31, 5, 2), (35, 6, 2), (64, 9, 1)])
-def test_unitig_construction_modes_agree_with_oracle(ctx, monkeypatch, mode, k, seed, hap):
+def test_unitig_construction_modes_agree_with_oracle(ctx, unitig_mode, mode, k, seed, hap):
     """Both unitig constructions — one lane walking each edge (k_walk) and pointer jumping
     (k_pj_*) — must give the oracle's graph, on bushy graphs and on a long clean unitig."""
-    monkeypatch.setenv("GK_GRAPH_UNITIGS", mode)
+    unitig_mode(mode)
     rnd = random.Random(seed)
     for err, nreads in ((0.01, 700), (0.0, 400)):
         reads = _reads(rnd, nreads, k + 5, min(255, k + 90), 1500, err, hap)
@@ -288,11 +297,11 @@ def test_hash_tie_kmers_table_and_graph(ctx, idx, rounds):
     for a, b in zip(m.sorted_items(), ref.export_sorted()):
         assert np.array_equal(a, b)
     for mode in ("walk", "pj"):
-        os.environ["GK_GRAPH_UNITIGS"] = mode
+        ctx.set_option("graph_unitigs", {"walk": 1, "pj": 2}[mode])
         try:
             g, og = buildGraph(k, m), O.Graph(ref)
         finally:
-            del os.environ["GK_GRAPH_UNITIGS"]
+            ctx.set_option("graph_unitigs", 0)
         assert g.canonical() == oracle_canonical(og)
         g.removeBubbles(); og.remove_bubbles(); g.simplifyGraph(); og.simplify()
         assert g.canonical() == oracle_canonical(og)

@@ -371,30 +371,33 @@ def test_interleaved_key_buffer(ctx, k, n, mode):
 
 
 @pytest.mark.parametrize("k", [31, 47])
-def test_failed_segments_are_replayed(ctx, k, monkeypatch):
+def test_failed_segments_are_replayed(ctx, k):
     """P5 hands a segment that fills up back to the host (grow + replay through the direct path).  Hashed keys do not
-    fill a segment of a properly reserved table, so the test hook GK_TEST_NO_RESERVE leaves the table too small: the
-    first call's second launch and the whole second call push loaded segments past their 2048 slots."""
-    monkeypatch.setenv("GK_TEST_NO_RESERVE", "1")
-    n, L_ = 40000, 150
-    rec = synth.reads_mode_u(2 * n, L_, 77)
-    d = ctx.alloc(rec.size + 64)
-    ctx.upload(d, rec)
-    distinct = n * (L_ - k + 1)
-    ref = O.PMap(k, 1)
-    m = HipDNAMap(ctx, k, int(distinct * 0.5))           # ~0.77 x distinct slots: the batch cannot fit
-    m.set_insert_path("partitioned")
-    assert m.count_reads_dev(d, n, L_) == distinct
-    ref.count_reads(rec[:n].tobytes(), n)
-    st = m.stats()
-    assert st["failed_segments"] > 0 and st["partitioned_launches"] >= 1, st
-    assert_same_table(m.sorted_items(), ref.export_sorted())
-    first = st["failed_segments"]
-    assert m.count_reads_dev(d + n * rec.shape[1], n, L_) == distinct
-    ref.count_reads(rec[n:].tobytes(), n)
-    assert m.stats()["failed_segments"] > first
-    assert_same_table(m.sorted_items(), ref.export_sorted())
-    m.close(); ctx.free(d)
+    fill a segment of a properly reserved table, so the test hook "test_no_reserve" leaves the table too small: both
+    calls push segments past their 2048 slots."""
+    ctx.set_option("test_no_reserve", 1)
+    try:
+        n, L_ = 40000, 150
+        rec = synth.reads_mode_u(2 * n, L_, 77)
+        d = ctx.alloc(rec.size + 64)
+        ctx.upload(d, rec)
+        distinct = n * (L_ - k + 1)
+        ref = O.PMap(k, 1)
+        m = HipDNAMap(ctx, k, int(distinct * 0.5))           # ~0.77 x distinct slots: the batch cannot fit
+        m.set_insert_path("partitioned")
+        assert m.count_reads_dev(d, n, L_) == distinct
+        ref.count_reads(rec[:n].tobytes(), n)
+        st = m.stats()
+        assert st["failed_segments"] > 0 and st["partitioned_launches"] >= 1, st
+        assert_same_table(m.sorted_items(), ref.export_sorted())
+        first = st["failed_segments"]
+        assert m.count_reads_dev(d + n * rec.shape[1], n, L_) == distinct
+        ref.count_reads(rec[n:].tobytes(), n)
+        assert m.stats()["failed_segments"] > first
+        assert_same_table(m.sorted_items(), ref.export_sorted())
+        m.close(); ctx.free(d)
+    finally:
+        ctx.set_option("test_no_reserve", 0)
 
 
 @pytest.mark.parametrize("k", [21, 55])
