@@ -51,8 +51,13 @@ SIGNATURES = {
     "gk_ctx_device": (C.c_int, [vp]),
     "gk_ctx_sync": (C.c_int, [vp]),
     "gk_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
-    "gk_map_verify": (C.c_int, [vp, u64p, u64p, u64p]),
+    "gk_map_verify": (C.c_int, [vp, u64p, u64p, u64p, u64p]),
     "gk_map_set_max_batch_keys": (C.c_int, [vp, C.c_uint64]),
+    "gk_map_trim": (C.c_int, [vp]),
+    "gk_host_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
+    "gk_host_free": (C.c_int, [vp, vp]),
+    "gk_host_register": (C.c_int, [vp, vp, C.c_size_t]),
+    "gk_host_unregister": (C.c_int, [vp, vp]),
     "gk_dev_alloc": (C.c_int, [vp, C.c_size_t, C.POINTER(vp)]),
     "gk_dev_free": (C.c_int, [vp, vp]),
     "gk_dev_upload": (C.c_int, [vp, vp, vp, C.c_size_t]),
@@ -76,6 +81,7 @@ SIGNATURES = {
     "gk_map_last_count_kernel": (C.c_int, [vp, C.POINTER(C.c_float), u64p]),
     "gk_map_last_phase_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
     "gk_shard_reads_dev": (C.c_int, [vp, C.c_int, vp, C.c_uint64, C.c_int, C.c_int, vp, C.c_uint64, u64p]),
+    "gk_map_count_foreign": (C.c_int, [vp, C.c_int, C.c_int, u64p]),
     "gk_owner_of": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_int]),
     "gk_skm_slot_bytes": (C.c_int, [C.c_int]),
     "gk_shard_superkmers_dev": (C.c_int, [vp, C.c_int, vp, C.c_uint64, C.c_int, C.c_int, vp, C.c_uint64, u64p, u64p]),
@@ -87,6 +93,9 @@ SIGNATURES = {
     "gk_graph_remove_bubbles": (C.c_int, [vp]),
     "gk_graph_remove_edges": (C.c_int, [vp, u64p, u64p, u8p, C.c_uint64, u64p]),
     "gk_graph_retain_largest": (C.c_int, [vp, u64p, u64p]),
+    "gk_graph_component_stats": (C.c_int, [vp, C.POINTER(C.c_uint32), u64p, C.c_uint64, u64p]),
+    "gk_graph_checksum": (C.c_int, [vp, u64p, u64p]),
+    "gk_graph_build_stats": (C.c_int, [vp, C.POINTER(C.c_float), u64p, C.POINTER(C.c_int)]),
     "gk_graph_export_nodes": (C.c_int, [vp, u64p, u64p, C.c_uint64, u64p]),
     "gk_graph_export_edges": (C.c_int, [vp, u64p, u64p, u64p, u64p, i64p, i64p, C.c_uint64, u64p, u8p, C.c_uint64, u64p]),
     "gk_graph_out_order": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -21,6 +21,7 @@
 // Where the reference's result depends on node iteration order (out-edge insertion order after
 // simplifyGraph), this file reproduces "ascending k-mer order", the oracle's deterministic choice.
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -60,6 +61,11 @@ struct gk_graph {
     GraphView v{};
     u64 node_cap = 0, edge_cap = 0, pool_cap = 0, pool_used = 0;
     u64 live_nodes = 0, live_edges = 0, live_len = 0;
+    // wall time of the phases of gk_graph_build (every phase ends in a stream sync): classify, terminals -> nodes + edge
+    // stubs, unitig measure (k_walk pass 0 / pointer jumping), pool reservation, unitig emit, node index + counts
+    float build_ms[6] = {0, 0, 0, 0, 0, 0};
+    u64 walked_bases = 0;        // bases emitted by the unitig construction (= total edge length at build time)
+    int used_pj = 0;
 };
 
 __device__ __forceinline__ int order_count(u32 o) { return (int)(o & 7u); }
@@ -272,45 +278,78 @@ __global__ __launch_bounds__(BLOCK) void k_make_nodes(Table<W> t, int k, const u
 }
 
 // buildEdges (Graph.scala:349-365): from a node, follow the unique outgoing base until the next
-// terminal k-mer.  write == 0: measure (end node, length, in-degree); write == 1: emit the bases
-// 2 bits each into the pool at e_off.  One lane per edge; every step is one dependent table probe.
+// terminal k-mer.  One lane per edge; every step is one dependent table probe.
+// pass 0: walk once — end node, length, in-degree — keeping the first WALK_BUF bases in registers; the workgroup then
+//         reserves the pool bytes of ALL its edges with one atomic and an edge that fits the registers (nearly all of
+//         them on a bushy error graph: 7 bases on average at C3) writes its sequence straight away.
+// pass 1: only for edges longer than WALK_BUF: walk again and emit the bases 2 bits each at e_off (assigned in pass 0).
+static constexpr u32 WALK_BUF = 128;          // bases kept in four 64-bit registers
 template <int W>
-__global__ __launch_bounds__(BLOCK) void k_walk(Table<W> t, int k, GraphView g, const u32 *slot_node, int write, u64 max_steps,
-                                                u32 *err) {
-    for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < g.n_edges; e += (u64)gridDim.x * BLOCK) {
-        const u32 n = g.e_start[e];
-        const int b0 = g.e_first[e];
-        Kmer<W> cur = append_base(node_kmer<W>(g, n), b0, k);          // read.drop(1) :+ base  :353
-        u64 len = 1;
-        u32 acc = (u32)b0;                                              // builder += base        :352
-        const u64 off = write ? g.e_off[e] : 0;
-        u32 end = NONE;
-        for (u64 step = 0; step <= max_steps; step++) {
-            bool fwd;
-            i64 slot = table_find_either(t, cur, k, &fwd);
-            if (slot < 0) { *err = 1; break; }
-            const u32 aux = t.slots[slot].aux;
-            if (aux & AUX_TERMINAL) {                                   // nodeMap.contains(seq)  :355
-                end = slot_node[slot] + (fwd ? 0u : 1u);
-                break;
+__global__ __launch_bounds__(BLOCK) void k_walk(Table<W> t, int k, GraphView g, const u32 *slot_node, int pass, u64 max_steps,
+                                                unsigned long long *pool_cursor, unsigned long long *n_long, u32 *err) {
+    __shared__ u32 lds4[BLOCK / 64];
+    __shared__ unsigned long long s_base;
+    const u64 ngroups = (g.n_edges + BLOCK - 1) / BLOCK;
+    for (u64 grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const u64 e = grp * BLOCK + threadIdx.x;
+        const bool active = e < g.n_edges && (pass == 0 || g.e_len[e] > WALK_BUF);
+        u64 len = 0;
+        u64 b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+        if (active) {
+            const u32 n = g.e_start[e];
+            const int first = g.e_first[e];
+            Kmer<W> cur = append_base(node_kmer<W>(g, n), first, k);       // read.drop(1) :+ base  :353
+            len = 1;
+            u32 acc = (u32)first;                                           // builder += base        :352
+            b0 = (u64)first;
+            const u64 off = pass ? g.e_off[e] : 0;
+            u32 end = NONE;
+            for (u64 step = 0; step <= max_steps; step++) {
+                bool fwd;
+                i64 slot = table_find_either(t, cur, k, &fwd);
+                if (slot < 0) { *err = 1; break; }
+                const u32 aux = t.slots[slot].aux;
+                if (aux & AUX_TERMINAL) {                                   // nodeMap.contains(seq)  :355
+                    end = slot_node[slot] + (fwd ? 0u : 1u);
+                    break;
+                }
+                const u32 om = fwd ? ((aux >> 4) & 15u) : rev4(aux & 15u);  // outcoming(seq)         :356
+                if (__popc(om) != 1) { *err = 2; break; }                   // assert(out.size == 1)  :357
+                const int nb = __ffs(om) - 1;
+                if (pass) {
+                    acc |= (u32)nb << ((len & 3) * 2);
+                    if ((len & 3) == 3) { g.pool[off + (len >> 2)] = (uint8_t)acc; acc = 0; }
+                } else if (len < WALK_BUF) {
+                    const u64 bits = (u64)nb << ((len & 31) * 2);
+                    if (len < 32) b0 |= bits; else if (len < 64) b1 |= bits; else if (len < 96) b2 |= bits; else b3 |= bits;
+                }
+                len++;
+                cur = append_base(cur, nb, k);                              // seq.drop(1) :+ out(0)  :360
             }
-            const u32 om = fwd ? ((aux >> 4) & 15u) : rev4(aux & 15u);  // outcoming(seq)         :356
-            if (__popc(om) != 1) { *err = 2; break; }                   // assert(out.size == 1)  :357
-            const int nb = __ffs(om) - 1;
-            if (write) {
-                acc |= (u32)nb << ((len & 3) * 2);
-                if ((len & 3) == 3) { g.pool[off + (len >> 2)] = (uint8_t)acc; acc = 0; }
+            if (pass) {
+                if (len & 3) g.pool[off + (len >> 2)] = (uint8_t)acc;
+            } else {
+                g.e_end[e] = end;
+                g.e_len[e] = len;
+                if (end != NONE) atomicAdd(&g.in_deg[end], 1u);             // end.inEdgeIds += id    :181
+                else *err = 3;
             }
-            len++;
-            cur = append_base(cur, nb, k);                              // seq.drop(1) :+ out(0)  :360
         }
-        if (write) {
-            if (len & 3) g.pool[off + (len >> 2)] = (uint8_t)acc;
-        } else {
-            g.e_end[e] = end;
-            g.e_len[e] = len;
-            if (end != NONE) atomicAdd(&g.in_deg[end], 1u);             // end.inEdgeIds += id    :181
-            else *err = 3;
+        if (pass) continue;
+        // pool bytes of this workgroup's edges: one atomic (per-block totals stay < 2^32 for edges up to 16M bases; longer ones reserve alone)
+        const u64 bytes = active ? (len + 3) / 4 : 0;
+        const u32 small = bytes < (1u << 22) ? (u32)bytes : 0u;
+        u64 o = block_reserve(small, pool_cursor, lds4, &s_base);
+        if (!active) continue;
+        if (small != bytes) o = atomicAdd(pool_cursor, (unsigned long long)bytes);
+        g.e_off[e] = o;
+        if (len > WALK_BUF) { atomicAdd(n_long, 1ull); continue; }
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const u64 word = w == 0 ? b0 : w == 1 ? b1 : w == 2 ? b2 : b3;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if ((u64)(w * 8 + j) < bytes) g.pool[o + w * 8 + j] = (uint8_t)(word >> (8 * j));
         }
     }
 }
@@ -735,6 +774,64 @@ __global__ __launch_bounds__(BLOCK) void k_cc_sizes(GraphView g, const u32 *pare
     __syncthreads();
     if (threadIdx.x == 0 && s_roots) atomicAdd(ncomp, (unsigned long long)s_roots);
 }
+// summed out-edge length per component (GraphBuilder.scala:44-46: comp.flatMap(_.outEdges.values).map(_.seq.size).sum): every
+// live edge adds its length to the root of its start node; lanes of a wave that share a root are combined first
+__global__ __launch_bounds__(BLOCK) void k_cc_edge_len(GraphView g, const u32 *parent, unsigned long long *len) {
+    const int lane = threadIdx.x & 63;
+    for (u64 e0 = (u64)blockIdx.x * BLOCK + (threadIdx.x & ~63u); e0 < g.n_edges; e0 += (u64)gridDim.x * BLOCK) {
+        const u64 e = e0 + lane;
+        const bool active = e < g.n_edges && g.e_alive[e];
+        const u32 root = active ? parent[g.e_start[e]] : 0xffffffffu;
+        const unsigned long long mylen = active ? g.e_len[e] : 0ull;
+        unsigned long long todo = __ballot(active);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const u32 lr = __shfl(root, leader);
+            const bool mine = active && root == lr;
+            const unsigned long long same = __ballot(mine);
+            unsigned long long part = mine ? mylen : 0ull;
+            for (int d = 32; d; d >>= 1) part += __shfl_down(part, d);
+            part = __shfl(part, 0);
+            if (lane == leader) atomicAdd(&len[lr], part);
+            todo &= ~same;
+        }
+    }
+}
+// one (node count, summed out-edge length) pair per component, in root order
+__global__ __launch_bounds__(BLOCK) void k_cc_collect(GraphView g, const u32 *parent, const u32 *size, const unsigned long long *len,
+                                                      u32 *out_nodes, unsigned long long *out_len, unsigned long long *cursor) {
+    __shared__ u32 lds4[BLOCK / 64];
+    __shared__ unsigned long long s_base;
+    const u64 ngroups = (g.n_nodes + BLOCK - 1) / BLOCK;
+    for (u64 grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const u64 n = grp * BLOCK + threadIdx.x;
+        const bool root = n < g.n_nodes && g.node_alive[n] && parent[n] == (u32)n;
+        const u64 o = block_reserve(root ? 1u : 0u, cursor, lds4, &s_base);
+        if (root) { out_nodes[o] = size[n]; out_len[o] = len[n]; }
+    }
+}
+// order-independent checksums of the canonical serialisation: nodes = k-mers; edges = (start k-mer,
+// end k-mer, length, every base) — ids, array order and pool offsets do not enter
+__global__ __launch_bounds__(BLOCK) void k_graph_checksum(GraphView g, unsigned long long *out /* nodes, edges */) {
+    u64 cn = 0, ce = 0;
+    const u64 tid = (u64)blockIdx.x * BLOCK + threadIdx.x, stride = (u64)gridDim.x * BLOCK;
+    for (u64 n = tid; n < g.n_nodes; n += stride)
+        if (g.node_alive[n]) cn += mix64(g.node_lo[n] ^ mix64(g.node_hi[n] ^ 0x13198a2e03707344ULL));
+    for (u64 e = tid; e < g.n_edges; e += stride) {
+        if (!g.e_alive[e]) continue;
+        const u32 s = g.e_start[e], t = g.e_end[e];
+        u64 h = mix64(g.node_lo[s] ^ mix64(g.node_hi[s] ^ 1)) + 3 * mix64(g.node_lo[t] ^ mix64(g.node_hi[t] ^ 2)) + 5 * mix64(g.e_len[e]);
+        const u64 off = g.e_off[e], len = g.e_len[e], nbytes = (len + 3) / 4;
+        for (u64 i = 0; i < nbytes; i++) {
+            u32 b = g.pool[off + i];
+            if (i == nbytes - 1 && (len & 3)) b &= (1u << ((len & 3) * 2)) - 1u;      // bits after the last base are not content
+            h = mix64(h ^ (b + 0x9e3779b97f4a7c15ULL * (i + 1)));
+        }
+        ce += h;
+    }
+    for (int d = 32; d; d >>= 1) { cn += __shfl_down(cn, d); ce += __shfl_down(ce, d); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], cn); atomicAdd(&out[1], ce); }
+}
 __global__ __launch_bounds__(BLOCK) void k_cc_max(GraphView g, const u32 *size, u32 *best) {
     u32 m = 0;
     for (u64 n = (u64)blockIdx.x * BLOCK + threadIdx.x; n < g.n_nodes; n += (u64)gridDim.x * BLOCK)
@@ -953,12 +1050,19 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
         return code;
     };
     if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: alloc"));
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](int i) {
+        const auto now = std::chrono::steady_clock::now();
+        g->build_ms[i] += std::chrono::duration<float, std::milli>(now - t_prev).count();
+        t_prev = now;
+    };
     // 1. degree classification of every live key
     hipLaunchKernelGGL(k_classify<W>, dim3(ggrid(ctx, m->capacity)), dim3(BLOCK), 0, ctx->stream, t, k, &d_cnt[0]);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: classify"));
+    lap(0);
     const u64 nT = h_cnt[0];
     if (2 * nT >= (u64)NONE) return done(fail(ctx, GK_E_CAPACITY, "more than 2^32 graph nodes"));
     // 2. terminal slots -> nodes (both strands) and edge stubs
@@ -986,6 +1090,7 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
         // every edge slot the walk will visit must have been written by k_make_nodes
         if (h_cnt[3] != nE) return done(fail(ctx, GK_E_STATE, "edge stub count mismatch: " + std::to_string(h_cnt[3]) + " vs " + std::to_string(nE)));
     }
+    lap(1);
     // 3. unitigs: measure, reserve the sequence pool, emit.  One lane per edge walking base by base
     //    (k_walk) when edges are short; pointer jumping when they are long (see k_pj_* above).
     if (nE) {
@@ -1022,23 +1127,37 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
             if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: pj rounds")); }
             hipLaunchKernelGGL(k_pj_edges<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node, stA, d_err);
         } else {
-            hipLaunchKernelGGL(k_walk<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node, 0, m->capacity + 1, d_err);
+            // every oriented interior k-mer lies on exactly one edge: sum of lengths <= edges + 2 x live keys, and every edge
+            // rounds up to a byte — the pool can be allocated before the walk, so the walk can write as it goes
+            g->pool_cap = ((nE + 2 * m->size) / 4 + nE + 16) / 4 * 4;
+            e = hipMalloc((void **)&g->v.pool, g->pool_cap);
+            if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: pool")); }
+            hipLaunchKernelGGL(k_walk<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node, 0, m->capacity + 1, &d_cnt[4], &d_cnt[6], d_err);
         }
         e = hipGetLastError();
-        if (e == hipSuccess) {
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        lap(2);
+        g->used_pj = use_pj ? 1 : 0;
+        if (e == hipSuccess && use_pj) {
             hipLaunchKernelGGL(k_reserve_pool, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, g->v, (u64)0, &d_cnt[4]);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 40, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 56, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: walk")); }
         if (h_err) { pj_free(); return done(fail(ctx, GK_E_STATE, "unitig construction failed (code " + std::to_string(h_err) +
                                     "): the table changed since classification or is inconsistent")); }
         g->pool_used = h_cnt[4];
-        g->pool_cap = (std::max<u64>(g->pool_used, 1) + 7) / 4 * 4;        // whole 32-bit words (k_pj_emit ORs words)
-        e = hipMalloc((void **)&g->v.pool, g->pool_cap);
-        if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: pool")); }
+        if (use_pj) {
+            g->pool_cap = (std::max<u64>(g->pool_used, 1) + 7) / 4 * 4;        // whole 32-bit words (k_pj_emit ORs words)
+            e = hipMalloc((void **)&g->v.pool, g->pool_cap);
+            if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: pool")); }
+        } else if (g->pool_used > g->pool_cap) {
+            pj_free();
+            return done(fail(ctx, GK_E_STATE, "edge sequences need " + std::to_string(g->pool_used) + " bytes, bound was " + std::to_string(g->pool_cap)));
+        }
+        lap(3);
         if (use_pj) {
             e = hipMemsetAsync(g->v.pool, 0, g->pool_cap, ctx->stream);
             if (e == hipSuccess) {
@@ -1047,21 +1166,25 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
                 e = hipGetLastError();
             }
             if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream);
-        } else {
-            hipLaunchKernelGGL(k_walk<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node, 1, m->capacity + 1, d_err);
+        } else if (h_cnt[6]) {       // edges longer than the walk's register buffer: second walk, emitting
+            hipLaunchKernelGGL(k_walk<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node, 1, m->capacity + 1, &d_cnt[4], &d_cnt[6], d_err);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         pj_free();
         if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: emit"));
         if (h_err) return done(fail(ctx, GK_E_STATE, "unitig emission failed (code " + std::to_string(h_err) + ")"));
+        lap(4);
     } else {
         e = hipMalloc((void **)&g->v.pool, 1);
         if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: pool"));
         g->pool_cap = 1;
     }
     if ((rc = graph_build_index(g)) != GK_OK) return done(rc);
-    return done(graph_refresh_counts(g));
+    rc = graph_refresh_counts(g);
+    g->walked_bases = g->live_len;
+    lap(5);
+    return done(rc);
 }
 
 static int check_graph(const gk_graph *g) {
@@ -1203,6 +1326,54 @@ int gk_graph_remove_edges(gk_graph *g, const uint64_t *start_lo, const uint64_t 
     return graph_refresh_counts(g);
 }
 
+}  // extern "C"
+
+// Graph.components (Graph.scala:54-72): label every live node with its component's root (min-label hooking + pointer
+// jumping) and count nodes per root.  *parent / *size are hipMalloc'ed here ([n_nodes] each); the caller frees them.
+static int graph_components(gk_graph *g, u32 **parent_out, u32 **size_out, u64 *ncomp) {
+    gk_ctx *ctx = g->ctx;
+    GraphView &v = g->v;
+    u32 *parent = nullptr, *size = nullptr, *d_changed = nullptr;
+    unsigned long long *d_ncomp = nullptr;
+    auto bail = [&](int code) {
+        for (void *p : {(void *)parent, (void *)size, (void *)d_changed, (void *)d_ncomp}) if (p) (void)hipFree(p);
+        return code;
+    };
+    hipError_t e = hipMalloc((void **)&parent, std::max<u64>(v.n_nodes, 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&size, std::max<u64>(v.n_nodes, 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_changed, 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_ncomp, 8);
+    if (e != hipSuccess) return bail(hip_fail(ctx, e, "graph components: alloc"));
+    const int gn = ggrid(ctx, std::max<u64>(v.n_nodes, 1)), ge = ggrid(ctx, std::max<u64>(v.n_edges, 1));
+    hipLaunchKernelGGL(k_cc_init, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, parent);
+    for (int it = 0; it < 100000; it++) {
+        u32 changed = 0;
+        e = hipMemsetAsync(d_changed, 0, 4, ctx->stream);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(k_cc_hook, dim3(ge), dim3(BLOCK), 0, ctx->stream, v, parent, d_changed);
+        hipLaunchKernelGGL(k_cc_compress, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, parent);
+        e = hipMemcpyAsync(&changed, d_changed, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess || !changed) break;
+    }
+    if (e != hipSuccess) return bail(hip_fail(ctx, e, "graph components: hooking"));
+    unsigned long long h = 0;
+    e = hipMemsetAsync(size, 0, std::max<u64>(v.n_nodes, 1) * 4, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_ncomp, 0, 8, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_cc_sizes, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, parent, size, d_ncomp);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d_ncomp, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return bail(hip_fail(ctx, e, "graph components: sizes"));
+    (void)hipFree(d_changed); (void)hipFree(d_ncomp);
+    *parent_out = parent; *size_out = size; *ncomp = h;
+    return GK_OK;
+}
+
+extern "C" {
+
 int gk_graph_retain_largest(gk_graph *g, uint64_t *kept_nodes, uint64_t *components) {
     if (int rc = check_graph(g)) return rc;
     gk_ctx *ctx = g->ctx;
@@ -1210,8 +1381,10 @@ int gk_graph_retain_largest(gk_graph *g, uint64_t *kept_nodes, uint64_t *compone
     if (kept_nodes) *kept_nodes = 0;
     if (components) *components = 0;
     if (g->live_nodes == 0) return GK_OK;
-    u32 *parent = nullptr, *size = nullptr, *d_u32 = nullptr;       // d_u32: [0] changed [1] best [2] winner
-    unsigned long long *d_u64 = nullptr;                            // [0] ncomp [1] min hi [2] min lo
+    u32 *parent = nullptr, *size = nullptr, *d_u32 = nullptr;       // d_u32: [0] unused [1] best [2] winner
+    unsigned long long *d_u64 = nullptr;                            // [0] unused [1] min hi [2] min lo
+    u64 ncomp = 0;
+    if (int rc = graph_components(g, &parent, &size, &ncomp)) return rc;
     auto done = [&](int code) {
         if (parent) (void)hipFree(parent);
         if (size) (void)hipFree(size);
@@ -1219,31 +1392,15 @@ int gk_graph_retain_largest(gk_graph *g, uint64_t *kept_nodes, uint64_t *compone
         if (d_u64) (void)hipFree(d_u64);
         return code;
     };
-    hipError_t e = hipMalloc((void **)&parent, v.n_nodes * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&size, v.n_nodes * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_u32, 16);
+    hipError_t e = hipMalloc((void **)&d_u32, 16);
     if (e == hipSuccess) e = hipMalloc((void **)&d_u64, 24);
     if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_retain_largest: alloc"));
-    const int gn = ggrid(ctx, v.n_nodes), ge = ggrid(ctx, std::max<u64>(v.n_edges, 1));
-    hipLaunchKernelGGL(k_cc_init, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, parent);
-    for (int it = 0; it < 100000; it++) {
-        u32 changed = 0;
-        e = hipMemsetAsync(d_u32, 0, 4, ctx->stream);
-        if (e != hipSuccess) break;
-        hipLaunchKernelGGL(k_cc_hook, dim3(ge), dim3(BLOCK), 0, ctx->stream, v, parent, &d_u32[0]);
-        hipLaunchKernelGGL(k_cc_compress, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, parent);
-        e = hipMemcpyAsync(&changed, d_u32, 4, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess || !changed) break;
-    }
-    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_retain_largest: cc"));
+    const int gn = ggrid(ctx, v.n_nodes);
     unsigned long long h64[3] = {0, ~0ull, ~0ull};
     u32 h32[3] = {0, 0, NONE};
-    e = hipMemsetAsync(size, 0, v.n_nodes * 4, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_u64, h64, 24, hipMemcpyHostToDevice, ctx->stream);
+    e = hipMemcpyAsync(d_u64, h64, 24, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_u32, h32, 12, hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_retain_largest"));
-    hipLaunchKernelGGL(k_cc_sizes, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, parent, size, &d_u64[0]);
     hipLaunchKernelGGL(k_cc_max, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, size, &d_u32[1]);
     e = hipMemcpyAsync(h32, d_u32, 12, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1252,17 +1409,77 @@ int gk_graph_retain_largest(gk_graph *g, uint64_t *kept_nodes, uint64_t *compone
     for (int stage = 0; stage < 3; stage++)
         hipLaunchKernelGGL(k_cc_pick, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, parent, size, best, stage, &d_u64[1], &d_u32[2]);
     e = hipMemcpyAsync(h32, d_u32, 12, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(h64, d_u64, 24, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_retain_largest: pick"));
     if (h32[2] == NONE) return done(fail(ctx, GK_E_STATE, "no component selected"));
     hipLaunchKernelGGL(k_retain, dim3(ggrid(ctx, std::max(v.n_nodes, v.n_edges))), dim3(BLOCK), 0, ctx->stream, v, parent, h32[2]);
     e = hipGetLastError();
     if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_retain_largest: retain"));
-    if (components) *components = h64[0];
+    if (components) *components = ncomp;
     int rc = graph_refresh_counts(g);
     if (rc == GK_OK && kept_nodes) *kept_nodes = g->live_nodes;
     return done(rc);
+}
+
+int gk_graph_component_stats(gk_graph *g, uint32_t *nodes_per_component, uint64_t *edge_len_per_component, uint64_t cap, uint64_t *n) {
+    if (int rc = check_graph(g)) return rc;
+    gk_ctx *ctx = g->ctx;
+    GraphView &v = g->v;
+    if (n) *n = 0;
+    if (g->live_nodes == 0) return GK_OK;
+    u32 *parent = nullptr, *size = nullptr, *d_nodes = nullptr;
+    unsigned long long *len = nullptr, *d_len = nullptr, *d_cur = nullptr;
+    u64 ncomp = 0;
+    if (int rc = graph_components(g, &parent, &size, &ncomp)) return rc;
+    auto done = [&](int code) {
+        for (void *p : {(void *)parent, (void *)size, (void *)d_nodes, (void *)len, (void *)d_len, (void *)d_cur}) if (p) (void)hipFree(p);
+        return code;
+    };
+    if (n) *n = ncomp;
+    if (ncomp > cap) return done(fail(ctx, GK_E_CAPACITY, "component buffer too small: need " + std::to_string(ncomp)));
+    if (!nodes_per_component || !edge_len_per_component) return done(fail(ctx, GK_E_INVALID, "null component buffer"));
+    hipError_t e = hipMalloc((void **)&len, v.n_nodes * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_nodes, ncomp * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_len, ncomp * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_cur, 8);
+    if (e == hipSuccess) e = hipMemsetAsync(len, 0, v.n_nodes * 8, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cur, 0, 8, ctx->stream);
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_component_stats: alloc"));
+    hipLaunchKernelGGL(k_cc_edge_len, dim3(ggrid(ctx, std::max<u64>(v.n_edges, 1))), dim3(BLOCK), 0, ctx->stream, v, parent, len);
+    hipLaunchKernelGGL(k_cc_collect, dim3(ggrid(ctx, v.n_nodes)), dim3(BLOCK), 0, ctx->stream, v, parent, size, len, d_nodes, d_len, d_cur);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(nodes_per_component, d_nodes, ncomp * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(edge_len_per_component, d_len, ncomp * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_component_stats"));
+    return done(GK_OK);
+}
+
+int gk_graph_checksum(gk_graph *g, uint64_t *nodes_checksum, uint64_t *edges_checksum) {
+    if (int rc = check_graph(g)) return rc;
+    gk_ctx *ctx = g->ctx;
+    unsigned long long *d = nullptr, h[2] = {0, 0};
+    GK_HIP(ctx, hipMalloc((void **)&d, 16));
+    hipError_t e = hipMemsetAsync(d, 0, 16, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_graph_checksum, dim3(ggrid(ctx, std::max<u64>(std::max(g->v.n_nodes, g->v.n_edges), 1))), dim3(BLOCK), 0, ctx->stream, g->v, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return hip_fail(ctx, e, "gk_graph_checksum");
+    if (nodes_checksum) *nodes_checksum = h[0];
+    if (edges_checksum) *edges_checksum = h[1];
+    return GK_OK;
+}
+
+int gk_graph_build_stats(gk_graph *g, float *phase_ms6, uint64_t *walked_bases, int *pointer_jumping) {
+    if (int rc = check_graph(g)) return rc;
+    if (phase_ms6) for (int i = 0; i < 6; i++) phase_ms6[i] = g->build_ms[i];
+    if (walked_bases) *walked_bases = g->walked_bases;
+    if (pointer_jumping) *pointer_jumping = g->used_pj;
+    return GK_OK;
 }
 
 int gk_graph_export_nodes(gk_graph *g, uint64_t *lo, uint64_t *hi, uint64_t cap, uint64_t *n) {

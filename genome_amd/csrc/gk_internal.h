@@ -13,6 +13,8 @@ struct gk_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // phase boundaries of the partitioned path
+    hipStream_t copy_stream = nullptr;            // host -> device copies that overlap kernels on `stream` (host-fed inserts)
+    hipEvent_t cev[16] = {};                      // "sub-chunk j has landed" (round robin)
     int cu_count = 256;
     void *skm_counts = nullptr;      // device scratch of gk_shard_superkmers_dev (cursors, counts, overflow flag)
     uint32_t *d_flags = nullptr;     // [0] = a device record's length byte exceeded the declared read length (kernels without a map)
@@ -20,6 +22,9 @@ struct gk_ctx {
     // cannot flip behaviour mid-run): GK_TEST_NO_RESERVE, GK_HOST_RAGGED, GK_PART_EXACT, GK_GRAPH_UNITIGS
     bool hook_no_reserve = false, hook_host_ragged = false, hook_part_exact = false;
     int hook_unitigs = 0;            // 0 auto, 1 walk, 2 pointer jumping
+    int hook_p4_direct = -1;         // exact fine level: -1 auto (by nb2), 0 chunk sorted in LDS, 1 straight scatter with per-range cursors
+    int hook_p4_wide = -1;           // exact fine level, 8-byte keys: -1 auto (by nb2), 0 sort 4096 keys at a time, 1 sort 8192 (1024 threads)
+    int hook_fine_exact = -1;        // -1 auto, 0 never unless forced by the data path, 1 always (A/B of the two fine levels)
     std::string err;
 };
 
@@ -34,7 +39,13 @@ struct ReadSrc {
     uint32_t stride = 0;
     int group = 64;          // lanes per read in the window loops (64 reads, 32/16 short records)
     int max_len = 255;
+    // host-fed: the records are still in HOST memory at `host` (stride x nreads bytes) and `rec` is the device staging area they
+    // go to.  Whoever consumes the source uploads them — the partitioned pipeline in sub-chunks on the copy stream, so that
+    // the upload of sub-chunk j+1 overlaps the L1 scatter (P2) of sub-chunk j; everything else in one piece (stage_source).
+    const uint8_t *host = nullptr;
+    size_t host_bytes = 0;
 };
+int stage_source(gk_ctx *ctx, const ReadSrc &src);      // upload a host-fed source in one piece, stream-ordered on ctx->stream
 }
 
 namespace gk { struct PartScratch; }

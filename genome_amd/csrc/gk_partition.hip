@@ -160,8 +160,8 @@ template <int W> __device__ __forceinline__ void store_key(u64 *keys, u64 i, Kme
 
 // block-wide (PBLOCK threads) in-place exclusive scan of arr[0..n) in LDS; returns nothing, arr[i]
 // becomes the sum of the elements before i.  wsum: PBLOCK/64 scratch words.
-__device__ __forceinline__ void block_scan_inplace(u32 *arr, u32 n, u32 *wsum) {
-    const u32 per = (n + PBLOCK - 1) / PBLOCK;
+template <int NT> __device__ __forceinline__ void block_scan_inplace(u32 *arr, u32 n, u32 *wsum) {
+    const u32 per = (n + NT - 1) / NT;
     const u32 b0 = threadIdx.x * per, b1 = min(b0 + per, n);
     u32 sum = 0;
     for (u32 b = b0; b < b1; b++) sum += arr[b];
@@ -279,27 +279,27 @@ __global__ __launch_bounds__(BLOCK) void k_part_hist1_keys(const u64 *__restrict
 // position [TILE2] u16, per-bin offset [nbins] u32, per-bin destination [nbins] u64.
 // RANGED (level 2, exact fine level): gb[] already holds this range's running destination of every bin (from the
 // range matrix), so nothing is reserved — no global atomic at all — and gb[] advances by the chunk's counts.
-template <int W, int LEVEL, bool RANGED>
+template <int W, int LEVEL, bool RANGED, int NT>
 __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u32 b1, u64 begin, u32 cnt, const Table<W> &t, u32 nbins,
                                               u64 *sorted, uint16_t *binof, u32 *off, u32 *lim, unsigned long long *gb, u32 *wsum,
                                               const PartArrays &a, u64 bin0, u64 *__restrict__ out, const Sampler &sp, u32 &claims,
                                               GK_TARGS_DECL) {
     Kmer<W> key[KEYS_PER_THREAD];
     u32 bin[KEYS_PER_THREAD], rank[KEYS_PER_THREAD];
-    for (u32 b = threadIdx.x; b < nbins; b += PBLOCK) off[b] = 0;
+    for (u32 b = threadIdx.x; b < nbins; b += NT) off[b] = 0;
     __syncthreads();
     GK_TICK(0);
     // all loads first, unconditionally (index clamped): one memory round trip per chunk instead of
     // one per key — a load inside `if (i < cnt)` is sunk next to its use and serialises
 #pragma unroll
     for (int j = 0; j < KEYS_PER_THREAD; j++) {
-        const u32 i = threadIdx.x + j * PBLOCK;
+        const u32 i = threadIdx.x + j * NT;
         const u64 src = begin + (i < cnt ? i : cnt - 1);
         key[j] = load_key<W>(in, LEVEL == 2 ? l1_key_index(a, b1, src) : src);
     }
 #pragma unroll
     for (int j = 0; j < KEYS_PER_THREAD; j++) {
-        const u32 i = threadIdx.x + j * PBLOCK;
+        const u32 i = threadIdx.x + j * NT;
         bin[j] = 0xffffffffu;
         if (i < cnt) {
             const u64 h = slot_hash(key[j]);
@@ -314,7 +314,7 @@ __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u32 b1
     GK_TICK(1);
     __syncthreads();
     GK_TICK(2);
-    for (u32 b = threadIdx.x; b < nbins; b += PBLOCK) {        // reserve the bin's run in the output
+    for (u32 b = threadIdx.x; b < nbins; b += NT) {        // reserve the bin's run in the output
         const u32 c = off[b];
         u32 fit = c;
         if (c && !RANGED) {
@@ -332,7 +332,7 @@ __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u32 b1
     }
     __syncthreads();
     GK_TICK(3);
-    block_scan_inplace(off, nbins, wsum);                      // counts -> offsets in the sorted chunk
+    block_scan_inplace<NT>(off, nbins, wsum);                      // counts -> offsets in the sorted chunk
     GK_TICK(4);
 #pragma unroll
     for (int j = 0; j < KEYS_PER_THREAD; j++)
@@ -343,7 +343,7 @@ __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u32 b1
         }
     __syncthreads();
     GK_TICK(5);
-    for (u32 i = threadIdx.x; i < cnt; i += PBLOCK) {          // linear, coalesced write-out
+    for (u32 i = threadIdx.x; i < cnt; i += NT) {          // linear, coalesced write-out
         const u32 b = binof[i], j = i - off[b];
         const Kmer<W> x = load_key<W>(sorted, i);
         if (j < lim[b]) store_key<W>(out, LEVEL == 1 && a.op1 ? l1_slot(a, b, gb[b] + j) : gb[b] + j, x);
@@ -353,23 +353,24 @@ __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u32 b1
     GK_TICK(6);
     __syncthreads();
     if (RANGED) {                                              // the range's next chunk continues where this one ended
-        for (u32 b = threadIdx.x; b < nbins; b += PBLOCK) gb[b] += lim[b];
+        for (u32 b = threadIdx.x; b < nbins; b += NT) gb[b] += lim[b];
     }
     GK_TICK(7);
 }
 
 // dynamic LDS carve for scatter_chunk
-template <int W> struct ScatterLds {
+template <int W, int NT = PBLOCK> struct ScatterLds {
+    static constexpr int TILE = NT * KEYS_PER_THREAD;
     u64 *sorted; uint16_t *binof; u32 *off, *lim; unsigned long long *gb; u32 *wsum;
     __device__ __forceinline__ ScatterLds(unsigned long long *base, u32 nbins) {
         gb = base;                                                       // [nbins] u64
-        sorted = reinterpret_cast<u64 *>(base + nbins);                  // [TILE2 * W] u64
-        off = reinterpret_cast<u32 *>(sorted + (size_t)TILE2 * W);       // [nbins] u32
+        sorted = reinterpret_cast<u64 *>(base + nbins);                  // [TILE * W] u64
+        off = reinterpret_cast<u32 *>(sorted + (size_t)TILE * W);       // [nbins] u32
         lim = off + nbins;                                               // [nbins] u32
-        wsum = lim + nbins;                                              // [PBLOCK / 64]
-        binof = reinterpret_cast<uint16_t *>(wsum + PBLOCK / 64);        // [TILE2] u16
+        wsum = lim + nbins;                                              // [NT / 64]
+        binof = reinterpret_cast<uint16_t *>(wsum + NT / 64);        // [TILE] u16
     }
-    static size_t bytes(u32 nbins) { return (size_t)nbins * 16 + (size_t)TILE2 * W * 8 + (PBLOCK / 64) * 4 + (size_t)TILE2 * 2 + 16; }
+    static size_t bytes(u32 nbins) { return (size_t)nbins * 16 + (size_t)TILE * W * 8 + (NT / 64) * 4 + (size_t)TILE * 2 + 16; }
 };
 
 template <int W>
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_keys(const u64 *__rest
     for (u64 c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const u64 begin = c * TILE2;
         const u32 cnt = (u32)min((u64)TILE2, n - begin);
-        scatter_chunk<W, 1, false>(keys, 0u, begin, cnt, t, 256u, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a, 0, out, sp, claims, GK_TARGS);
+        scatter_chunk<W, 1, false, PBLOCK>(keys, 0u, begin, cnt, t, 256u, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a, 0, out, sp, claims, GK_TARGS);
     }
     if (sp.set) block_add_global(claims, &L.off[0], sp.claims);
 }
@@ -593,16 +594,17 @@ __global__ __launch_bounds__(256) void k_part_prefix2(PartArrays a, u32 nb1, u32
 // ---------------------------------------------------------------------------------------------
 // P4: L1 regions -> keys in segment order
 // ---------------------------------------------------------------------------------------------
-template <int W, bool RANGED>
-__global__ __launch_bounds__(PBLOCK) void k_part_scatter2(const u64 *__restrict__ bufA, Table<W> t, PartArrays a, u64 max_units,
+template <int W, bool RANGED, int NT>
+__global__ __launch_bounds__(NT) void k_part_scatter2(const u64 *__restrict__ bufA, Table<W> t, PartArrays a, u64 max_units,
                                                           u64 *__restrict__ bufB) {
     extern __shared__ unsigned long long lds_dyn[];
-    ScatterLds<W> L(lds_dyn, t.nb2);
+    ScatterLds<W, NT> L(lds_dyn, t.nb2);
+    constexpr u32 TILE = NT * KEYS_PER_THREAD;          // keys this workgroup sorts at a time (ranges and the chunk table stay in TILE2 units)
     // chunk / range table and L1 bucket extents: LDS copies (the binary search below was eight dependent global
     // loads per chunk: 16 % of the kernel by the phase timers)
     __shared__ unsigned long long s_ubase[257], s_l1n[256];
-    for (u32 b = threadIdx.x; b < 257u; b += PBLOCK) s_ubase[b] = RANGED ? a.rbase[b] : a.cbase[b];
-    for (u32 b = threadIdx.x; b < 256u; b += PBLOCK) s_l1n[b] = b < (1u << t.lnb1) ? l1_count(a, b) : 0ull;
+    for (u32 b = threadIdx.x; b < 257u; b += NT) s_ubase[b] = RANGED ? a.rbase[b] : a.cbase[b];
+    for (u32 b = threadIdx.x; b < 256u; b += NT) s_l1n[b] = b < (1u << t.lnb1) ? l1_count(a, b) : 0ull;
     __syncthreads();
     const u64 total = min((u64)s_ubase[256], max_units);
     const Sampler nosp{nullptr, 0, nullptr};
@@ -613,9 +615,9 @@ __global__ __launch_bounds__(PBLOCK) void k_part_scatter2(const u64 *__restrict_
             const RangeGeom g = range_geom(s_ubase, s_l1n, r, a.range_chunks);
             const u64 bin0 = (u64)g.b1 * t.nb2;
             const u32 *row = a.rmat + r * t.nb2;
-            for (u32 b = threadIdx.x; b < t.nb2; b += PBLOCK) L.gb[b] = a.fine_base[bin0 + b] + row[b];
-            for (u32 cb = 0; cb < g.cnt; cb += TILE2)          // (scatter_chunk opens with a barrier: gb[] is visible)
-                scatter_chunk<W, 2, true>(bufA, g.b1, g.begin + cb, min((u32)TILE2, g.cnt - cb), t, t.nb2, L.sorted, L.binof, L.off, L.lim,
+            for (u32 b = threadIdx.x; b < t.nb2; b += NT) L.gb[b] = a.fine_base[bin0 + b] + row[b];
+            for (u32 cb = 0; cb < g.cnt; cb += TILE)           // (scatter_chunk opens with a barrier: gb[] is visible)
+                scatter_chunk<W, 2, true, NT>(bufA, g.b1, g.begin + cb, min(TILE, g.cnt - cb), t, t.nb2, L.sorted, L.binof, L.off, L.lim,
                                           L.gb, L.wsum, a, bin0, bufB, nosp, noclaims, GK_TARGS);
             __syncthreads();
         }
@@ -624,11 +626,53 @@ __global__ __launch_bounds__(PBLOCK) void k_part_scatter2(const u64 *__restrict_
             const u32 b1 = chunk_bucket(s_ubase, c);
             const u64 begin = (c - s_ubase[b1]) * TILE2;
             const u32 cnt = (u32)min((u64)TILE2, s_l1n[b1] - begin);
-            scatter_chunk<W, 2, false>(bufA, b1, begin, cnt, t, t.nb2, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a,
+            scatter_chunk<W, 2, false, NT>(bufA, b1, begin, cnt, t, t.nb2, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a,
                                        (u64)b1 * t.nb2, bufB, nosp, noclaims, GK_TARGS);
         }
     }
     GK_TFLUSH(8);
+}
+
+// P4 of the exact fine level when a chunk of 4096 keys meets MANY fine buckets (nb2 in the thousands: 2-3 keys per bin and
+// chunk).  Sorting the chunk by bin in LDS then buys no coalescing — a bin's run is shorter than a line — and costs five
+// loops over all bins plus six barriers per chunk, which is what bounds scatter_chunk there (52 ms of C3's 123 ms count
+// at nb2 = 1525).  The range matrix already gives every (range, bin) its exact destination, so a range keeps ONE running
+// cursor per bin in LDS and every key goes straight out: one LDS atomic and one 8/16-byte store per key, one loop over the
+// bins and two barriers per RANGE (64 Ki keys), nothing per chunk.  Order inside a segment's run is arbitrary (as it
+// always was: P5's result does not depend on it).
+template <int W>
+__global__ __launch_bounds__(PBLOCK) void k_part_scatter2_direct(const u64 *__restrict__ bufA, Table<W> t, PartArrays a, u64 max_ranges,
+                                                                 u64 *__restrict__ bufB) {
+    extern __shared__ u32 lds_cur[];                 // [nb2] next free position of every bin, relative to the L1 bucket's first key in bufB
+    __shared__ unsigned long long s_rbase[257], s_l1n[256];
+    for (u32 b = threadIdx.x; b < 257u; b += PBLOCK) s_rbase[b] = a.rbase[b];
+    for (u32 b = threadIdx.x; b < 256u; b += PBLOCK) s_l1n[b] = b < (1u << t.lnb1) ? l1_count(a, b) : 0ull;
+    __syncthreads();
+    const u64 total = min((u64)s_rbase[256], max_ranges);
+    for (u64 r = blockIdx.x; r < total; r += gridDim.x) {
+        const RangeGeom g = range_geom(s_rbase, s_l1n, r, a.range_chunks);
+        const u64 bin0 = (u64)g.b1 * t.nb2;
+        const u64 base = a.fine_base[bin0];          // (= l1_base[b1]: bufB is dense)
+        const u32 *row = a.rmat + r * t.nb2;
+        __syncthreads();                             // the previous range's keys are out
+        for (u32 b = threadIdx.x; b < t.nb2; b += PBLOCK) lds_cur[b] = (u32)(a.fine_base[bin0 + b] - base) + row[b];
+        __syncthreads();
+        for (u32 cb = 0; cb < g.cnt; cb += TILE2) {
+            const u32 cnt = min((u32)TILE2, g.cnt - cb);
+            Kmer<W> key[KEYS_PER_THREAD];
+#pragma unroll
+            for (int j = 0; j < KEYS_PER_THREAD; j++) {
+                const u32 i = threadIdx.x + j * PBLOCK;
+                key[j] = load_key<W>(bufA, l1_key_index(a, g.b1, g.begin + cb + (i < cnt ? i : cnt - 1)));
+            }
+#pragma unroll
+            for (int j = 0; j < KEYS_PER_THREAD; j++)
+                if (threadIdx.x + j * PBLOCK < cnt) {
+                    const u32 pos = atomicAdd(&lds_cur[seg_fine(t, slot_hash(key[j]))], 1u);
+                    store_key<W>(bufB, base + pos, key[j]);
+                }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1006,10 +1050,14 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
     const int cu8 = ctx->cu_count * 8;
     const size_t lds = ((size_t)1 << SegBits<W>::value) * sizeof(Slot<W>) + 16;
     if (!ps->lds_attr_set) {
-        GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<W, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<W, false, PBLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)ScatterLds<W>::bytes(MAX_NB2)));
-        GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<W, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<W, true, PBLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)ScatterLds<W>::bytes(MAX_NB2)));
+        if constexpr (W == 1) {
+            const int wide_max = (int)ScatterLds<1, 1024>::bytes(MAX_NB2);
+            GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<1, true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, wide_max));
+        }
         GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter1_keys<W>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)ScatterLds<W>::bytes(256u)));
         GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_seg_insert<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1030,9 +1078,34 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         const int rs = (int)std::max<u64>(1, std::min<u64>(by_bytes, (u64)(OP_CAP / W) / (u64)max_windows));
         const u64 ntiles = (src.nreads + rs - 1) / rs;
         const int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)ctx->cu_count * 2);
-        hipLaunchKernelGGL(k_op_scatter1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, src.nreads, src.stride, m->k, src.group, rs,
-                           src.max_len, t, a, sp, m->d_ctr, ps->bufA);
+        if (!src.host) {
+            hipLaunchKernelGGL(k_op_scatter1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, src.nreads, src.stride, m->k, src.group, rs,
+                               src.max_len, t, a, sp, m->d_ctr, ps->bufA);
+        } else {
+            // Host-fed: upload in sub-chunks on the copy stream, scatter each as soon as it has landed.  The L1 regions are
+            // append-only (cursor1), so P2 can run once per sub-chunk; P4 and P5 then see one batch.  With the caller's buffer
+            // pinned (gk_host_alloc / gk_host_register) the upload of sub-chunk j+1 overlaps the scatter of sub-chunk j.
+            const u64 sub_reads = std::max<u64>((u64)rs * 1024, (src.nreads + 7) / 8 / rs * rs);      // <= 8 pieces, whole tiles
+            int j = 0;
+            for (u64 r0 = 0; r0 < src.nreads; r0 += sub_reads, j++) {
+                const u64 nr = std::min<u64>(sub_reads, src.nreads - r0);
+                const size_t off = (size_t)r0 * src.stride, bytes = (size_t)nr * src.stride;
+                hipEvent_t ev = ctx->cev[j % 16];
+                if (j == 0) {       // the copy stream must not overwrite the staging area while an earlier kernel still reads it
+                    GK_HIP(ctx, hipEventRecord(ev, ctx->stream));
+                    GK_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ev, 0));
+                }
+                GK_HIP(ctx, hipMemcpyAsync(const_cast<uint8_t *>(d_rec) + off, src.host + off, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+                GK_HIP(ctx, hipEventRecord(ev, ctx->copy_stream));
+                GK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ev, 0));
+                const u64 nt = (nr + rs - 1) / rs;
+                const int gsub = (int)std::min<u64>(std::max<u64>(nt, 1), (u64)ctx->cu_count * 2);
+                hipLaunchKernelGGL(k_op_scatter1_reads<W>, dim3(gsub), dim3(PBLOCK), 0, ctx->stream, d_rec + off, nr, src.stride, m->k, src.group, rs,
+                                   src.max_len, t, a, sp, m->d_ctr, ps->bufA);
+            }
+        }
     } else if (d_rec) {
+        if (int rc = stage_source(ctx, src)) return rc;
         const u64 ntiles = (src.nreads + PTILE_READS - 1) / PTILE_READS;
         const int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)ctx->cu_count * 4);
         hipLaunchKernelGGL(k_part_hist1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, src.nreads, d_off, src.stride, m->k, src.group,
@@ -1124,11 +1197,27 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         hipLaunchKernelGGL(k_part_scan2, dim3((m->nb2 + 255) / 256, nb1), dim3(256), 0, ctx->stream, a, m->nb2);
         hipLaunchKernelGGL(k_part_prefix2, dim3(nb1), dim3(256), 0, ctx->stream, a, nb1, m->nb2);
         GK_HIP(ctx, hipEventRecord(ctx->pev[3], ctx->stream));
-        hipLaunchKernelGGL((k_part_scatter2<W, true>), dim3(gr), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2), ctx->stream, ps->bufA, t, a, max_ranges, ps->bufB);
+        // few keys per bin and chunk: straight scatter with per-range cursors; otherwise sort each chunk in LDS (coalesced runs)
+        // (measured at C3, nb2 = 1525: 67 ms against 52 ms for the sorted form — 8-byte stores to 64 different lines per
+        //  instruction leave L2 as partial-line writes; kept as an A/B option, never chosen by default)
+        const bool direct = ctx->hook_p4_direct > 0;
+        if (direct)
+            hipLaunchKernelGGL(k_part_scatter2_direct<W>, dim3((int)std::min<u64>(max_ranges, (u64)ctx->cu_count * 8)), dim3(PBLOCK), m->nb2 * 4,
+                               ctx->stream, ps->bufA, t, a, max_ranges, ps->bufB);
+        else if (W == 1 && (ctx->hook_p4_wide >= 0 ? ctx->hook_p4_wide != 0 : m->nb2 >= 512)) {
+            // many fine buckets: sort 8192 keys at a time (1024 threads) — twice the keys per bin and visit, so fewer
+            // partial-line writes, and half the per-bin bookkeeping per key
+            if constexpr (W == 1) {
+                const size_t wide_lds = ScatterLds<1, 1024>::bytes(m->nb2);
+                const int gw = (int)std::min<u64>(max_ranges, (u64)ctx->cu_count * 2);
+                hipLaunchKernelGGL((k_part_scatter2<1, true, 1024>), dim3(gw), dim3(1024), wide_lds, ctx->stream, ps->bufA, t, a, max_ranges, ps->bufB);
+            }
+        } else
+            hipLaunchKernelGGL((k_part_scatter2<W, true, PBLOCK>), dim3(gr), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2), ctx->stream, ps->bufA, t, a, max_ranges, ps->bufB);
     } else {
         GK_HIP(ctx, hipEventRecord(ctx->pev[3], ctx->stream));
         const int gchunks = (int)std::min<u64>(max_chunks, (u64)ctx->cu_count * 4);
-        hipLaunchKernelGGL((k_part_scatter2<W, false>), dim3(gchunks), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2), ctx->stream, ps->bufA, t, a, max_chunks, ps->bufB);
+        hipLaunchKernelGGL((k_part_scatter2<W, false, PBLOCK>), dim3(gchunks), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2), ctx->stream, ps->bufA, t, a, max_chunks, ps->bufB);
     }
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipEventRecord(ctx->pev[4], ctx->stream));

@@ -68,6 +68,18 @@ __global__ __launch_bounds__(BLOCK) void k_shard_scatter(const uint8_t *__restri
     }
 }
 
+// how many live keys of a partition's table belong to ANOTHER owner under gk_owner_of (must be 0: PartitionedDNAMap.partition,
+// PartitionedDNAMap.scala:60-63, names exactly one partition per key)
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_count_foreign(Table<W> t, int k, int P, int p, unsigned long long *out) {
+    unsigned long long bad = 0;
+    const u64 ncap = t.capacity();
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < ncap; i += (u64)gridDim.x * BLOCK)
+        if (slot_live(&t.slots[i]) && owner_of(slot_key(t.slots, i, t.tagged), k, P) != p) bad++;
+    for (int d = 32; d; d >>= 1) bad += __shfl_down(bad, d);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(out, bad);
+}
+
 // SplitMix64 in counter form — identical to genome_amd/synth.py
 __device__ __forceinline__ u64 splitmix_at(u64 seed, u64 idx) {
     u64 z = seed + (idx + 1) * 0x9E3779B97F4A7C15ULL;
@@ -119,6 +131,28 @@ int gk_owner_of(int k, uint64_t lo, uint64_t hi, int P) {
     if (!k_supported(k) || P <= 0) return -1;
     if (words_for_k(k) == 1) return owner_of(Kmer<1>{lo}, k, P);
     return owner_of(Kmer<2>{lo, hi}, k, P);
+}
+
+int gk_map_count_foreign(gk_map *m, int P, int p, uint64_t *foreign) {
+    if (!m || !m->ctx) return fail(nullptr, GK_E_INVALID, "null map handle");
+    gk_ctx *ctx = m->ctx;
+    if (!foreign || P < 1 || p < 0 || p >= P) return fail(ctx, GK_E_INVALID, "gk_map_count_foreign: bad argument");
+    GK_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc = map_materialize(m)) return rc;
+    unsigned long long *d = (unsigned long long *)map_scratch(m, 256), h = 0;
+    if (!d) return GK_E_CAPACITY;
+    GK_HIP(ctx, hipMemsetAsync(d, 0, 8, ctx->stream));
+    const int grid = (int)std::min<u64>(std::max<u64>((m->capacity + BLOCK - 1) / BLOCK, 1), (u64)ctx->cu_count * 8);
+    if (m->W == 1)
+        hipLaunchKernelGGL(k_count_foreign<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, Table<1>{(Slot<1> *)m->slots, m->nb2, m->lnb1, 0u}, m->k, P, p, d);
+    else
+        hipLaunchKernelGGL(k_count_foreign<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream,
+                           Table<2>{(Slot<2> *)m->slots, m->nb2, m->lnb1, m->k == 64 ? 1u : 0u}, m->k, P, p, d);
+    GK_HIP(ctx, hipGetLastError());
+    GK_HIP(ctx, hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *foreign = h;
+    return GK_OK;
 }
 
 int gk_shard_reads_dev(gk_ctx *ctx, int k, const void *dev_records, uint64_t nreads, int read_len, int P,

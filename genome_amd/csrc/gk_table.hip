@@ -169,20 +169,30 @@ __global__ __launch_bounds__(BLOCK) void k_get(const u64 *__restrict__ lo, const
 // Self-check of the table's invariants (what `size` and the slot protocol promise): every live key is found again at
 // its own slot (a key stored twice, or in a segment its hash does not name, is not), counts add up.
 template <int W>
-__global__ __launch_bounds__(BLOCK) void k_verify(Table<W> t, unsigned long long *out /* live, duplicates or misplaced, sum of counts */) {
-    unsigned long long live = 0, bad = 0, sum = 0;
+__global__ __launch_bounds__(BLOCK) void k_verify(Table<W> t, unsigned long long *out /* live, duplicates or misplaced, sum of counts, checksum */) {
+    unsigned long long live = 0, bad = 0, sum = 0, chk = 0;
     const u64 ncap = t.capacity();
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < ncap; i += (u64)gridDim.x * BLOCK) {
         if (!slot_live(&t.slots[i])) continue;
         live++;
         sum += slot_count(&t.slots[i]);
-        if (table_find(t, slot_key(t.slots, i, t.tagged)) != (i64)i) bad++;
+        const Kmer<W> key = slot_key(t.slots, i, t.tagged);
+        if (table_find(t, key) != (i64)i) bad++;
+        // order-independent content checksum: sum over entries of a mix of (key, count) — slot order, table size and
+        // insertion order do not enter
+        u64 kh;
+        if constexpr (W == 1) kh = mix64(key.lo ^ 0x243f6a8885a308d3ULL);
+        else kh = mix64(key.lo ^ mix64(key.hi ^ 0x13198a2e03707344ULL));
+        chk += mix64(kh + (u64)slot_count(&t.slots[i]) * 0x9e3779b97f4a7c15ULL);
     }
-    for (int d = 32; d; d >>= 1) { live += __shfl_down(live, d); bad += __shfl_down(bad, d); sum += __shfl_down(sum, d); }
+    for (int d = 32; d; d >>= 1) {
+        live += __shfl_down(live, d); bad += __shfl_down(bad, d); sum += __shfl_down(sum, d); chk += __shfl_down(chk, d);
+    }
     if ((threadIdx.x & 63) == 0) {
         if (live) atomicAdd(&out[0], live);
         if (bad) atomicAdd(&out[1], bad);
         if (sum) atomicAdd(&out[2], sum);
+        atomicAdd(&out[3], chk);
     }
 }
 
@@ -269,6 +279,12 @@ int map_sync_counters(gk_map *m) {
                                              "unspecified: clear it)");
         return fail(m->ctx, GK_E_CAPACITY, "a table segment filled up (internal sizing error)");
     }
+    return GK_OK;
+}
+
+int stage_source(gk_ctx *ctx, const ReadSrc &src) {
+    if (!src.host) return GK_OK;
+    GK_HIP(ctx, hipMemcpyAsync(const_cast<uint8_t *>(src.rec), src.host, src.host_bytes, hipMemcpyHostToDevice, ctx->stream));
     return GK_OK;
 }
 
@@ -395,6 +411,8 @@ int gk_ctx_create(int device, gk_ctx **out) {
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&ctx->pev[i]);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+    for (int i = 0; i < 16 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->cev[i], hipEventDisableTiming);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_flags, 64);
@@ -423,6 +441,8 @@ void gk_ctx_destroy(gk_ctx *ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (int i = 0; i < 6; i++) if (ctx->pev[i]) (void)hipEventDestroy(ctx->pev[i]);
+    for (int i = 0; i < 16; i++) if (ctx->cev[i]) (void)hipEventDestroy(ctx->cev[i]);
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     delete ctx;
 }
 
@@ -438,13 +458,38 @@ int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value) {
     else if (n == "graph_unitigs") {
         if (value < 0 || value > 2) return fail(ctx, GK_E_INVALID, "graph_unitigs: 0 auto, 1 walk, 2 pointer jumping");
         ctx->hook_unitigs = (int)value;
-    } else return fail(ctx, GK_E_INVALID, "gk_ctx_set_option: unknown option '" + n + "'");
+    } else if (n == "p4_direct") ctx->hook_p4_direct = value < 0 ? -1 : value != 0;
+    else if (n == "p4_wide") ctx->hook_p4_wide = value < 0 ? -1 : value != 0;
+    else if (n == "fine_exact") ctx->hook_fine_exact = value < 0 ? -1 : value != 0;
+    else return fail(ctx, GK_E_INVALID, "gk_ctx_set_option: unknown option '" + n + "'");
     return GK_OK;
 }
 
 int gk_ctx_sync(gk_ctx *ctx) {
     if (!ctx) return fail(nullptr, GK_E_INVALID, "null ctx");
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GK_OK;
+}
+int gk_host_alloc(gk_ctx *ctx, size_t nbytes, void **host_ptr) {
+    if (!ctx || !host_ptr) return fail(ctx, GK_E_INVALID, "gk_host_alloc: null argument");
+    GK_HIP(ctx, hipSetDevice(ctx->device));
+    GK_HIP(ctx, hipHostMalloc(host_ptr, nbytes ? nbytes : 1, hipHostMallocDefault));
+    return GK_OK;
+}
+int gk_host_free(gk_ctx *ctx, void *host_ptr) {
+    if (!ctx) return fail(ctx, GK_E_INVALID, "null ctx");
+    if (host_ptr) GK_HIP(ctx, hipHostFree(host_ptr));
+    return GK_OK;
+}
+int gk_host_register(gk_ctx *ctx, void *host_ptr, size_t nbytes) {
+    if (!ctx || !host_ptr) return fail(ctx, GK_E_INVALID, "gk_host_register: null argument");
+    GK_HIP(ctx, hipSetDevice(ctx->device));
+    GK_HIP(ctx, hipHostRegister(host_ptr, nbytes, hipHostRegisterDefault));
+    return GK_OK;
+}
+int gk_host_unregister(gk_ctx *ctx, void *host_ptr) {
+    if (!ctx || !host_ptr) return fail(ctx, GK_E_INVALID, "gk_host_unregister: null argument");
+    GK_HIP(ctx, hipHostUnregister(host_ptr));
     return GK_OK;
 }
 int gk_dev_alloc(gk_ctx *ctx, size_t nbytes, void **dev_ptr) {
@@ -564,6 +609,7 @@ static int launch_count(gk_map *m, const ReadSrc &src) {
     gk_ctx *ctx = m->ctx;
     u64 ntiles = (src.nreads + TILE_READS - 1) / TILE_READS;
     int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)ctx->cu_count * 8);
+    if (int rc = stage_source(ctx, src)) return rc;
     GK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     if (m->W == 1)
         hipLaunchKernelGGL(k_count_reads<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, src.rec, src.nreads, src.off, src.stride, m->k, src.group,
@@ -666,9 +712,11 @@ static u64 reads_per_launch(gk_map *m, u64 nk) {
     return std::max<u64>(1, occ / nk);
 }
 // how many windows one partitioned batch may hold: bounded by the scratch it needs (two key buffers, the spill list)
-// next to what is free in HBM, and by a default of 2^31 keys (32 GB of 8-byte-key scratch; gk_map_set_max_batch_keys)
+// next to what is free in HBM — half of it at most — and by 16 GiB of keys per buffer (gk_map_set_max_batch_keys changes
+// that).  Big batches pay: every batch after the first streams the whole table in and out again
 static u64 part_batch_keys(gk_map *m) {
-    u64 cap = m->max_batch_keys ? m->max_batch_keys : (1ull << 31);
+    // (default: key buffers of 16 GiB — hipMalloc of much larger ones takes seconds: 54 GB measured at ~1 s)
+    u64 cap = m->max_batch_keys ? m->max_batch_keys : (1ull << 31) / (u64)m->W;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
         const gk::PartScratch *ps = m->part;
@@ -690,7 +738,7 @@ static int insert_batch(gk_map *m, const ReadSrc &src, const u64 *d_keys, u64 nk
     if (bound && use_partitioned(m, bound)) {
         PartPlan plan;
         plan.grow_ahead = grow_ahead;
-        plan.fine_exact = m->repeats;
+        plan.fine_exact = ctx->hook_fine_exact >= 0 ? ctx->hook_fine_exact != 0 : m->repeats;
         plan.check_canon = verbatim;
         const bool fits = (double)bound <= map_room(m);
         if (!fits) {
@@ -884,12 +932,14 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
             GK_HIP(ctx, hipMalloc(&m->d_offsets, offs.size() * sizeof(u32)));
             m->offsets_bytes = offs.size() * sizeof(u32);
         }
-        GK_HIP(ctx, hipMemcpyAsync(m->d_stage, bin + chunk_begin, cbytes, hipMemcpyHostToDevice, ctx->stream));
+        // the records stay in host memory for now: the consumer uploads them (ReadSrc::host)
         // a chunk of equal-length records (the usual case: one sequencing run) is a fixed-stride array: no offset
         // table to upload, and the partitioned path can take its one-extraction form
         ReadSrc src;
         src.rec = (const uint8_t *)m->d_stage;
         src.nreads = creads;
+        src.host = bin + chunk_begin;
+        src.host_bytes = cbytes;
         if (uniform && first_len >= 0 && !ctx->hook_host_ragged) {
             src.stride = 1 + (u32)(first_len + 3) / 4;
             src.max_len = first_len;
@@ -1023,7 +1073,11 @@ static int map_compact(gk_map *m) {
     gk_ctx *ctx = m->ctx;
     uint32_t nnb2, nlnb1;
     uint64_t ncap;
-    plan_segments(m->W, (uint64_t)((double)m->size / target_load(m)) + 1, &nnb2, &nlnb1, &ncap);
+    // What follows deleteAll is the read-only graph phase: 8 lookups per key of which ~6 MISS, and a miss in a linearly
+    // probed table walks (1 + 1/(1-load)^2)/2 slots — 4.6 at load 0.65, i.e. a second, DEPENDENT 64-byte sector for most
+    // misses.  HBM is not what is scarce here: the compacted table is sized for load 0.4 (1.9 slots per miss).
+    const double graph_load = m->k == 64 ? 0.3 : 0.4;
+    plan_segments(m->W, (uint64_t)((double)m->size / graph_load) + 1, &nnb2, &nlnb1, &ncap);
     if (ncap > m->capacity) { nnb2 = m->nb2; nlnb1 = m->lnb1; ncap = m->capacity; }
     void *nslots = nullptr;
     if (alloc_table(ctx, m->W, ncap, &nslots) != GK_OK) { if (nslots) (void)hipFree(nslots); return GK_OK; }   // keep tombstones if memory is short
@@ -1123,21 +1177,34 @@ int gk_map_export(gk_map *m, uint64_t *lo, uint64_t *hi, int32_t *counts, uint64
     return GK_OK;
 }
 
-int gk_map_verify(gk_map *m, uint64_t *live, uint64_t *bad_slots, uint64_t *sum_counts) {
+int gk_map_verify(gk_map *m, uint64_t *live, uint64_t *bad_slots, uint64_t *sum_counts, uint64_t *checksum) {
     if (int rc = check_map(m)) return rc;
     gk_ctx *ctx = m->ctx;
-    unsigned long long *d = (unsigned long long *)map_scratch(m, 256), h[3] = {0, 0, 0};
+    unsigned long long *d = (unsigned long long *)map_scratch(m, 256), h[4] = {0, 0, 0, 0};
     if (!d) return GK_E_CAPACITY;
-    GK_HIP(ctx, hipMemsetAsync(d, 0, 24, ctx->stream));
+    GK_HIP(ctx, hipMemsetAsync(d, 0, 32, ctx->stream));
     int grid = grid_for(ctx, m->capacity, BLOCK);
     if (m->W == 1) hipLaunchKernelGGL(k_verify<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, table_of<1>(m), d);
     else hipLaunchKernelGGL(k_verify<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, table_of<2>(m), d);
     GK_HIP(ctx, hipGetLastError());
-    GK_HIP(ctx, hipMemcpyAsync(h, d, 24, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP(ctx, hipMemcpyAsync(h, d, 32, hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (live) *live = h[0];
     if (bad_slots) *bad_slots = h[1];
     if (sum_counts) *sum_counts = h[2];
+    if (checksum) *checksum = h[3];
+    return GK_OK;
+}
+
+int gk_map_trim(gk_map *m) {
+    if (int rc = check_map_lazy(m)) return rc;
+    gk_ctx *ctx = m->ctx;
+    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (m->d_stage) { (void)hipFree(m->d_stage); m->d_stage = nullptr; m->stage_bytes = 0; }
+    if (m->d_offsets) { (void)hipFree(m->d_offsets); m->d_offsets = nullptr; m->offsets_bytes = 0; }
+    if (m->d_scratch) { (void)hipFree(m->d_scratch); m->d_scratch = nullptr; m->scratch_bytes = 0; }
+    part_scratch_free(m->part);
+    m->part = nullptr;
     return GK_OK;
 }
 

@@ -45,6 +45,16 @@ class Context:
         """Wait for everything queued on the context's stream."""
         L.check(L.lib().gk_ctx_sync(self.h), self.h)
 
+    def host_alloc(self, nbytes: int) -> np.ndarray:
+        """Page-locked host buffer as a uint8 array (gk_host_alloc); give it back with host_free(array)."""
+        p = L.vp()
+        L.check(L.lib().gk_host_alloc(self.h, nbytes, C.byref(p)), self.h)
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(nbytes, 1),))[:nbytes]
+        return arr
+
+    def host_free(self, arr: np.ndarray):
+        L.check(L.lib().gk_host_free(self.h, arr.ctypes.data), self.h)
+
     def alloc(self, nbytes: int) -> int:
         p = L.vp()
         L.check(L.lib().gk_dev_alloc(self.h, nbytes, C.byref(p)), self.h)
@@ -224,9 +234,17 @@ class HipDNAMap:
 
     def verify(self):
         """-> (live slots, bad slots, sum of counts): the table's invariants, checked on the device."""
-        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
-        L.check(L.lib().gk_map_verify(self.h, C.byref(a), C.byref(b), C.byref(c)), self.ctx.h)
-        return a.value, b.value, c.value
+        return self.verify_checksum()[:3]
+
+    def verify_checksum(self):
+        """-> (live slots, bad slots, sum of counts, order-independent checksum of the (key, count) set)."""
+        a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        L.check(L.lib().gk_map_verify(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), self.ctx.h)
+        return a.value, b.value, c.value, d.value
+
+    def trim(self):
+        """Release the scratch kept between calls (gk_map_trim)."""
+        L.check(L.lib().gk_map_trim(self.h), self.ctx.h)
 
     def set_max_batch_keys(self, keys: int):
         L.check(L.lib().gk_map_set_max_batch_keys(self.h, int(keys)), self.ctx.h)

@@ -58,6 +58,37 @@ class HipGraph:
         L.check(L.lib().gk_graph_retain_largest(self.h, C.byref(kept), C.byref(comps)), self.ctx.h)
         return kept.value, comps.value
 
+    def componentStats(self):
+        """-> (nodes per component, summed out-edge length per component), one entry per component."""
+        n = C.c_uint64()
+        rc = L.lib().gk_graph_component_stats(self.h, None, None, 0, C.byref(n))
+        if rc not in (L.GK_OK, L.GK_E_CAPACITY):
+            L.check(rc, self.ctx.h)
+        nodes, length = np.zeros(n.value, np.uint32), np.zeros(n.value, np.uint64)
+        if n.value:
+            L.check(L.lib().gk_graph_component_stats(self.h, L.ptr(nodes, C.c_uint32), L.ptr(length, C.c_uint64), n.value, C.byref(n)), self.ctx.h)
+        return nodes, length
+
+    def componentHistograms(self):
+        """GraphBuilder.scala:41-47: `hist` = components by node count, `hist2` = components by summed out-edge length,
+        each as a sorted list of (value, number of components)."""
+        nodes, length = self.componentStats()
+        h1 = sorted((int(a), int(b)) for a, b in zip(*np.unique(nodes, return_counts=True)))
+        h2 = sorted((int(a), int(b)) for a, b in zip(*np.unique(length, return_counts=True)))
+        return h1, h2
+
+    def checksum(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        L.check(L.lib().gk_graph_checksum(self.h, C.byref(a), C.byref(b)), self.ctx.h)
+        return a.value, b.value
+
+    def buildStats(self):
+        ms = (C.c_float * 6)()
+        bases, pj = C.c_uint64(), C.c_int()
+        L.check(L.lib().gk_graph_build_stats(self.h, ms, C.byref(bases), C.byref(pj)), self.ctx.h)
+        names = ("classify", "make_nodes", "unitig_measure", "reserve_pool", "unitig_emit", "index_counts")
+        return {"phase_ms": {n_: float(x) for n_, x in zip(names, ms)}, "walked_bases": bases.value, "pointer_jumping": bool(pj.value)}
+
     def getNodes(self):
         n = self.counts()[0]
         lo, hi = np.zeros(n, np.uint64), np.zeros(n, np.uint64)

@@ -34,6 +34,9 @@ class PartitionedDNAMap:
         self.ctx, self.k, self.P = ctx, k, P
         self.W = 1 if k <= 32 else 2
         self.parts = [HipDNAMap(ctx, k, max(1, capacity_hint // P)) for _ in range(P)]
+        # P logical partitions share ONE device: let every partition give its insert scratch back after each batch (a rank
+        # of the N-GPU run keeps it — it has one partition)
+        self.trim_scratch = P > 1
 
     def close(self):
         for p in self.parts:
@@ -73,26 +76,93 @@ class PartitionedDNAMap:
         if nreads * nk == 0:
             return 0
         slot = skm_slot_bytes(self.k)
-        cap = max(1024 * self.P, nreads * 16)
+        d_out, region, recs, kmers = self._route(d_records, nreads, read_len)
+        try:
+            for p in range(self.P):                       # owner p's records start at slot p * region
+                if recs[p]:
+                    self.parts[p].count_superkmers_dev(d_out + p * region * slot, int(recs[p]), int(kmers[p]))
+                    if self.trim_scratch:
+                        self.parts[p].trim()
+        finally:
+            self.ctx.free(d_out)
+        return int(kmers.sum())
+
+    def _route(self, d_records: int, nreads: int, read_len: int):
+        """gk_shard_superkmers_dev into a fresh buffer -> (d_out, region slots, records per owner, k-mers per owner)."""
+        slot = skm_slot_bytes(self.k)
+        # a run of same-owner windows is about half a minimizer window long: (k - m + 2) / 2 windows, m = 11
+        nk = max(1, read_len - self.k + 1)
+        per_read = max(2.0, nk / max(1.0, (self.k - 9) / 2.0)) * 1.5 + 1
+        cap = max(1024 * self.P, int(nreads * per_read) // self.P * self.P)
         while True:
             d_out = self.ctx.alloc(cap * slot)
             try:
                 recs, kmers = self.ctx.shard_superkmers(self.k, d_records, nreads, read_len, self.P, d_out, cap)
+                return d_out, cap // self.P, recs, kmers
             except L.GkError as e:
                 self.ctx.free(d_out)
                 if e.code != L.GK_E_CAPACITY:
                     raise
                 cap = cap * 4
-                continue
-            break
+
+    def count_reads_dev_prefiltered(self, chunks, read_len: int, expected_distinct: int, progress=None):
+        """FreqFilter.add through the exact singleton pre-filter, PARTITIONED: what one rank of the N-GPU run does with the
+        records it owns.  `chunks` yields (device pointer, reads) pairs (the buffer may be reused between them): every chunk is
+        routed once and its super-k-mer records are KEPT in HBM (~2 bits/base: 62.5 M reads of 150 bp are 20-30 GB), because
+        the filter needs two passes over what an owner receives — pass 1 over ALL of an owner's records, then pass 2.
+        The records are `.bin` records at a fixed stride, so the pre-filter's ordinary device entry points take them as they
+        are.  Returns (windows looked at, windows admitted).  expected_distinct: distinct k-mers over all partitions."""
+        from .prefilter import HipPrefilter
+        slot = skm_slot_bytes(self.k)
+        rec_len = (slot - 1) * 4                     # a record slot holds up to this many bases: stride(rec_len) == slot
+        kept = []
+        looked = admitted = 0
         try:
-            region = cap // self.P                        # owner p's records start at slot p * region
+            for d_records, nreads in chunks:
+                if nreads * max(0, read_len - self.k + 1) == 0:
+                    continue
+                kept.append(self._route(d_records, nreads, read_len))
+                if progress:
+                    progress("routed", len(kept))
             for p in range(self.P):
-                if recs[p]:
-                    self.parts[p].count_superkmers_dev(d_out + p * region * slot, int(recs[p]), int(kmers[p]))
+                pf = HipPrefilter(self.ctx, self.k, max(1, expected_distinct // self.P))
+                try:
+                    for d_out, region, recs, kmers in kept:
+                        if recs[p]:
+                            pf.add_reads_dev(d_out + p * region * slot, int(recs[p]), rec_len)
+                    for d_out, region, recs, kmers in kept:
+                        if recs[p]:
+                            _, adm = pf.count_reads_dev(self.parts[p], d_out + p * region * slot, int(recs[p]), rec_len)
+                            admitted += adm
+                            looked += int(kmers[p])
+                finally:
+                    pf.close()
+                    if self.trim_scratch:
+                        self.parts[p].trim()
+                if progress:
+                    progress("partition", p)
         finally:
-            self.ctx.free(d_out)
-        return int(kmers.sum())
+            for d_out, _, _, _ in kept:
+                self.ctx.free(d_out)
+        return looked, admitted
+
+    def foreign_keys(self) -> int:
+        """live keys that sit in a partition other than the one gk_owner_of names (must be 0)."""
+        tot = 0
+        for p, part in enumerate(self.parts):
+            n = C.c_uint64()
+            L.check(L.lib().gk_map_count_foreign(part.h, self.P, p, C.byref(n)), self.ctx.h)
+            tot += n.value
+        return tot
+
+    def verify(self):
+        """-> (live, bad slots, sum of counts, checksum) over all partitions (gk_map_verify: checksums of partitions add up)."""
+        tot = [0, 0, 0, 0]
+        for part in self.parts:
+            for i, v in enumerate(part.verify_checksum()):
+                tot[i] += v
+        tot[3] &= (1 << 64) - 1
+        return tuple(tot)
 
     def count_reads_dev_keys(self, d_records: int, nreads: int, read_len: int) -> int:
         """extract + canonicalise + bucket 8/16-B keys by owner on the device, then owner-side inserts."""

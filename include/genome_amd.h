@@ -62,8 +62,16 @@ int gk_ctx_sync(gk_ctx *ctx);                    /* hipStreamSynchronize on the 
 /* Test / A-B switches (never needed in production).  Their defaults are read from the environment ONCE, in
  * gk_ctx_create (GK_TEST_NO_RESERVE, GK_HOST_RAGGED, GK_PART_EXACT, GK_GRAPH_UNITIGS=walk|pj); no entry point
  * consults the environment afterwards.  Names: "test_no_reserve", "host_ragged", "part_exact" (0/1),
- * "graph_unitigs" (0 auto, 1 one lane per edge, 2 pointer jumping). */
+ * "graph_unitigs" (0 auto, 1 one lane per edge, 2 pointer jumping), "p4_direct" / "fine_exact" (-1 auto, 0, 1: A/B of the
+ * partitioned insert's fine level, gk_partition.hip). */
 int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value);
+/* Pinned host memory: gk_map_count_reads / gk_prefilter_add_reads read the caller's `.bin` buffer with asynchronous copies
+ * that overlap the insert kernels only if the buffer is page-locked — allocate it here, or register an existing one (a JNI
+ * direct ByteBuffer's address) for as long as it is passed in.  Pageable buffers work, at a staged copy's speed. */
+int gk_host_alloc(gk_ctx *ctx, size_t nbytes, void **host_ptr);
+int gk_host_free(gk_ctx *ctx, void *host_ptr);
+int gk_host_register(gk_ctx *ctx, void *host_ptr, size_t nbytes);
+int gk_host_unregister(gk_ctx *ctx, void *host_ptr);
 /* raw device memory helpers for callers without their own allocator (tests, the C++ host side) */
 int gk_dev_alloc(gk_ctx *ctx, size_t nbytes, void **dev_ptr);
 int gk_dev_free(gk_ctx *ctx, void *dev_ptr);
@@ -86,11 +94,17 @@ int gk_map_size(gk_map *m, uint64_t *n);                   /* DNAMap.size :50 (l
 int gk_map_slots(gk_map *m, uint64_t *slots);              /* current table capacity in slots */
 /* Invariants of the table, checked on the device (the reference prints `nodeMap.size` next to the expected total,
  * Graph.scala:117): *live = live slots (== gk_map_size), *bad_slots = keys that are stored twice or in a segment
- * their hash does not name (must be 0), *sum_counts = sum of all counts (== occurrences inserted).  Any may be NULL. */
-int gk_map_verify(gk_map *m, uint64_t *live, uint64_t *bad_slots, uint64_t *sum_counts);
+ * their hash does not name (must be 0), *sum_counts = sum of all counts (== occurrences inserted), *checksum = an
+ * order-independent 64-bit checksum of the (key, count) set: two maps hold the same table iff (live, sum, checksum)
+ * agree — whatever their sizes, slot orders and insert histories (partitions of one table ADD UP: the checksum of a
+ * PartitionedDNAMap is the sum of its partitions' checksums mod 2^64).  Any may be NULL. */
+int gk_map_verify(gk_map *m, uint64_t *live, uint64_t *bad_slots, uint64_t *sum_counts, uint64_t *checksum);
 /* Upper bound on the k-mer windows one partitioned insert batch holds when a call brings more windows than the
- * table has room for (the batch's key scratch is ~17 x W x 8 bytes per window); 0 = default (2^31, or what HBM allows). */
+ * table has room for (the batch's key scratch is ~17 x W bytes per window); 0 = default (16 GiB of keys, half of the free HBM at most). */
 int gk_map_set_max_batch_keys(gk_map *m, uint64_t keys);
+/* Release the scratch the handle keeps between calls (key buffers of the partitioned insert, staging of host streams,
+ * point-query scratch).  The table is untouched; the next call allocates what it needs again. */
+int gk_map_trim(gk_map *m);
 
 /* FreqFilter.add over a stream of reads (S/data/FreqFilter.scala:28-36, 44-48):
  * for every read with len >= k, every window in order -> reverse complement -> orientation with
@@ -163,6 +177,8 @@ int gk_shard_superkmers_dev(gk_ctx *ctx, int k, const void *dev_records, uint64_
 int gk_map_count_superkmers_dev(gk_map *m, const void *dev_records, uint64_t nrecords, uint64_t kmers_total, uint64_t *occurrences);
 /* owner of one key under the same function (host-side, for tests and for routing point queries) */
 int gk_owner_of(int k, uint64_t lo, uint64_t hi, int P);
+/* *foreign = live keys of partition p's table whose owner (of P) is not p — 0 for a correctly routed PartitionedDNAMap */
+int gk_map_count_foreign(gk_map *m, int P, int p, uint64_t *foreign);
 
 /* ---- Graph: S/data/graph/Graph.scala ------------------------------------------------------- */
 /* Graph.buildGraph(k, kmersFreq) (:269-382): degree classification of every live key through
@@ -180,6 +196,17 @@ int gk_graph_remove_edges(gk_graph *g, const uint64_t *start_lo, const uint64_t 
 /* Graph.components + retain(maxBy size) (:54-72, :161-165; GraphBuilder.scala:52-54); ties between
  * equal-size components go to the one holding the smallest k-mer. */
 int gk_graph_retain_largest(gk_graph *g, uint64_t *kept_nodes, uint64_t *components);
+/* GraphBuilder's two component histograms (GraphBuilder.scala:41-47) are group-bys of these two arrays: one entry per
+ * connected component, nodes_per_component[i] = comp.size, edge_len_per_component[i] = sum of seq.size over the out-edges
+ * of its nodes; order unspecified.  If cap < *n the call fails with GK_E_CAPACITY and *n holds the required size. */
+int gk_graph_component_stats(gk_graph *g, uint32_t *nodes_per_component, uint64_t *edge_len_per_component, uint64_t cap, uint64_t *n);
+/* Order-independent 64-bit checksums of the canonical serialisation: the node k-mer set, and the edge set
+ * as (start k-mer, end k-mer, length, every base).  Two graphs with equal counts and checksums are the same graph. */
+int gk_graph_checksum(gk_graph *g, uint64_t *nodes_checksum, uint64_t *edges_checksum);
+/* How gk_graph_build spent its time: phase_ms6 = {degree classification (k_classify), terminals -> nodes + edge stubs,
+ * unitig measurement (k_walk pass 0 or pointer jumping), pool reservation, unitig emission, node index + counts} (wall ms,
+ * every phase ends in a stream sync); *walked_bases = bases emitted; *pointer_jumping = 1 if k_pj_* built the unitigs. */
+int gk_graph_build_stats(gk_graph *g, float *phase_ms6, uint64_t *walked_bases, int *pointer_jumping);
 /* live nodes, unspecified order */
 int gk_graph_export_nodes(gk_graph *g, uint64_t *lo, uint64_t *hi, uint64_t cap, uint64_t *n);
 /* live edges, unspecified order: start/end k-mer, length in bases, and the edge sequence as 2-bit

@@ -1,6 +1,6 @@
 """BASELINE.json configs[2] (C3): N x 150 bp reads over an E. coli-scale genome, k=31, one GPU:
 count -> deleteAll(<3) -> buildGraph -> removeBubbles -> simplifyGraph -> retainLargest, timed.
-usage: python scripts/run_c3.py [reads=5000000] [genome=4600000] [err=0.005] [chunk_reads=0] [capacity_hint=0] [prefilter_distinct=0] [k=31] [path=auto]
+usage: python scripts/run_c3.py [reads=5000000] [genome=4600000] [err=0.005] [chunk_reads=0] [capacity_hint=0] [prefilter_distinct=0] [k=31] [path=auto] [opts]
 chunk_reads = 0: ALL reads resident in HBM (39 B each), ONE gk_map_count_reads_dev call — the library cuts it into
 batches itself; > 0: the round-1 form, reads regenerated chunk by chunk into one small buffer, one call per chunk.
 prefilter_distinct > 0: two passes over the reads through the exact singleton pre-filter."""
@@ -15,8 +15,12 @@ arg = lambda i, d, f=int: f(sys.argv[i]) if len(sys.argv) > i else d
 n, G, err = arg(1, 5_000_000), arg(2, 4_600_000), arg(3, 0.005, float)
 chunk, hint, pfd, k = arg(4, 0), arg(5, 0), arg(6, 0), arg(7, 31)
 path = arg(8, "auto", str)
+opts = arg(9, "", str)          # gk_ctx_set_option pairs: name=value,name=value (A/B switches of the insert pipeline)
 L = 150
 ctx = Context(0)
+for kv in filter(None, opts.split(",")):
+    name, val = kv.split("=")
+    ctx.set_option(name, int(val))
 stride = synth.record_stride(L)
 resident = chunk == 0
 if resident:
@@ -65,7 +69,7 @@ distinct = m.size(); st = m.stats()
 t0 = time.perf_counter(); m.deleteAll_lt(3); t["filter_s"] = time.perf_counter() - t0
 good = m.size()
 t0 = time.perf_counter(); g = buildGraph(k, m); t["build_s"] = time.perf_counter() - t0
-c0 = g.counts()
+c0 = g.counts(); bstats = g.buildStats()
 t0 = time.perf_counter(); g.removeBubbles(); t["bubbles_s"] = time.perf_counter() - t0
 c1 = g.counts()
 t0 = time.perf_counter(); g.simplifyGraph(); t["simplify_s"] = time.perf_counter() - t0
@@ -77,5 +81,5 @@ print(json.dumps({"reads": n, "genome": G, "err": err, "resident": resident, "oc
                   "table": {k_: st[k_] for k_ in ("slots", "grows", "partitioned_launches", "direct_launches", "spilled_keys", "failed_segments",
                                                    "retries_direct", "est_new_distinct_last_batch", "repeat_heavy")},
                   "count_kernel_ms": kernel_ms, "count_phases_ms": [round(float(x), 3) for x in phases],
-                  "occ_per_s_count": occ / t["count_s"], "graph_built": c0, "after_bubbles": c1, "after_simplify": c2,
+                  "occ_per_s_count": occ / t["count_s"], "graph_built": c0, "build_stats": bstats, "after_bubbles": c1, "after_simplify": c2,
                   "components": comps, "largest": c3, "times": {k_: round(v, 4) for k_, v in t.items()}}))

@@ -1,0 +1,187 @@
+"""BASELINE.json's configurations on one MI355X (-m gpu).
+
+C1 (10k x 100 bp, k=21) at its stated size: table and graph bit-exact against the oracle.
+C2 (1M x 150 bp, k=31) at full size, mode U (the bench's insert-stress reading) and mode G: size-independent
+   properties + sampled exactness, through the partitioned pipeline the bench runs.
+C4 (500M x 150 bp, k=55, 8 GPUs) and C5 (2B x 150 bp, k=63, 8 GPUs): ONE RANK'S SHARE — an eighth of the reads
+   over an eighth of the genome (so coverage and the table a rank ends up with are those of the real run) —
+   routed to P = 8 logical partitions on one device, through the exact singleton pre-filter so that the tables
+   fit.  The oracle cannot follow at this size (parity at oracle-size inputs: test_table_gpu.py,
+   test_prefilter_gpu.py); checked here: the window count, owner placement of every stored key, no key stored twice,
+   sum of counts == windows admitted, and — where the unfiltered table fits — survivors of deleteAll(v < 3)
+   identical with and without the pre-filter (live, sum, checksum over all partitions).
+The 8-GPU exchange itself (RCCL) cannot run on this box: `configs_untested` keeps "C4/C5 at 8 ranks".
+"""
+import numpy as np
+import pytest
+
+from genome_amd import dna, synth
+from genome_amd.dnamap import Context, HipDNAMap
+from genome_amd.graph import buildGraph
+from genome_amd.partitioned import PartitionedDNAMap
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = Context(0)
+    yield c
+    c.close()
+
+
+def assert_same_table(got, want):
+    for name, a, b in zip(("lo", "hi", "count"), got, want):
+        assert a.shape == b.shape, f"{name}: {a.shape} vs {b.shape}"
+        assert np.array_equal(a, b), name
+
+
+def oracle_canonical(og):
+    k = og.k
+    nlo, nhi = og.nodes()
+    nodes = [dna.unpack(int(a), int(b), k) for a, b in zip(nlo, nhi)]
+    e = og.edges()
+    edges = []
+    for i in range(len(e["len"])):
+        seq = synth.bases_to_str(e["bases"][e["off"][i]:e["off"][i] + e["len"][i]])
+        edges.append((dna.unpack(int(e["slo"][i]), int(e["shi"][i]), k), dna.unpack(int(e["elo"][i]), int(e["ehi"][i]), k), seq))
+    return nodes, edges
+
+
+def test_c1_full_size_table_and_graph_exact(ctx):
+    """configs[0]: 10k x 100 bp, k = 21, 20 kbp genome (50x), 1 % error — SURVEY.md §8d C1, at its stated size."""
+    n, L_, k, G, e = 10_000, 100, 21, 20_000, 0.01
+    rec = synth.reads_mode_g(n, L_, G, e, config_id=1)
+    ref = O.PMap(k, 1)
+    occ = ref.count_reads(rec.tobytes(), n)
+    assert occ == n * (L_ - k + 1) == 800_000
+    want = ref.export_sorted()
+    d = ctx.alloc(rec.size + 64)
+    ctx.upload(d, rec)
+    maps = []
+    for path, entry in (("auto", "host"), ("direct", "dev"), ("partitioned", "dev")):
+        m = HipDNAMap(ctx, k)
+        m.set_insert_path(path)
+        got = m.count_reads(rec.tobytes(), n) if entry == "host" else m.count_reads_dev(d, n, L_)
+        assert got == occ
+        assert_same_table(m.sorted_items(), want)
+        assert m.verify() == (ref.size(), 0, occ)
+        maps.append(m)
+    ref.delete_lt(3)                                   # GraphBuilder.scala:30 rounds = 3
+    for m in maps:
+        m.deleteAll_lt(3)
+        assert_same_table(m.sorted_items(), ref.export_sorted())
+    og = O.Graph(ref)
+    g = buildGraph(k, maps[0])
+    assert g.canonical() == oracle_canonical(og)
+    assert g.counts() == (og.num_nodes(), og.num_edges(), og.total_edge_len())
+    # GraphBuilder.scala:37-54: components, the two histograms, retain(max component)
+    nodes_pc, len_pc = g.componentStats()
+    assert len(nodes_pc) == og.num_components()
+    assert int(nodes_pc.sum()) == og.num_nodes() and int(len_pc.sum()) == og.total_edge_len()
+    h1, h2 = g.componentHistograms()
+    assert sum(c for _, c in h1) == sum(c for _, c in h2) == og.num_components()
+    kept, comps = g.retainLargest()
+    assert comps == og.num_components() and kept == og.retain_largest() == int(nodes_pc.max())
+    assert g.canonical() == oracle_canonical(og)
+    g.removeBubbles(); og.remove_bubbles(); g.simplifyGraph(); og.simplify()
+    assert g.canonical() == oracle_canonical(og)
+    g.close()
+    for m in maps:
+        m.close()
+    ctx.free(d)
+
+
+@pytest.mark.parametrize("mode", ["U", "G"])
+def test_c2_full_size_properties(ctx, mode):
+    """configs[1]: 1M x 150 bp, k = 31 — the bench's workload, both synthetic modes, the path the bench takes."""
+    n, L_, k = 1_000_000, 150, 31
+    stride = synth.record_stride(L_)
+    d = ctx.alloc(n * stride + 64)
+    ctx.synth_reads(d, n, L_, mode, 2, 0, 5_000_000, 0.01)
+    occ = n * (L_ - k + 1)
+    m = HipDNAMap(ctx, k, int(occ * 1.05))             # bench.py's hint
+    assert m.count_reads_dev(d, n, L_) == occ
+    st = m.stats()
+    assert st["partitioned_launches"] >= 1 and st["direct_launches"] == 0, st
+    live, bad, total, chk = m.verify_checksum()
+    assert live == m.size() and bad == 0 and total == occ
+    if mode == "U":
+        assert live > occ - 100                        # uniform 31-mers: all distinct but for birthday collisions
+    # sampled exactness: the first 300 reads through the oracle
+    head = ctx.download(d, 300 * stride)
+    ref = O.PMap(k, 1)
+    ref.count_reads(head.tobytes(), 300)
+    rlo, rhi, rcnt = ref.export_sorted()
+    got = m.apply_batch((rlo, rhi))
+    assert (got >= rcnt).all()
+    if mode == "U":
+        assert (got == rcnt).sum() > len(rcnt) - 5      # distinct reads: the sample's counts are the table's
+    # the direct path builds the same table (live, sum, checksum)
+    m2 = HipDNAMap(ctx, k, int(occ * 1.05))
+    m2.set_insert_path("direct")
+    assert m2.count_reads_dev(d, n, L_) == occ
+    assert m2.verify_checksum() == (live, 0, total, chk)
+    m2.close()
+    # additivity of a second pass, filter monotonicity
+    m.count_reads_dev(d, n, L_)
+    assert m.size() == live and m.verify()[2] == 2 * occ
+    m.deleteAll_lt(3)
+    assert m.verify()[0] == m.size() <= live
+    m.close(); ctx.free(d)
+
+
+def _share(ctx, k, n, G, e, cfg, chunk, with_plain):
+    """One rank's share of an 8-GPU configuration on P = 8 logical partitions, pre-filtered."""
+    L_, P = 150, 8
+    stride = synth.record_stride(L_)
+    nk = L_ - k + 1
+    d = ctx.alloc(chunk * stride + 64)
+
+    def chunks():
+        for first in range(0, n, chunk):
+            c = min(chunk, n - first)
+            ctx.synth_reads(d, c, L_, "G", cfg, first, G, e)
+            ctx.sync()
+            yield d, c
+
+    solid = G                                            # ~ one k-mer per genome position
+    errors = int(n * L_ * e * k)                         # ~ k new k-mers per sequencing error, almost all seen once
+    pm = PartitionedDNAMap(ctx, k, P, capacity_hint=int(solid * 1.2 + errors * 0.3))
+    looked, admitted = pm.count_reads_dev_prefiltered(chunks(), L_, solid + errors)
+    assert looked == n * nk
+    assert 0 < admitted < looked
+    live, bad, total, chk = pm.verify()
+    assert live == pm.size() and bad == 0 and total == admitted
+    assert pm.foreign_keys() == 0
+    sizes = [p.size() for p in pm.parts]
+    assert max(sizes) < 2.5 * (sum(sizes) / P), sizes      # minimizer owners: uneven, but every partition carries its part
+    pm.deleteAll_lt(3)
+    filtered = pm.verify()
+    assert filtered[0] == pm.size() and filtered[1] == 0
+    assert 0.5 * solid < filtered[0] < 1.6 * solid          # what survives is the genome's k-mers (plus errors seen 3 times)
+    pm.close()
+    if with_plain:
+        plain = PartitionedDNAMap(ctx, k, P, capacity_hint=int((solid + errors) * 1.05))
+        occ = 0
+        for dd, c in chunks():
+            occ += plain.count_reads_dev(dd, c, L_)
+        assert occ == n * nk
+        lv, bd, tot, _ = plain.verify()
+        assert bd == 0 and tot == occ and plain.foreign_keys() == 0
+        plain.deleteAll_lt(3)
+        assert plain.verify() == filtered, "survivors with and without the pre-filter must be the same table"
+        plain.close()
+    ctx.free(d)
+
+
+def test_c4_one_rank_share_k55_partitioned_prefiltered(ctx):
+    """configs[3] / 8: 62.5 M x 150 bp over 187.5 Mbp (50x), k = 55, e = 0.5 %; 6e9 windows of 16-byte keys."""
+    _share(ctx, k=55, n=62_500_000, G=187_500_000, e=0.005, cfg=4, chunk=12_500_000, with_plain=True)
+
+
+def test_c5_one_rank_share_k63_partitioned_prefiltered(ctx):
+    """configs[4] / 8: 250 M x 150 bp over 387.5 Mbp (~97x), k = 63, e = 0.2 %; 2.2e10 windows.  The unfiltered table
+    (~5e9 16-byte keys) does not fit one GPU — which is what the pre-filter is for — so no with/without comparison here."""
+    _share(ctx, k=63, n=250_000_000, G=387_500_000, e=0.002, cfg=5, chunk=25_000_000, with_plain=False)
