@@ -6,10 +6,11 @@ in HBM: clear the table, then FreqFilter.add for every read (extract -> canonica
 count).  Workload = BASELINE.json configs[1] ("C2"): 1M x 150 bp reads per GPU, k=31.
   N = 1 : single-partition DNAMap kernel (gk_map_count_reads_dev).
   N > 1 : weak scaling, one rank per GPU: every rank owns 1M reads and one table partition; k-mers are
-          routed by strand-symmetric minimizer owner as SUPER-K-MER records (gk_shard_superkmers_dev:
-          runs of same-owner windows, 2 bits/base in 16-B slots), exchanged with ONE RCCL all-to-all
-          (torch.distributed, backend nccl) and counted by their owner with the same pipeline as
-          reads (gk_map_count_superkmers_dev).  value = distinct k-mers over all partitions / max-over-ranks time.
+          routed by strand-symmetric minimizer owner as SUPER-K-MER records (runs of same-owner windows,
+          2 bits/base in 16-B slots), exchanged with ONE all-to-all over RCCL/xGMI and counted by their
+          owner with the same pipeline as reads — all of it inside the C-ABI (gk_dist_count_reads_dev,
+          csrc/gk_dist.hip).  torch.distributed (gloo) only carries the 128-byte RCCL id from rank 0 to
+          the others.  value = distinct k-mers over all partitions / max-over-ranks time.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -21,8 +22,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402  (first: its bundled HIP runtime must be the process's only one)
-import torch.distributed as dist  # noqa: E402
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # only to bootstrap the RCCL id across ranks — and FIRST: the HIP runtime (and RCCL) torch bundles must be the
+    # process's only ones (the library dlopens whichever RCCL is already loaded)
+    import torch  # noqa: E402
+    import torch.distributed as dist  # noqa: E402
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -78,6 +82,102 @@ def cpu_baseline(rec_host: np.ndarray, nreads_total: int, k: int, target_s: floa
                               "sample": f"first {sample1} reads, {dt1:.1f} s, one ArrayDNAMap"}}
 
 
+def c2_variant(ctx, rec_ptr, n, L, k, mode, steps, warmup, host_buf=None):
+    """C2 again, outside the headline: mode G (5 Mbp genome, 30x, 1 % error — repeats) device-resident, or the §8(d) reading
+    of the metric: packed reads in PINNED HOST memory -> complete table in HBM (gk_map_count_reads: the upload runs in
+    sub-chunks on a copy stream and overlaps the L1 scatter of the pipeline)."""
+    from genome_amd.dnamap import HipDNAMap
+    nk = L - k + 1
+    m = HipDNAMap(ctx, k, int(n * nk * 1.05))
+    kms, phases = [], []
+
+    def step():
+        m.clear()
+        if host_buf is None:
+            m.count_reads_dev(rec_ptr, n, L)
+        else:
+            m.count_reads(host_buf, n)
+        kms.append(m.last_count_kernel()[0]); phases.append(m.last_phase_ms())
+
+    for _ in range(warmup):
+        step()
+    kms.clear(); phases.clear()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / steps
+    distinct = m.size()
+    st = m.stats()
+    out = {"ms_per_step": dt * 1e3, "value": distinct / dt, "unit": "distinct k-mers/s", "occurrences_per_s": n * nk / dt,
+           "distinct_per_step": distinct, "steps": steps, "kernel_ms": float(np.mean(kms)),
+           "phases_ms": dict(zip(["k_part_hist1", "k_part_scatter1", "k_part_hist2", "k_part_scatter2", "k_seg_insert"],
+                                 [float(x) for x in np.mean(np.array(phases), axis=0)])),
+           "insert_path": "partitioned" if st["partitioned_launches"] else "direct", "table_slots": st["slots"]}
+    abytes = algorithmic_bytes_count_kernel(n * nk, distinct, L, k)
+    out["roofline_frac_of_step"] = abytes / dt / 1e9 / HBM_PEAK_GBS
+    m.close()
+    return out
+
+
+def c3_object(ctx):
+    """BASELINE.json configs[2] measured in THIS run: 50 M x 150 bp reads over a 4.6 Mbp genome (~1600x, 0.5 % error), k = 31, one
+    GPU, all reads resident in HBM (1.95 GB): FreqFilter.extractFilteredKmers(.., 3) -> Graph.buildGraph -> removeBubbles ->
+    simplifyGraph -> components + retain (GraphBuilder.scala:32-54).  One warm-up pass, one timed pass; wall ms per phase
+    (every call returns synchronised), device ms where the library keeps them, and each phase's algorithmic bytes against HBM peak."""
+    from genome_amd import synth
+    from genome_amd.dnamap import HipDNAMap
+    from genome_amd.graph import buildGraph
+    N, L, k, G, err = 50_000_000, 150, 31, 4_600_000, 0.005
+    nk = L - k + 1
+    d = ctx.alloc(N * synth.record_stride(L) + 64)
+    ctx.synth_reads(d, N, L, "G", 3, 0, G, err)
+    ctx.sync()
+    m = HipDNAMap(ctx, k, 0)
+    res = None
+    for timed in (False, True):
+        t = {}
+        m.clear()
+        t0 = time.perf_counter(); occ = m.count_reads_dev(d, N, L); t["count"] = time.perf_counter() - t0
+        count_kernel_ms = m.last_count_kernel()[0]; phases = m.last_phase_ms(); st = m.stats(); distinct = m.size()
+        t0 = time.perf_counter(); m.deleteAll_lt(3); t["filter_lt"] = time.perf_counter() - t0
+        good = m.size()
+        t0 = time.perf_counter(); g = buildGraph(k, m); t["buildGraph"] = time.perf_counter() - t0
+        built, bs = g.counts(), g.buildStats()
+        t0 = time.perf_counter(); g.removeBubbles(); t["removeBubbles"] = time.perf_counter() - t0
+        t0 = time.perf_counter(); g.simplifyGraph(); t["simplifyGraph"] = time.perf_counter() - t0
+        t0 = time.perf_counter(); kept, comps = g.retainLargest(); t["retainLargest"] = time.perf_counter() - t0
+        final = g.counts()
+        g.close()
+        if not timed:
+            continue
+        ph = bs["phase_ms"]
+        walk_ms = ph["unitig_measure"] + ph["unitig_emit"]
+
+        def roof(nbytes, ms):
+            gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            return {"algorithmic_bytes": nbytes, "ms": ms, "achieved_GB_s": gbs, "frac": gbs / HBM_PEAK_GBS}
+        res = {"workload": f"C3: {N} x {L}bp reads (SplitMix64 mode G, {G} bp genome, e={err}), k={k}, 1 GPU, reads resident in HBM, no capacity hint",
+               "occurrences": occ, "distinct": distinct, "good_kmers_ge3": good,
+               "wall_ms": {k_: v * 1e3 for k_, v in t.items()}, "total_wall_ms": sum(t.values()) * 1e3,
+               "count": {"kernel_ms": count_kernel_ms,
+                         "phases_ms": dict(zip(["k_part_hist1", "k_part_scatter1", "k_part_hist2+scans", "k_part_scatter2", "k_seg_insert"], phases)),
+                         "occurrences_per_s": occ / t["count"], "distinct_per_s": distinct / t["count"],
+                         "partitioned_launches": st["partitioned_launches"], "direct_launches": st["direct_launches"],
+                         "table_slots": st["slots"], "grows": st["grows"], "spilled_keys": st["spilled_keys"]},
+               "graph": {"nodes_edges_bases_built": built, "build_phase_ms": ph, "pointer_jumping": bs["pointer_jumping"],
+                         "components": comps, "largest_component_nodes": kept, "nodes_edges_bases_final": final},
+               "roofline": {"count": roof(occ * (2.0 * L / (8.0 * nk) + 16.0) + distinct * 8.0, t["count"] * 1e3),
+                            "filter_lt": roof(20.0 * st["slots"], t["filter_lt"] * 1e3),
+                            "classify": roof(80.0 * good, ph["classify"]),
+                            "unitig_walk": roof(9.25 * bs["walked_bases"], walk_ms),
+                            "bytes_per_unit": "SURVEY.md §8d: 16.3 B/occurrence (+8 B/distinct key) count; 20 B/slot filter (12 B scan + 8 B tombstone; the wall "
+                                              "time also holds the rebuild into a table sized for the survivors); 80 B/live key classify; 9.25 B/walked base"}}
+    m.close(); ctx.free(d)
+    return res
+
+
 def main():
     # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version banner) write to
     # fd 1 behind Python's back, so fd 1 is pointed at stderr until the result is ready.
@@ -98,6 +198,7 @@ def main():
     ap.add_argument("--sharded", action="store_true", help="run the N>1 code path (owner bucketing + all-to-all + owner insert) "
                     "even with one rank: the only way to exercise it on a 1-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the objects measured next to the headline at N=1: mode_G, pcie_inclusive, c3")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,67 +209,64 @@ def main():
             print(f"bench.py: --gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)", file=sys.stderr)
         if world == 1 and args.gpus > 1:
             sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.sharded
-    if sharded:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from genome_amd import synth
     from genome_amd.dnamap import Context, HipDNAMap
-    from genome_amd.dnamap import skm_slot_bytes
-    from genome_amd.partitioned import exchange_records
 
     n, L, k = args.reads, args.read_len, args.k
     W = 1 if k <= 32 else 2
     nk = L - k + 1
     stride = synth.record_stride(L)
     ctx = Context(local_rank)
-    rec = torch.empty(n * stride + 64, dtype=torch.uint8, device=dev)
+    rec = ctx.alloc(n * stride + 64)
     G, err = 5_000_000 * world, 0.01
-    ctx.synth_reads(rec.data_ptr(), n, L, args.mode, 2, rank * n, G, err)     # config_id 2 = C2
+    ctx.synth_reads(rec, n, L, args.mode, 2, rank * n, G, err)     # config_id 2 = C2
     occ_rank = n * nk
-    m = HipDNAMap(ctx, k, int(occ_rank * 1.05 * float(os.environ.get('GK_HINT_SCALE', '1'))))
-    m.set_insert_path(args.insert_path)
+    hint = int(occ_rank * 1.05 * float(os.environ.get('GK_HINT_SCALE', '1')))
+    hd = None
     if sharded:
-        slot = skm_slot_bytes(k)
-        send_cap = n * 24 // world * world                       # records, world regions of send_cap/world slots
-        send = torch.empty(send_cap * slot, dtype=torch.uint8, device=dev)
-        recv = torch.empty(send_cap * slot, dtype=torch.uint8, device=dev)
+        from genome_amd.dist import DistDNAMap, HipDist, unique_id
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            idt = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                idt = torch.frombuffer(bytearray(unique_id()), dtype=torch.uint8).clone()
+            dist.broadcast(idt, 0)
+            id128 = bytes(idt.numpy().tobytes())
+        else:
+            id128 = unique_id()
+        hd = HipDist(ctx, rank, world, id128)
+        pm = DistDNAMap(hd, k, hint)
+        m = pm.local
+    else:
+        m = HipDNAMap(ctx, k, hint)
+    m.set_insert_path(args.insert_path)
 
-    kernel_ms, kernel_units, phase_ms = [], [], []
+    kernel_ms, kernel_units, phase_ms, dist_ms = [], [], [], []
 
     def step():
         m.clear()
         if not sharded:
-            m.count_reads_dev(rec.data_ptr(), n, L)
+            m.count_reads_dev(rec, n, L)
             ms, kocc = m.last_count_kernel()
             kernel_ms.append(ms); kernel_units.append(kocc); phase_ms.append(m.last_phase_ms())
             return
-        nonlocal recv
-        recs, kmers = ctx.shard_superkmers(k, rec.data_ptr(), n, L, world, send.data_ptr(), send_cap)
-        recv, nrec, nrecv = exchange_records(dist, send, recs, kmers, slot, send_cap // world, recv)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        m.count_superkmers_dev(recv.data_ptr(), nrec, nrecv)
-        kernel_ms.append((time.perf_counter() - t0) * 1e3); kernel_units.append(nrecv); phase_ms.append(m.last_phase_ms())
+        _, owned = pm.count_reads_dev(rec, n, L)
+        ms, _ = m.last_count_kernel()
+        kernel_ms.append(ms); kernel_units.append(owned); phase_ms.append(m.last_phase_ms()); dist_ms.append(hd.last_ms())
 
     def fence():
-        torch.cuda.synchronize()
-        ctx_sync()
+        ctx.sync()
         if sharded:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    def ctx_sync():
-        from genome_amd import _lib
-        _lib.check(_lib.lib().gk_ctx_sync(ctx.h), ctx.h)
+            hd.barrier()
+            ctx.sync()
 
     for _ in range(args.warmup):
         step()
-    kernel_ms.clear(); kernel_units.clear(); phase_ms.clear()
+    kernel_ms.clear(); kernel_units.clear(); phase_ms.clear(); dist_ms.clear()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -177,11 +275,10 @@ def main():
     dt = time.perf_counter() - t0
 
     distinct_rank = m.size()
-    tt = torch.tensor([dt, float(distinct_rank), float(occ_rank)], dtype=torch.float64, device=dev)
     if sharded:
-        tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt_max, distinct_total, occ_total = float(tmax[0]), float(tsum[1]), float(tsum[2])
+        dt_max = float(hd.allreduce([dt], "max")[0])
+        tsum = hd.allreduce([float(distinct_rank), float(occ_rank)], "sum")
+        distinct_total, occ_total = float(tsum[0]), float(tsum[1])
     else:
         dt_max, distinct_total, occ_total = dt, float(distinct_rank), float(occ_rank)
 
@@ -217,7 +314,9 @@ def main():
         avg_kernel_ms = kernel_time_ms
         achieved = abytes / (avg_kernel_ms * 1e-3) / 1e9
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_pipeline_v8.json" if partitioned else "pmc_count_reads_v2.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r02", "pmc_pipeline_v9.json") if partitioned else os.path.join(ROOT, "profiles", "r01", "pmc_count_reads_v2.json")
+        if partitioned and not os.path.exists(pmc_file):
+            pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_pipeline_v8.json")
         if not sharded and args.mode == "U" and n == 1_000_000 and L == 150 and k == 31 and os.path.exists(pmc_file):
             pj = json.load(open(pmc_file))
             traffic = pj.get("hbm_bytes_per_launch", pj.get("k_count_reads<1>", {}).get("hbm_bytes_per_launch"))
@@ -243,9 +342,28 @@ def main():
                          "phases_ms": phase_detail, "dominant": dominant,
                          "traffic_source": (os.path.relpath(pmc_file, ROOT) if traffic else None)},
         }
+        if sharded and dist_ms:
+            out["per_rank_step_ms"] = {k_: float(np.mean([x[k_] for x in dist_ms])) for k_ in dist_ms[0]}
+            out["per_rank_step_ms"]["what"] = ("rank 0, wall ms inside gk_dist_count_reads_dev: route = reads -> super-k-mer records grouped by owner; "
+                                               "exchange = counts + records over RCCL (enqueue + the one host sync for the sizes); owner_count = "
+                                               "the pipeline over what arrived (stream-ordered behind the receives)")
+        default_workload = args.mode == "U" and n == 1_000_000 and L == 150 and k == 31
+        if world == 1 and not sharded and not args.no_extras and default_workload:
+            recg = ctx.alloc(n * stride + 64)
+            ctx.synth_reads(recg, n, L, "G", 2, 0, 5_000_000, 0.01)
+            out["mode_G"] = c2_variant(ctx, recg, n, L, k, "G", 5, 2)
+            out["mode_G"]["workload"] = "C2 mode G: 5 Mbp genome, 30x, 1 % error (SURVEY.md §8d) — the same reads count, with repeats"
+            ctx.free(recg)
+            hb = ctx.host_alloc(n * stride)
+            hb[:] = ctx.download(rec, n * stride)
+            out["pcie_inclusive"] = c2_variant(ctx, None, n, L, k, "U", 10, 2, host_buf=hb)
+            out["pcie_inclusive"]["workload"] = ("SURVEY.md §8(d) reading of the metric: the headline's reads as a `.bin` stream in PINNED HOST memory -> complete "
+                                                 "table in HBM (gk_map_count_reads; host framing walk + PCIe upload in sub-chunks overlapped with the L1 scatter)")
+            ctx.host_free(hb)
+            out["c3"] = c3_object(ctx)
         if not args.no_cpu_baseline and world == 1 and not sharded:
             sample_reads = min(n, 400_000)
-            host = ctx.download(rec.data_ptr(), sample_reads * stride).reshape(sample_reads, stride)
+            host = ctx.download(rec, sample_reads * stride).reshape(sample_reads, stride)
             out["cpu_baseline"] = cpu_baseline(host, sample_reads, k)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
@@ -255,8 +373,10 @@ def main():
         os.dup2(2, 1)
     m.close()
     if sharded:
-        dist.barrier()
-        dist.destroy_process_group()
+        hd.barrier()
+        hd.close()
+        if world > 1:
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -19,9 +19,9 @@ LIB_PATH = os.path.join(_HERE, "libgenome_amd.so")
 
 GK_OK = 0
 GK_E_INVALID, GK_E_KLEN, GK_E_UNSUPPORTED_K, GK_E_CAPACITY = -1, -2, -3, -4
-GK_E_HIP, GK_E_NODEVICE, GK_E_FORMAT, GK_E_STATE = -5, -6, -7, -8
+GK_E_HIP, GK_E_NODEVICE, GK_E_FORMAT, GK_E_STATE, GK_E_COMM = -5, -6, -7, -8, -9
 _NAMES = {-1: "GK_E_INVALID", -2: "GK_E_KLEN", -3: "GK_E_UNSUPPORTED_K", -4: "GK_E_CAPACITY", -5: "GK_E_HIP",
-          -6: "GK_E_NODEVICE", -7: "GK_E_FORMAT", -8: "GK_E_STATE"}
+          -6: "GK_E_NODEVICE", -7: "GK_E_FORMAT", -8: "GK_E_STATE", -9: "GK_E_COMM"}
 
 
 class GkError(RuntimeError):
@@ -86,6 +86,33 @@ SIGNATURES = {
     "gk_skm_slot_bytes": (C.c_int, [C.c_int]),
     "gk_shard_superkmers_dev": (C.c_int, [vp, C.c_int, vp, C.c_uint64, C.c_int, C.c_int, vp, C.c_uint64, u64p, u64p]),
     "gk_map_count_superkmers_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, u64p]),
+    "gk_dist_unique_id": (C.c_int, [vp]),
+    "gk_dist_create": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]),
+    "gk_dist_destroy": (None, [vp]),
+    "gk_dist_rank": (C.c_int, [vp]),
+    "gk_dist_world": (C.c_int, [vp]),
+    "gk_dist_barrier": (C.c_int, [vp]),
+    "gk_dist_allreduce_f64": (C.c_int, [vp, C.POINTER(C.c_double), C.c_int, C.c_int]),
+    "gk_dist_count_reads_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, u64p, u64p]),
+    "gk_dist_last_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
+    "gk_dist_size": (C.c_int, [vp, vp, u64p]),
+    "gk_dist_gather_map": (C.c_int, [vp, vp, C.POINTER(vp)]),
+    "gk_vmap_create": (C.c_int, [vp, C.c_int, C.c_uint64, C.POINTER(vp)]),
+    "gk_vmap_destroy": (None, [vp]),
+    "gk_vmap_k": (C.c_int, [vp]),
+    "gk_vmap_size": (C.c_int, [vp, u64p]),
+    "gk_vmap_put_new_batch": (C.c_int, [vp, u64p, u64p, u64p, C.c_uint64]),
+    "gk_vmap_update_batch": (C.c_int, [vp, u64p, u64p, u64p, C.c_uint64]),
+    "gk_vmap_get_all_batch": (C.c_int, [vp, u64p, u64p, C.c_uint64, u64p, u64p, C.c_uint64, u64p]),
+    "gk_vmap_get_batch": (C.c_int, [vp, u64p, u64p, C.c_uint64, u64p, u8p]),
+    "gk_vmap_export": (C.c_int, [vp, u64p, u64p, u64p, C.c_uint64, u64p]),
+    "gk_graph_position_map": (C.c_int, [vp, vp, u64p]),
+    "gk_graph_node_lookup": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "gk_graph_nodes_by_id": (C.c_int, [vp, C.POINTER(C.c_uint32), C.c_uint64, u64p, u64p, u8p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "gk_graph_edges_by_id": (C.c_int, [vp, C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u64p, u8p, u8p]),
+    "gk_graph_add_node": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]),
+    "gk_graph_replace_start": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
+    "gk_graph_replace_end": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
     "gk_graph_build": (C.c_int, [vp, C.POINTER(vp)]),
     "gk_graph_destroy": (None, [vp]),
     "gk_graph_counts": (C.c_int, [vp, u64p, u64p, u64p]),

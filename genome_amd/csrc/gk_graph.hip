@@ -32,6 +32,13 @@
 
 using namespace gk;
 
+struct gk_vmap;
+namespace gk {
+int vmap_put_new_dev(gk_vmap *m, const uint64_t *d_lo, const uint64_t *d_hi, const uint64_t *d_val, uint64_t n);
+int vmap_k(const gk_vmap *m);
+gk_ctx *vmap_ctx(const gk_vmap *m);
+}
+
 static constexpr u32 NONE = 0xFFFFFFFFu;
 static constexpr u32 AUX_TERMINAL = 1u << 8;
 static constexpr u32 AUX_SECONDARY = 1u << 9;
@@ -915,6 +922,158 @@ template <int W> __global__ void k_out_order(GraphView g, u64 lo, u64 hi, int *o
     for (int i = 0; i < order_count(o); i++) out5[1 + i] = order_base(o, i);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Graph.getGraphMap (Graph.scala:90-119): every k-mer of the graph -> where it sits.  A node's k-mer -> NodeGraphPosition(id);
+// for an edge, the k-mers at distance 1 .. len-1 from its start node — windows of (start.seq ++ edge.seq) — ->
+// EdgeGraphPosition(id, dist); the window at distance len is the end node's own k-mer and is not added (:108-113).
+// One lane per (edge, distance): the window is cut out of the start k-mer and the 2-bit pool directly, no rolling.
+// ---------------------------------------------------------------------------------------------
+static constexpr u64 POS_EDGE = 1ull << 63;
+__device__ __forceinline__ int path_base(const GraphView &g, u32 s, u64 off, int k, u64 i) {      // base i of start.seq ++ edge.seq
+    if (i < (u64)k) return (int)(((i < 32 ? g.node_lo[s] : g.node_hi[s]) >> (2 * (i & 31))) & 3);
+    return pool_get(g.pool, off, i - (u64)k);
+}
+template <int W> __device__ __forceinline__ Kmer<W> path_window(const GraphView &g, u32 s, u64 off, int k, u64 dist) {
+    Kmer<W> x{};
+    for (int i = 0; i < k; i++) {
+        const u64 b = (u64)path_base(g, s, off, k, dist + (u64)i);
+        if (i < 32) x.lo |= b << (2 * i);
+        else if constexpr (W == 2) x.hi |= b << (2 * (i - 32));
+    }
+    return x;
+}
+// pass 0: entries per live edge (len - 1) -> its first entry through a block-aggregated cursor; pass 1 (flat): fill
+__global__ __launch_bounds__(BLOCK) void k_pos_reserve(GraphView g, unsigned long long *first_entry, unsigned long long *cursor) {
+    __shared__ u32 lds4[BLOCK / 64];
+    __shared__ unsigned long long s_base;
+    const u64 ngroups = (g.n_edges + BLOCK - 1) / BLOCK;
+    for (u64 grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const u64 e = grp * BLOCK + threadIdx.x;
+        const u64 cnt = e < g.n_edges && g.e_alive[e] ? g.e_len[e] - 1 : 0;
+        const u32 small = cnt < (1u << 22) ? (u32)cnt : 0u;
+        u64 o = block_reserve(small, cursor, lds4, &s_base);
+        if (e < g.n_edges) first_entry[e] = small == cnt ? o : atomicAdd(cursor, (unsigned long long)cnt);
+    }
+}
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_pos_fill(GraphView g, int k, const unsigned long long *__restrict__ first_entry, u64 node_entries,
+                                                    u64 *lo, u64 *hi, u64 *val) {
+    const u64 tid = (u64)blockIdx.x * BLOCK + threadIdx.x, stride = (u64)gridDim.x * BLOCK;
+    // short edges: one lane walks the edge; long ones (> 64 entries): the whole grid strides over their distances below
+    for (u64 e = tid; e < g.n_edges; e += stride) {
+        if (!g.e_alive[e]) continue;
+        const u64 cnt = g.e_len[e] - 1;
+        if (cnt > 64) continue;
+        const u32 s = g.e_start[e];
+        const u64 off = g.e_off[e], at = node_entries + first_entry[e];
+        for (u64 d = 1; d <= cnt; d++) {
+            const Kmer<W> x = path_window<W>(g, s, off, k, d);
+            lo[at + d - 1] = x.lo;
+            if constexpr (W == 2) hi[at + d - 1] = x.hi;
+            val[at + d - 1] = POS_EDGE | ((u64)e << 32) | d;
+        }
+    }
+}
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_pos_fill_long(GraphView g, int k, const unsigned long long *__restrict__ first_entry, u64 node_entries,
+                                                         u64 *lo, u64 *hi, u64 *val) {
+    // one WORKGROUP per long edge at a time (grid-stride over edges), its lanes over the distances
+    for (u64 e = blockIdx.x; e < g.n_edges; e += gridDim.x) {
+        if (!g.e_alive[e]) continue;
+        const u64 cnt = g.e_len[e] - 1;
+        if (cnt <= 64) continue;
+        const u32 s = g.e_start[e];
+        const u64 off = g.e_off[e], at = node_entries + first_entry[e];
+        for (u64 d = 1 + threadIdx.x; d <= cnt; d += BLOCK) {
+            const Kmer<W> x = path_window<W>(g, s, off, k, d);
+            lo[at + d - 1] = x.lo;
+            if constexpr (W == 2) hi[at + d - 1] = x.hi;
+            val[at + d - 1] = POS_EDGE | ((u64)e << 32) | d;
+        }
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_pos_nodes(GraphView g, u64 *lo, u64 *hi, u64 *val, unsigned long long *cursor) {
+    __shared__ u32 lds4[BLOCK / 64];
+    __shared__ unsigned long long s_base;
+    const u64 ngroups = (g.n_nodes + BLOCK - 1) / BLOCK;
+    for (u64 grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const u64 n = grp * BLOCK + threadIdx.x;
+        const bool live = n < g.n_nodes && g.node_alive[n];
+        const u64 o = block_reserve(live ? 1u : 0u, cursor, lds4, &s_base);
+        if (live) { lo[o] = g.node_lo[n]; if (hi) hi[o] = g.node_hi[n]; val[o] = (u64)n; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// point edits by id (the simplifier's node split: addNode, replaceStart, replaceEnd — Graph.scala:172-176, 197-209)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_replace_start(GraphView g, u32 e, u32 ns, int *status) {
+    if (e >= g.n_edges || !g.e_alive[e] || ns >= g.n_nodes || !g.node_alive[ns]) { *status = 1; return; }
+    const u32 old = g.e_start[e];
+    const int b = g.e_first[e];
+    // edge.start.outEdgeIds -= edge.seq(0)            :200
+    if (g.out_edge[(u64)old * 4 + b] == e) { g.out_edge[(u64)old * 4 + b] = NONE; g.out_order[old] = order_remove(g.out_order[old], b); }
+    // newStart.outEdgeIds += edge.seq(0) -> edge.id   :201  (an immutable Map: an existing key keeps its place, its value is replaced)
+    const u32 prev = g.out_edge[(u64)ns * 4 + b];
+    g.out_edge[(u64)ns * 4 + b] = e;
+    if (prev == NONE) g.out_order[ns] = order_append(g.out_order[ns], b);
+    g.e_start[e] = ns;                                  // edges(edge.id) = new Edge(edge.id, newStart.id, ...)  :199
+    *status = 0;
+}
+__global__ void k_replace_end(GraphView g, u32 e, u32 ne, int *status) {
+    if (e >= g.n_edges || !g.e_alive[e] || ne >= g.n_nodes || !g.node_alive[ne]) { *status = 1; return; }
+    const u32 old = g.e_end[e];
+    if (g.in_deg[old]) g.in_deg[old]--;                 // edge.end.inEdgeIds -= edge.id   :207
+    g.in_deg[ne]++;                                     // newEnd.inEdgeIds += edge.id     :208
+    g.e_end[e] = ne;
+    *status = 0;
+}
+__global__ void k_add_node(GraphView g, u32 n, u64 lo, u64 hi) {
+    g.node_lo[n] = lo; g.node_hi[n] = hi;
+    g.node_alive[n] = 1;
+    g.out_order[n] = 0; g.in_deg[n] = 0;
+    for (int b = 0; b < 4; b++) g.out_edge[(u64)n * 4 + b] = NONE;
+}
+__global__ __launch_bounds__(BLOCK) void k_nodes_by_id(GraphView g, const u32 *ids, u64 n, u64 *lo, u64 *hi, uint8_t *alive, u32 *in_deg, u32 *out_deg) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        const u32 v = ids[i];
+        const bool ok = v < g.n_nodes;
+        lo[i] = ok ? g.node_lo[v] : 0; hi[i] = ok ? g.node_hi[v] : 0;
+        alive[i] = ok ? g.node_alive[v] : 0;
+        in_deg[i] = ok ? g.in_deg[v] : 0;
+        out_deg[i] = ok ? (u32)order_count(g.out_order[v]) : 0;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_edges_by_id(GraphView g, const u32 *ids, u64 n, u32 *start, u32 *end, u64 *len, uint8_t *first, uint8_t *alive) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        const u32 e = ids[i];
+        const bool ok = e < g.n_edges;
+        start[i] = ok ? g.e_start[e] : NONE; end[i] = ok ? g.e_end[e] : NONE;
+        len[i] = ok ? g.e_len[e] : 0; first[i] = ok ? g.e_first[e] : 0; alive[i] = ok ? g.e_alive[e] : 0;
+    }
+}
+template <int W> __global__ void k_node_lookup(GraphView g, u64 lo, u64 hi, int base, u32 *out2) {
+    Kmer<W> x;
+    if constexpr (W == 1) x = Kmer<1>{lo};
+    else x = Kmer<2>{lo, hi};
+    // node_find returns the first index entry with this k-mer; after a node split several nodes share a sequence: the live one
+    // with the smallest id is reported
+    u32 best = NONE;
+    u64 i = slot_hash(x) & g.nidx_mask;
+    for (u64 p = 0; p <= g.nidx_mask; p++) {
+        const u32 n = g.nidx[i];
+        if (n == NONE) break;
+        if (g.node_alive[n] && node_kmer<W>(g, n) == x && n < best) best = n;
+        i = (i + 1) & g.nidx_mask;
+    }
+    out2[0] = best;
+    out2[1] = best != NONE && base >= 0 && base < 4 ? g.out_edge[(u64)best * 4 + base] : NONE;
+}
+__global__ void k_nidx_insert(GraphView g, u32 n, u64 h) {
+    u64 i = h & g.nidx_mask;
+    while (atomicCAS(&g.nidx[i], NONE, n) != NONE) i = (i + 1) & g.nidx_mask;
+}
+
 // =============================================================================================
 // host side
 // =============================================================================================
@@ -1570,6 +1729,192 @@ int gk_graph_out_order(gk_graph *g, uint64_t lo, uint64_t hi, int *bases4, int *
     if (e != hipSuccess) return hip_fail(ctx, e, "gk_graph_out_order");
     *count = h[0];
     for (int i = 0; i < 4; i++) bases4[i] = i < h[0] ? h[1 + i] : 0;
+    return GK_OK;
+}
+
+static int graph_grow_nodes(gk_graph *g, u64 new_cap) {
+    gk_ctx *ctx = g->ctx;
+    GraphView &v = g->v;
+    if (new_cap <= g->node_cap) return GK_OK;
+    const u64 old = v.n_nodes;
+    GK_HIP(ctx, dev_grow(&v.node_lo, old, new_cap, ctx->stream));
+    GK_HIP(ctx, dev_grow(&v.node_hi, old, new_cap, ctx->stream));
+    GK_HIP(ctx, dev_grow(&v.node_alive, old, new_cap, ctx->stream));
+    GK_HIP(ctx, dev_grow(&v.out_edge, old * 4, new_cap * 4, ctx->stream));
+    GK_HIP(ctx, dev_grow(&v.out_order, old, new_cap, ctx->stream));
+    GK_HIP(ctx, dev_grow(&v.in_deg, old, new_cap, ctx->stream));
+    GK_HIP(ctx, hipMemsetAsync(v.node_alive + old, 0, new_cap - old, ctx->stream));
+    g->node_cap = new_cap;
+    return GK_OK;
+}
+
+// Graph.getGraphMap (Graph.scala:90-119): putNew of every node k-mer and of every interior k-mer of every edge into `vm`
+int gk_graph_position_map(gk_graph *g, gk_vmap *vm, uint64_t *entries) {
+    if (int rc = check_graph(g)) return rc;
+    gk_ctx *ctx = g->ctx;
+    if (entries) *entries = 0;
+    if (!vm || vmap_ctx(vm) != ctx) return fail(ctx, GK_E_INVALID, "gk_graph_position_map: the value map must live on the graph's context");
+    if (vmap_k(vm) != g->k) return fail(ctx, GK_E_KLEN, "gk_graph_position_map: the map's k differs from the graph's");     // key.length == k
+    GraphView &v = g->v;
+    unsigned long long *first = nullptr, *d_cur = nullptr, h_cur[2] = {0, 0};
+    u64 *lo = nullptr, *hi = nullptr, *val = nullptr;
+    auto done = [&](int code) {
+        for (void *p : {(void *)first, (void *)d_cur, (void *)lo, (void *)hi, (void *)val}) if (p) (void)hipFree(p);
+        return code;
+    };
+    hipError_t e = hipMalloc((void **)&first, std::max<u64>(v.n_edges, 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_cur, 16);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cur, 0, 16, ctx->stream);
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_position_map: alloc"));
+    if (v.n_edges) hipLaunchKernelGGL(k_pos_reserve, dim3(ggrid(ctx, v.n_edges)), dim3(BLOCK), 0, ctx->stream, v, first, &d_cur[0]);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h_cur, d_cur, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_position_map: reserve"));
+    // the reference's own check, printed side by side at :117: size == sum of edge lengths + nodes - edges
+    const u64 total = g->live_nodes + h_cur[0];
+    if (h_cur[0] != g->live_len - g->live_edges) return done(fail(ctx, GK_E_STATE, "gk_graph_position_map: interior k-mer count does not match the graph's counters"));
+    if (total == 0) return done(GK_OK);
+    e = hipMalloc((void **)&lo, total * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&hi, total * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&val, total * 8);
+    if (e == hipSuccess && g->W == 1) e = hipMemsetAsync(hi, 0, total * 8, ctx->stream);
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_position_map: entries"));
+    hipLaunchKernelGGL(k_pos_nodes, dim3(ggrid(ctx, std::max<u64>(v.n_nodes, 1))), dim3(BLOCK), 0, ctx->stream, v, lo, hi, val, &d_cur[1]);
+    if (v.n_edges) {
+        if (g->W == 1) {
+            hipLaunchKernelGGL(k_pos_fill<1>, dim3(ggrid(ctx, v.n_edges)), dim3(BLOCK), 0, ctx->stream, v, g->k, first, g->live_nodes, lo, hi, val);
+            hipLaunchKernelGGL(k_pos_fill_long<1>, dim3((int)std::min<u64>(v.n_edges, (u64)ctx->cu_count * 8)), dim3(BLOCK), 0, ctx->stream, v, g->k, first, g->live_nodes, lo, hi, val);
+        } else {
+            hipLaunchKernelGGL(k_pos_fill<2>, dim3(ggrid(ctx, v.n_edges)), dim3(BLOCK), 0, ctx->stream, v, g->k, first, g->live_nodes, lo, hi, val);
+            hipLaunchKernelGGL(k_pos_fill_long<2>, dim3((int)std::min<u64>(v.n_edges, (u64)ctx->cu_count * 8)), dim3(BLOCK), 0, ctx->stream, v, g->k, first, g->live_nodes, lo, hi, val);
+        }
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_position_map: fill"));
+    if (int rc = vmap_put_new_dev(vm, lo, hi, val, total)) return done(rc);
+    if (entries) *entries = total;
+    return done(GK_OK);
+}
+
+// first live node holding this k-mer (NONE = 0xffffffff if there is none) and, if base is 0..3, its out-edge for that first base
+int gk_graph_node_lookup(gk_graph *g, uint64_t lo, uint64_t hi, int base, uint32_t *node_id, uint32_t *edge_id) {
+    if (int rc = check_graph(g)) return rc;
+    gk_ctx *ctx = g->ctx;
+    u32 *d = nullptr, h[2] = {NONE, NONE};
+    GK_HIP(ctx, hipMalloc((void **)&d, 8));
+    if (g->W == 1) hipLaunchKernelGGL(k_node_lookup<1>, dim3(1), dim3(1), 0, ctx->stream, g->v, lo, hi, base, d);
+    else hipLaunchKernelGGL(k_node_lookup<2>, dim3(1), dim3(1), 0, ctx->stream, g->v, lo, hi, base, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return hip_fail(ctx, e, "gk_graph_node_lookup");
+    if (node_id) *node_id = h[0];
+    if (edge_id) *edge_id = h[1];
+    return GK_OK;
+}
+
+// MapGraph.addNode(seq) (Graph.scala:172-176): a fresh node without edges; several nodes may carry the same sequence
+int gk_graph_add_node(gk_graph *g, uint64_t lo, uint64_t hi, uint32_t *node_id) {
+    if (int rc = check_graph(g)) return rc;
+    gk_ctx *ctx = g->ctx;
+    GraphView &v = g->v;
+    if (g->W == 1 ? ((lo >> (2 * g->k)) != 0 || hi != 0) : (g->k < 64 && (hi >> (2 * (g->k - 32))) != 0))
+        return fail(ctx, GK_E_KLEN, "gk_graph_add_node: not a " + std::to_string(g->k) + "-mer");
+    if (v.n_nodes + 1 >= (u64)NONE) return fail(ctx, GK_E_CAPACITY, "more than 2^32 graph nodes");
+    if (v.n_nodes + 1 > g->node_cap) { if (int rc = graph_grow_nodes(g, std::max<u64>(g->node_cap * 2, 16))) return rc; }
+    const u32 n = (u32)v.n_nodes;
+    hipLaunchKernelGGL(k_add_node, dim3(1), dim3(1), 0, ctx->stream, v, n, lo, hi);
+    v.n_nodes++;
+    g->live_nodes++;
+    if (2 * v.n_nodes > v.nidx_mask) {
+        if (int rc = graph_build_index(g)) return rc;          // the index outgrew its table: rebuild (power of two >= 2 n)
+    } else {
+        const u64 h = g->W == 1 ? slot_hash(Kmer<1>{lo}) : slot_hash(Kmer<2>{lo, hi});
+        hipLaunchKernelGGL(k_nidx_insert, dim3(1), dim3(1), 0, ctx->stream, v, n, h);
+    }
+    GK_HIP(ctx, hipGetLastError());
+    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (node_id) *node_id = n;
+    return GK_OK;
+}
+
+static int graph_point_edit(gk_graph *g, bool start, uint32_t edge_id, uint32_t node_id) {
+    if (int rc = check_graph(g)) return rc;
+    gk_ctx *ctx = g->ctx;
+    int *d = nullptr, h = 1;
+    GK_HIP(ctx, hipMalloc((void **)&d, 4));
+    if (start) hipLaunchKernelGGL(k_replace_start, dim3(1), dim3(1), 0, ctx->stream, g->v, edge_id, node_id, d);
+    else hipLaunchKernelGGL(k_replace_end, dim3(1), dim3(1), 0, ctx->stream, g->v, edge_id, node_id, d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return hip_fail(ctx, e, "graph edit");
+    if (h) return fail(ctx, GK_E_INVALID, std::string(start ? "gk_graph_replace_start" : "gk_graph_replace_end") + ": no such live edge / node");
+    return GK_OK;
+}
+int gk_graph_replace_start(gk_graph *g, uint32_t edge_id, uint32_t new_start_node) { return graph_point_edit(g, true, edge_id, new_start_node); }   // :197-202
+int gk_graph_replace_end(gk_graph *g, uint32_t edge_id, uint32_t new_end_node) { return graph_point_edit(g, false, edge_id, new_end_node); }       // :204-209
+
+int gk_graph_nodes_by_id(gk_graph *g, const uint32_t *ids, uint64_t n, uint64_t *lo, uint64_t *hi, uint8_t *alive, uint32_t *in_deg, uint32_t *out_deg) {
+    if (int rc = check_graph(g)) return rc;
+    gk_ctx *ctx = g->ctx;
+    if (n == 0) return GK_OK;
+    if (!ids || !lo || !hi || !alive || !in_deg || !out_deg) return fail(ctx, GK_E_INVALID, "gk_graph_nodes_by_id: null argument");
+    u32 *d_ids = nullptr, *d_in = nullptr, *d_out = nullptr;
+    u64 *d_lo = nullptr, *d_hi = nullptr;
+    uint8_t *d_al = nullptr;
+    hipError_t e = hipMalloc((void **)&d_ids, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_in, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_lo, n * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_hi, n * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_al, n);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_ids, ids, n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_nodes_by_id, dim3(ggrid(ctx, n)), dim3(BLOCK), 0, ctx->stream, g->v, d_ids, n, d_lo, d_hi, d_al, d_in, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(lo, d_lo, n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hi, d_hi, n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(alive, d_al, n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(in_deg, d_in, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_deg, d_out, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    for (void *p : {(void *)d_ids, (void *)d_in, (void *)d_out, (void *)d_lo, (void *)d_hi, (void *)d_al}) if (p) (void)hipFree(p);
+    if (e != hipSuccess) return hip_fail(ctx, e, "gk_graph_nodes_by_id");
+    return GK_OK;
+}
+
+int gk_graph_edges_by_id(gk_graph *g, const uint32_t *ids, uint64_t n, uint32_t *start_node, uint32_t *end_node, uint64_t *len, uint8_t *first_base, uint8_t *alive) {
+    if (int rc = check_graph(g)) return rc;
+    gk_ctx *ctx = g->ctx;
+    if (n == 0) return GK_OK;
+    if (!ids || !start_node || !end_node || !len || !first_base || !alive) return fail(ctx, GK_E_INVALID, "gk_graph_edges_by_id: null argument");
+    u32 *d_ids = nullptr, *d_s = nullptr, *d_e = nullptr;
+    u64 *d_len = nullptr;
+    uint8_t *d_f = nullptr, *d_al = nullptr;
+    hipError_t e = hipMalloc((void **)&d_ids, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_s, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_e, n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_len, n * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_f, n);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_al, n);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_ids, ids, n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_edges_by_id, dim3(ggrid(ctx, n)), dim3(BLOCK), 0, ctx->stream, g->v, d_ids, n, d_s, d_e, d_len, d_f, d_al);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(start_node, d_s, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(end_node, d_e, n * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(len, d_len, n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(first_base, d_f, n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(alive, d_al, n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    for (void *p : {(void *)d_ids, (void *)d_s, (void *)d_e, (void *)d_len, (void *)d_f, (void *)d_al}) if (p) (void)hipFree(p);
+    if (e != hipSuccess) return hip_fail(ctx, e, "gk_graph_edges_by_id");
     return GK_OK;
 }
 

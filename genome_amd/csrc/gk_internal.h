@@ -130,7 +130,8 @@ int map_reserve(gk_map *m, uint64_t extra_keys);     // grow so that size+extra 
 int map_sync_counters(gk_map *m);                    // refresh m->size, detect device-side error flag
 int map_materialize(gk_map *m);                      // run a deferred clear so that the slots are valid
 int map_add_keys_direct(gk_map *m, const uint64_t *d_keys, uint64_t n);   // k_add_keys on device keys (W words each)
-int map_insert_keys_dev(gk_map *m, const uint64_t *d_keys, uint64_t n, bool verbatim);   // update(key, 1, _+1) for device keys, either path
+int map_insert_keys_dev(gk_map *m, const uint64_t *d_keys, uint64_t n, bool verbatim);
+int map_add_counted_keys_dev(gk_map *m, const uint64_t *d_keys, const int32_t *d_counts, uint64_t n);   // update(key, c, _ + c), canonical device keys   // update(key, 1, _+1) for device keys, either path
 void *map_scratch(gk_map *m, size_t bytes);          // pooled scratch (grown, never shrunk); nullptr + error set on failure
 // partitioned path (part_count may return PART_RETRY_DIRECT: take the direct path for this batch)
 constexpr int PART_RETRY_DIRECT = 1;

@@ -981,6 +981,10 @@ static int add_keys_dev(gk_map *m, const u64 *d_keys, const i32 *d_counts, u64 n
 }  // extern "C"
 namespace gk {
 int map_add_keys_direct(gk_map *m, const uint64_t *d_keys, uint64_t n) { return n ? add_keys_dev(m, d_keys, nullptr, n) : GK_OK; }
+int map_add_counted_keys_dev(gk_map *m, const uint64_t *d_keys, const int32_t *d_counts, uint64_t n) {
+    if (int rc = map_materialize(m)) return rc;
+    return n ? add_keys_dev(m, d_keys, d_counts, n) : GK_OK;
+}
 }
 extern "C" {
 

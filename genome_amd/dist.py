@@ -1,0 +1,90 @@
+"""PartitionedDNAMap[Int] over the GPUs of one node (S/ds/PartitionedDNAMap.scala:15-64), one rank per GPU, behind the
+C-ABI's gk_dist_* entry points (RCCL over xGMI inside the library — no torch on the data path).
+
+The Python side only carries the 128-byte RCCL id from rank 0 to the others (any channel will do: bench.py uses
+torch.distributed's broadcast, a C++ host a file or MPI, the Scala driver its Akka channel)."""
+from __future__ import annotations
+
+import ctypes as C
+import sys
+
+import numpy as np
+
+from . import _lib as L
+from .dnamap import Context, HipDNAMap
+
+
+def unique_id() -> bytes:
+    """rank 0: a fresh RCCL id (128 bytes) to hand to every rank"""
+    buf = C.create_string_buffer(128)
+    L.check(L.lib().gk_dist_unique_id(buf))
+    return buf.raw
+
+
+class HipDist:
+    """One rank of the communicator (gk_dist_create is collective: every rank calls it with the same id)."""
+
+    def __init__(self, ctx: Context, rank: int, world: int, id128: bytes):
+        assert len(id128) == 128
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self.h = L.vp()
+        L.check(L.lib().gk_dist_create(ctx.h, rank, world, C.create_string_buffer(id128, 128), C.byref(self.h)), ctx.h)
+
+    def close(self):
+        if self.h:
+            L.lib().gk_dist_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        if sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def barrier(self):
+        L.check(L.lib().gk_dist_barrier(self.h), self.ctx.h)
+
+    def allreduce(self, values, op: str = "sum") -> np.ndarray:
+        v = np.ascontiguousarray(values, np.float64).copy()
+        L.check(L.lib().gk_dist_allreduce_f64(self.h, v.ctypes.data_as(C.POINTER(C.c_double)), len(v), 1 if op == "max" else 0), self.ctx.h)
+        return v
+
+    def last_ms(self):
+        ms = (C.c_float * 4)()
+        L.check(L.lib().gk_dist_last_ms(self.h, ms), self.ctx.h)
+        return dict(zip(("route", "exchange", "owner_count", "total"), (float(x) for x in ms)))
+
+
+class DistDNAMap:
+    """`PartitionedDNAMap[Int]` with one partition per rank: this object is ONE rank's view (its partition + the communicator)."""
+
+    def __init__(self, dist: HipDist, k: int, capacity_hint: int = 0):
+        self.dist, self.ctx, self.k = dist, dist.ctx, k
+        self.local = HipDNAMap(dist.ctx, k, capacity_hint)
+
+    def close(self):
+        self.local.close()
+
+    def count_reads_dev(self, d_records: int, nreads: int, read_len: int):
+        """FreqFilter.add over this rank's reads -> (windows sent, windows this rank counted as owner)."""
+        sent, owned = C.c_uint64(), C.c_uint64()
+        L.check(L.lib().gk_dist_count_reads_dev(self.dist.h, self.local.h, d_records, nreads, read_len, C.byref(sent), C.byref(owned)), self.ctx.h)
+        return sent.value, owned.value
+
+    def size(self) -> int:                                    # PartitionedDNAMap.scala:31
+        n = C.c_uint64()
+        L.check(L.lib().gk_dist_size(self.dist.h, self.local.h, C.byref(n)), self.ctx.h)
+        return n.value
+
+    def deleteAll_lt(self, rounds: int):                      # :49-51 — local on every rank
+        self.local.deleteAll_lt(rounds)
+
+    def gathered(self) -> HipDNAMap:
+        """every partition's survivors in one table on this rank (what Graph.buildGraph needs)"""
+        h = L.vp()
+        L.check(L.lib().gk_dist_gather_map(self.dist.h, self.local.h, C.byref(h)), self.ctx.h)
+        m = HipDNAMap.__new__(HipDNAMap)
+        m.ctx, m.k, m.h = self.ctx, self.k, h
+        return m

@@ -268,3 +268,105 @@ class HipDNAMap:
         ms, occ = C.c_float(), C.c_uint64()
         L.check(L.lib().gk_map_last_count_kernel(self.h, C.byref(ms), C.byref(occ)), self.ctx.h)
         return ms.value, occ.value
+
+
+POS_EDGE = 1 << 63
+
+
+def pos_node(node_id: int) -> int:
+    """NodeGraphPosition(id) (S/data/graph/GraphPosition.scala) as the map's 64-bit value"""
+    return int(node_id)
+
+
+def pos_edge(edge_id: int, dist: int) -> int:
+    """EdgeGraphPosition(id, dist)"""
+    return POS_EDGE | (int(edge_id) << 32) | int(dist)
+
+
+def pos_decode(v: int):
+    v = int(v)
+    return ("E", (v >> 32) & 0x7fffffff, v & 0xffffffff) if v >> 63 else ("N", v & 0xffffffff, 0)
+
+
+class HipValueMap:
+    """`DNAMap[T]` for a 64-bit T (GraphPosition, Long) with the multimap half of the trait (ArrayDNAMap.scala:49-60):
+    putNew, getAll, update(key, v), apply — over gk_vmap_*."""
+
+    def __init__(self, ctx: Context, k: int, capacity_hint: int = 0):
+        self.ctx, self.k = ctx, k
+        self.h = L.vp()
+        L.check(L.lib().gk_vmap_create(ctx.h, k, capacity_hint, C.byref(self.h)), ctx.h)
+
+    def close(self):
+        if self.h:
+            L.lib().gk_vmap_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        if sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self) -> int:                                   # :50
+        n = C.c_uint64()
+        L.check(L.lib().gk_vmap_size(self.h, C.byref(n)), self.ctx.h)
+        return n.value
+
+    def putNew_batch(self, keys, values):                    # :55
+        lo, hi = _keys(self.k, keys)
+        v = L.as_u64(values)
+        assert len(v) == len(lo)
+        L.check(L.lib().gk_vmap_put_new_batch(self.h, L.ptr(lo, C.c_uint64), L.ptr(hi, C.c_uint64), L.ptr(v, C.c_uint64), len(lo)), self.ctx.h)
+
+    def putNew(self, key, value):
+        self.putNew_batch([key], [value])
+
+    def update_batch(self, keys, values):                    # :53 update(key, v)
+        lo, hi = _keys(self.k, keys)
+        v = L.as_u64(values)
+        assert len(v) == len(lo)
+        L.check(L.lib().gk_vmap_update_batch(self.h, L.ptr(lo, C.c_uint64), L.ptr(hi, C.c_uint64), L.ptr(v, C.c_uint64), len(lo)), self.ctx.h)
+
+    def update(self, key, value):
+        self.update_batch([key], [value])
+
+    def getAll_batch(self, keys):                            # :52, batched -> list of uint64 arrays
+        lo, hi = _keys(self.k, keys)
+        n = len(lo)
+        off = np.zeros(n + 1, np.uint64)
+        tot = C.c_uint64()
+        rc = L.lib().gk_vmap_get_all_batch(self.h, L.ptr(lo, C.c_uint64), L.ptr(hi, C.c_uint64), n, L.ptr(off, C.c_uint64), None, 0, C.byref(tot))
+        if rc not in (L.GK_OK, L.GK_E_CAPACITY):
+            L.check(rc, self.ctx.h)
+        vals = np.zeros(max(tot.value, 1), np.uint64)
+        if tot.value:
+            L.check(L.lib().gk_vmap_get_all_batch(self.h, L.ptr(lo, C.c_uint64), L.ptr(hi, C.c_uint64), n, L.ptr(off, C.c_uint64),
+                                                  L.ptr(vals, C.c_uint64), tot.value, C.byref(tot)), self.ctx.h)
+        return [vals[int(off[i]):int(off[i + 1])] for i in range(n)]
+
+    def getAll(self, key):
+        return self.getAll_batch([key])[0].tolist()
+
+    def apply_batch(self, keys):                             # :51 -> (values, found)
+        lo, hi = _keys(self.k, keys)
+        vals, found = np.zeros(len(lo), np.uint64), np.zeros(len(lo), np.uint8)
+        L.check(L.lib().gk_vmap_get_batch(self.h, L.ptr(lo, C.c_uint64), L.ptr(hi, C.c_uint64), len(lo), L.ptr(vals, C.c_uint64), L.ptr(found, C.c_uint8)), self.ctx.h)
+        return vals, found.astype(bool)
+
+    def apply(self, key):
+        v, f = self.apply_batch([key])
+        return int(v[0]) if f[0] else None
+
+    def contains(self, key) -> bool:
+        return self.apply(key) is not None
+
+    def items(self):
+        n = self.size()
+        lo, hi, val = np.zeros(n, np.uint64), np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        got = C.c_uint64()
+        L.check(L.lib().gk_vmap_export(self.h, L.ptr(lo, C.c_uint64), L.ptr(hi, C.c_uint64), L.ptr(val, C.c_uint64), n, C.byref(got)), self.ctx.h)
+        return lo, hi, val
+

@@ -89,6 +89,54 @@ class HipGraph:
         names = ("classify", "make_nodes", "unitig_measure", "reserve_pool", "unitig_emit", "index_counts")
         return {"phase_ms": {n_: float(x) for n_, x in zip(names, ms)}, "walked_bases": bases.value, "pointer_jumping": bool(pj.value)}
 
+    # ---- GraphSimplifier's tools: the position map, ids, point edits ----------------------------
+    def getGraphMap(self, capacity_hint: int = 0):         # Graph.scala:90-119
+        from .dnamap import HipValueMap
+        n, e, ln = self.counts()
+        vm = HipValueMap(self.ctx, self.k, capacity_hint or (ln + n - e))
+        got = C.c_uint64()
+        L.check(L.lib().gk_graph_position_map(self.h, vm.h, C.byref(got)), self.ctx.h)
+        assert got.value == ln + n - e                       # the reference prints both, :117
+        return vm
+
+    def nodeId(self, kmer: str, base=None):
+        """(node id or None, id of its out-edge starting with `base` or None)"""
+        lo, hi = dna.pack(kmer)
+        a, b = C.c_uint32(), C.c_uint32()
+        L.check(L.lib().gk_graph_node_lookup(self.h, lo, hi, -1 if base is None else dna.BASES.index(base), C.byref(a), C.byref(b)), self.ctx.h)
+        none = 0xffffffff
+        return (None if a.value == none else a.value), (None if b.value == none else b.value)
+
+    def nodesById(self, ids):
+        ids = np.ascontiguousarray(ids, np.uint32)
+        n = len(ids)
+        lo, hi = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        alive, ind, outd = np.zeros(n, np.uint8), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        L.check(L.lib().gk_graph_nodes_by_id(self.h, L.ptr(ids, C.c_uint32), n, L.ptr(lo, C.c_uint64), L.ptr(hi, C.c_uint64), L.ptr(alive, C.c_uint8),
+                                             L.ptr(ind, C.c_uint32), L.ptr(outd, C.c_uint32)), self.ctx.h)
+        return {"lo": lo, "hi": hi, "alive": alive.astype(bool), "in_deg": ind, "out_deg": outd}
+
+    def edgesById(self, ids):
+        ids = np.ascontiguousarray(ids, np.uint32)
+        n = len(ids)
+        s, e = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        ln, first, alive = np.zeros(n, np.uint64), np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        L.check(L.lib().gk_graph_edges_by_id(self.h, L.ptr(ids, C.c_uint32), n, L.ptr(s, C.c_uint32), L.ptr(e, C.c_uint32), L.ptr(ln, C.c_uint64),
+                                             L.ptr(first, C.c_uint8), L.ptr(alive, C.c_uint8)), self.ctx.h)
+        return {"start": s, "end": e, "len": ln, "first": first, "alive": alive.astype(bool)}
+
+    def addNode(self, kmer: str) -> int:                   # Graph.scala:172-176
+        lo, hi = dna.pack(kmer)
+        out = C.c_uint32()
+        L.check(L.lib().gk_graph_add_node(self.h, lo, hi, C.byref(out)), self.ctx.h)
+        return out.value
+
+    def replaceStart(self, edge_id: int, node_id: int):    # :197-202
+        L.check(L.lib().gk_graph_replace_start(self.h, edge_id, node_id), self.ctx.h)
+
+    def replaceEnd(self, edge_id: int, node_id: int):      # :204-209
+        L.check(L.lib().gk_graph_replace_end(self.h, edge_id, node_id), self.ctx.h)
+
     def getNodes(self):
         n = self.counts()[0]
         lo, hi = np.zeros(n, np.uint64), np.zeros(n, np.uint64)

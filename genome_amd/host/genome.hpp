@@ -6,6 +6,7 @@
 //   FreqFilter.extractFilteredKmers       S/data/FreqFilter.scala:25-58     -> genome::FreqFilter::extractFilteredKmers
 //   Graph.buildGraph / trait Graph        S/data/graph/Graph.scala:23-150,269-382 -> genome::Graph
 //   PairedEndData                         S/data/PairedEndData.scala:11-36  -> genome::PairedEndData
+//   PartitionedDNAMap                     S/ds/PartitionedDNAMap.scala:15-64 -> genome::PartitionedDNAMap (one rank per GPU, RCCL)
 //
 // Header-only, C++17, links against libgenome_amd.so.  Errors are exceptions (GkError) carrying the
 // C-ABI status and message; a wrong key length throws KeyLengthError, the analogue of the
@@ -16,6 +17,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <functional>
+#include <map>
 #include <optional>
 #include <ostream>
 #include <stdexcept>
@@ -105,6 +107,8 @@ class DNAMap {
     DNAMap(const DNAMap &) = delete;
     DNAMap &operator=(const DNAMap &) = delete;
     DNAMap(DNAMap &&o) noexcept : ctx_(o.ctx_), k_(o.k_), h_(o.h_) { o.h_ = nullptr; }
+    // adopt a handle the library created (gk_dist_gather_map)
+    DNAMap(Context &ctx, int k, gk_map *adopted) : ctx_(ctx), k_(k), h_(adopted) {}
 
     int k() const { return k_; }
     gk_map *handle() const { return h_; }
@@ -149,6 +153,13 @@ class DNAMap {
         check(gk_map_count_reads(h_, bin, nbytes, nreads, &occ), ctx_.handle());
         return occ;
     }
+    // the table's invariants and an order-independent content checksum (gk_map_verify)
+    struct Verify { uint64_t live, bad, sumCounts, checksum; };
+    Verify verify() const {
+        Verify v{};
+        check(gk_map_verify(h_, &v.live, &v.bad, &v.sumCounts, &v.checksum), ctx_.handle());
+        return v;
+    }
 
   private:
     void requireLen(const DNASeq &key) const {                     // assert(key.length == k)  :182
@@ -157,6 +168,56 @@ class DNAMap {
     Context &ctx_;
     int k_;
     gk_map *h_ = nullptr;
+};
+
+// One rank's view of a PartitionedDNAMap[Int] spread over the GPUs of a node (PartitionedDNAMap.scala:15-64): this rank's
+// partition (an ordinary DNAMap on this rank's device) + the RCCL communicator.  One process per GPU; rank 0 obtains the id
+// with PartitionedDNAMap::uniqueId() and hands it to the others through whatever channel the host program has.
+// Every member that moves data is COLLECTIVE.  Owner of a k-mer = strand-symmetric minimizer hash mod world (gk_owner_of),
+// not `hashCode mod P` (:60-63): the partition function is unobservable in results and keeps x and rc(x) together.
+class PartitionedDNAMap {
+  public:
+    static std::vector<uint8_t> uniqueId() {
+        std::vector<uint8_t> id(128);
+        check(gk_dist_unique_id(id.data()), nullptr);
+        return id;
+    }
+    PartitionedDNAMap(Context &ctx, int k, int rank, int world, const std::vector<uint8_t> &id128, uint64_t capacityHintPerRank = 0)
+        : ctx_(ctx), local_(ctx, k, capacityHintPerRank) {
+        if (id128.size() != 128) throw GkError(GK_E_INVALID, "the RCCL id is 128 bytes");
+        check(gk_dist_create(ctx.handle(), rank, world, id128.data(), &d_), ctx.handle());
+    }
+    ~PartitionedDNAMap() { gk_dist_destroy(d_); }
+    PartitionedDNAMap(const PartitionedDNAMap &) = delete;
+    PartitionedDNAMap &operator=(const PartitionedDNAMap &) = delete;
+
+    int rank() const { return gk_dist_rank(d_); }
+    int world() const { return gk_dist_world(d_); }
+    DNAMap &local() { return local_; }
+    // FreqFilter.add over THIS rank's device-resident reads: update(key, 1, _ + 1) sent to each key's owner (:41-43)
+    std::pair<uint64_t, uint64_t> countReadsDev(const void *devRecords, uint64_t nreads, int readLen) {
+        uint64_t sent = 0, owned = 0;
+        check(gk_dist_count_reads_dev(d_, local_.handle(), devRecords, nreads, readLen, &sent, &owned), ctx_.handle());
+        return {sent, owned};
+    }
+    uint64_t size() {                                              // :31
+        uint64_t n = 0;
+        check(gk_dist_size(d_, local_.handle(), &n), ctx_.handle());
+        return n;
+    }
+    void deleteAll(ValueLessThan p) { local_.deleteAll(p); }      // :49-51 — every partition filters its own keys
+    // every partition's keys in one table on this rank: what Graph.buildGraph needs
+    DNAMap gathered() {
+        gk_map *full = nullptr;
+        check(gk_dist_gather_map(d_, local_.handle(), &full), ctx_.handle());
+        return DNAMap(ctx_, local_.k(), full);
+    }
+    void barrier() { check(gk_dist_barrier(d_), ctx_.handle()); }
+
+  private:
+    Context &ctx_;
+    DNAMap local_;
+    gk_dist *d_ = nullptr;
 };
 
 namespace FreqFilter {
@@ -216,6 +277,19 @@ class Graph {
         uint64_t kept = 0, comps = 0;
         check(gk_graph_retain_largest(h_, &kept, &comps), ctx_.handle());
         return {kept, comps};
+    }
+    // GraphBuilder.scala:41-47: `hist` = components grouped by node count, `hist2` = grouped by the summed length of their
+    // nodes' out-edges; each as value -> number of components, ascending
+    std::pair<std::map<uint64_t, uint64_t>, std::map<uint64_t, uint64_t>> componentHistograms() const {
+        uint64_t n = 0;
+        int rc = gk_graph_component_stats(h_, nullptr, nullptr, 0, &n);
+        if (rc != GK_OK && rc != GK_E_CAPACITY) check(rc, ctx_.handle());
+        std::vector<uint32_t> nodes(n);
+        std::vector<uint64_t> len(n);
+        if (n) check(gk_graph_component_stats(h_, nodes.data(), len.data(), n, &n), ctx_.handle());
+        std::map<uint64_t, uint64_t> h1, h2;
+        for (uint64_t i = 0; i < n; i++) { h1[nodes[i]]++; h2[len[i]]++; }
+        return {h1, h2};
     }
     std::tuple<uint64_t, uint64_t, uint64_t> counts() const {
         uint64_t n = 0, e = 0, l = 0;

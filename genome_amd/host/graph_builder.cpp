@@ -49,16 +49,27 @@ int main(int argc, char **argv) {
         const uint64_t good = kmersFreq.size();                                                          // :34
         auto graph = genome::Graph::buildGraph(k, kmersFreq);                                            // :36
         auto [nodes, edges, totalLen] = graph.counts();                                                  // :39
-        if (simplify) { graph.removeBubbles(); graph.simplifyGraph(); }                                  // GraphSimplifier.scala:317-318
+        // :41-47 the two component histograms, on the graph as built (the reference computes them before retain)
+        auto [hist, hist2] = graph.componentHistograms();
         uint64_t kept = nodes, comps = 0;
         if (retain) std::tie(kept, comps) = graph.retainLargestComponent();                              // :52-54
+        // --simplify = GraphSimplifier.scala:317-318, applied to the graph GraphBuilder hands over (i.e. after retain)
+        if (simplify) { graph.removeBubbles(); graph.simplifyGraph(); }
         auto [n2, e2, l2] = graph.counts();
         std::printf("{\"k\":%d,\"rounds\":%d,\"good_kmers\":%llu,\"graph_nodes\":%llu,\"graph_edges\":%llu,"
                     "\"total_edges_length\":%llu,\"components\":%llu,\"max_component_size\":%llu,"
-                    "\"retained_nodes\":%llu,\"retained_edges\":%llu,\"retained_edges_length\":%llu}\n",
+                    "\"retained_nodes\":%llu,\"retained_edges\":%llu,\"retained_edges_length\":%llu,",
                     k, rounds, (unsigned long long)good, (unsigned long long)nodes, (unsigned long long)edges,
                     (unsigned long long)totalLen, (unsigned long long)comps, (unsigned long long)kept,
                     (unsigned long long)n2, (unsigned long long)e2, (unsigned long long)l2);
+        auto dump = [](const char *name, const std::map<uint64_t, uint64_t> &h, const char *tail) {
+            std::printf("\"%s\":[", name);
+            bool first = true;
+            for (const auto &p : h) { std::printf("%s[%llu,%llu]", first ? "" : ",", (unsigned long long)p.first, (unsigned long long)p.second); first = false; }
+            std::printf("]%s", tail);
+        };
+        dump("components_histogram", hist, ",");          // GraphBuilder.scala:42 "Components histogram"
+        dump("components_histogram_2", hist2, "}\n");     // :47 "Components histogram 2"
         if (!out.empty()) {                                                                              // :56 (Kryo file there)
             std::ofstream nf(out + ".nodes.txt"), ef(out + ".edges.txt");
             for (const auto &n : graph.getNodes()) nf << n.toString() << "\n";

@@ -44,13 +44,15 @@ typedef enum {
     GK_E_HIP = -5,            /* HIP runtime error (message has the hipError string) */
     GK_E_NODEVICE = -6,       /* no usable gfx950 device */
     GK_E_FORMAT = -7,         /* malformed `.bin` read stream */
-    GK_E_STATE = -8           /* operation not valid in the handle's current state */
+    GK_E_STATE = -8,          /* operation not valid in the handle's current state */
+    GK_E_COMM = -9            /* RCCL missing or a collective failed (message has the RCCL error string) */
 } gk_status;
 
 typedef struct gk_ctx gk_ctx;       /* one device + stream; replaces ActorsHome.system (S/scripts/ActorsHome.scala:20-30) */
 typedef struct gk_map gk_map;       /* one ArrayDNAMap[Int] partition, resident in HBM */
 typedef struct gk_graph gk_graph;   /* a MapGraph, resident in HBM */
 typedef struct gk_prefilter gk_prefilter;   /* exact two-pass singleton pre-filter (2-bit counters) */
+typedef struct gk_dist gk_dist;     /* one rank of a PartitionedDNAMap spread over the GPUs of a node (RCCL communicator) */
 
 /* ---- context ---------------------------------------------------------------------------- */
 int gk_device_count(void);                       /* number of HIP devices, 0 if none / no runtime */
@@ -180,6 +182,66 @@ int gk_owner_of(int k, uint64_t lo, uint64_t hi, int P);
 /* *foreign = live keys of partition p's table whose owner (of P) is not p — 0 for a correctly routed PartitionedDNAMap */
 int gk_map_count_foreign(gk_map *m, int P, int p, uint64_t *foreign);
 
+/* ---- DNAMap[T] with values and multimap inserts: the rest of the trait (S/ds/ArrayDNAMap.scala:49-60) -------------- */
+/* A second kind of map, for T = a 64-bit value (GraphPosition, Long): putNew stores a key as often as it is put, getAll
+ * returns every value stored under a key, update(key, v) inserts or overwrites, apply returns the first value in probe order.
+ * Same HBM table layout as gk_map; nothing is deleted from these maps.  Used by gk_graph_position_map (Graph.getGraphMap). */
+typedef struct gk_vmap gk_vmap;
+int gk_vmap_create(gk_ctx *ctx, int k, uint64_t capacity_hint, gk_vmap **out);     /* new PartitionedDNAMap[GraphPosition](k), Graph.scala:92 */
+void gk_vmap_destroy(gk_vmap *m);
+int gk_vmap_k(const gk_vmap *m);
+int gk_vmap_size(gk_vmap *m, uint64_t *n);                                         /* DNAMap.size :50 — entries, duplicates included */
+/* DNAMap.putNew(key, v) (:55; Container.putNew ArrayDNAMap.scala:152-162), batched: no duplicate check — a multimap */
+int gk_vmap_put_new_batch(gk_vmap *m, const uint64_t *lo, const uint64_t *hi, const uint64_t *values, uint64_t n);
+/* DNAMap.update(key, v) (:53; Container.update :115-127), batched: insert, or overwrite the first entry of the key; for a key
+ * that occurs several times in one batch the LAST occurrence wins, as in the reference's sequential loop */
+int gk_vmap_update_batch(gk_vmap *m, const uint64_t *lo, const uint64_t *hi, const uint64_t *values, uint64_t n);
+/* DNAMap.getAll(key) (:52; Container.getAll :103-113), batched, CSR output: the values of key i are
+ * values_out[offsets_out[i] .. offsets_out[i+1]) (offsets_out has n + 1 entries); *total = offsets_out[n].  If values_cap <
+ * *total the offsets are still filled and the call fails with GK_E_CAPACITY.  Order inside a key's run: most recently probed
+ * first, as the reference's list — callers treat it as a set (GraphSimplifier.scala:192-217). */
+int gk_vmap_get_all_batch(gk_vmap *m, const uint64_t *lo, const uint64_t *hi, uint64_t n, uint64_t *offsets_out, uint64_t *values_out,
+                          uint64_t values_cap, uint64_t *total);
+/* DNAMap.apply(key) (:51), batched: first value in probe order; found_out[i] = 0/1 (may be NULL) */
+int gk_vmap_get_batch(gk_vmap *m, const uint64_t *lo, const uint64_t *hi, uint64_t n, uint64_t *values_out, uint8_t *found_out);
+/* Container.iterator: every (key, value), unspecified order */
+int gk_vmap_export(gk_vmap *m, uint64_t *lo, uint64_t *hi, uint64_t *values, uint64_t cap, uint64_t *n);
+
+/* GraphPosition (S/data/graph/GraphPosition.scala) as a 64-bit value: NodeGraphPosition(id) = id;
+ * EdgeGraphPosition(id, dist) = 1<<63 | id<<32 | dist.  Ids are this library's node / edge ids (gk_graph_*_by_id). */
+#define GK_POS_IS_EDGE(v) (((v) >> 63) != 0)
+#define GK_POS_ID(v) ((uint32_t)(GK_POS_IS_EDGE(v) ? (((v) >> 32) & 0x7fffffffu) : ((v) & 0xffffffffu)))
+#define GK_POS_DIST(v) ((uint32_t)((v) & 0xffffffffu))
+
+/* ---- PartitionedDNAMap over N GPUs: one rank (process) per GPU, RCCL over xGMI ---------------- */
+/* Reference: `new PartitionedDNAMap[Int](k)` deploys one ArrayDNAMap actor per storage node and sends one message per k-mer
+ * occurrence to its owner (S/ds/PartitionedDNAMap.scala:20-47).  Here every rank holds ONE partition (a gk_map it created on
+ * its own context), routes the k-mers of ITS reads as super-k-mer records and exchanges them with one all-to-all per call.
+ * Bootstrap: rank 0 calls gk_dist_unique_id and hands the 128 bytes to the other ranks by any means the host has (the JVM
+ * driver's own channel, a file, MPI, torch.distributed in bench.py); every rank then calls gk_dist_create — collectively.
+ * RCCL is loaded on first use (dlopen); without it these calls fail with GK_E_COMM and nothing else is affected.
+ * All gk_dist_* calls that move data are COLLECTIVE: every rank of the communicator must make them, in the same order. */
+int gk_dist_unique_id(void *id128);                                   /* out: 128 bytes */
+int gk_dist_create(gk_ctx *ctx, int rank, int world, const void *id128, gk_dist **out);
+void gk_dist_destroy(gk_dist *d);
+int gk_dist_rank(const gk_dist *d);
+int gk_dist_world(const gk_dist *d);
+int gk_dist_barrier(gk_dist *d);
+/* all-reduce of up to 32 doubles in place (op_max: 0 = sum, 1 = max) — for the host's own bookkeeping (timings, totals) */
+int gk_dist_allreduce_f64(gk_dist *d, double *values, int n, int op_max);
+/* FreqFilter.add over THIS rank's reads, every k-mer counted by its owner rank (PartitionedDNAMap.update, :41-43):
+ * route (gk_shard_superkmers_dev, P = world) -> exchange counts -> exchange records -> gk_map_count_superkmers_dev on `local`.
+ * *occurrences_sent = windows of this rank's reads, *occurrences_owned = windows this rank counted (sums over ranks agree). */
+int gk_dist_count_reads_dev(gk_dist *d, gk_map *local, const void *dev_records, uint64_t nreads, int read_len,
+                            uint64_t *occurrences_sent, uint64_t *occurrences_owned);
+/* wall ms of the last gk_dist_count_reads_dev on this rank: {route, exchange, owner count, total} */
+int gk_dist_last_ms(gk_dist *d, float *ms4);
+int gk_dist_size(gk_dist *d, gk_map *local, uint64_t *total);         /* PartitionedDNAMap.size (:31): sum over the partitions */
+/* deleteAll / filter_lt, stats, export are LOCAL: call gk_map_filter_lt etc. on `local` on every rank (:49-51 scatter, no data moves). */
+/* The whole k-mer set on every rank, for Graph.buildGraph (the unitig walk crosses partitions arbitrarily):
+ * all-gather of every partition's live (key, count), device to device, into a NEW map (*full, caller destroys it). */
+int gk_dist_gather_map(gk_dist *d, gk_map *local, gk_map **full);
+
 /* ---- Graph: S/data/graph/Graph.scala ------------------------------------------------------- */
 /* Graph.buildGraph(k, kmersFreq) (:269-382): degree classification of every live key through
  * `contains` on both strands, one node per terminal k-mer (both strands), one edge per
@@ -207,6 +269,23 @@ int gk_graph_checksum(gk_graph *g, uint64_t *nodes_checksum, uint64_t *edges_che
  * unitig measurement (k_walk pass 0 or pointer jumping), pool reservation, unitig emission, node index + counts} (wall ms,
  * every phase ends in a stream sync); *walked_bases = bases emitted; *pointer_jumping = 1 if k_pj_* built the unitigs. */
 int gk_graph_build_stats(gk_graph *g, float *phase_ms6, uint64_t *walked_bases, int *pointer_jumping);
+/* Graph.getGraphMap (Graph.scala:90-119): putNew of every node's k-mer -> NodeGraphPosition(node id) and of the k-mers at
+ * distance 1 .. len-1 along every edge -> EdgeGraphPosition(edge id, dist) into `vm` (same k, same context).  *entries =
+ * number of entries added = sum of edge lengths + nodes - edges (the reference prints both side by side, :117; here the
+ * equality is checked). */
+int gk_graph_position_map(gk_graph *g, gk_vmap *vm, uint64_t *entries);
+/* Ids.  Node and edge ids are array indices (arbitrary, like the reference's AtomicLong ids; stable for a graph's lifetime).
+ * gk_graph_node_lookup: the live node with this k-mer (smallest id if a node split left several) and, for base in 0..3, the id
+ * of its out-edge whose sequence starts with that base; 0xffffffff = none. */
+int gk_graph_node_lookup(gk_graph *g, uint64_t lo, uint64_t hi, int base, uint32_t *node_id, uint32_t *edge_id);
+int gk_graph_nodes_by_id(gk_graph *g, const uint32_t *ids, uint64_t n, uint64_t *lo, uint64_t *hi, uint8_t *alive, uint32_t *in_deg, uint32_t *out_deg);
+int gk_graph_edges_by_id(gk_graph *g, const uint32_t *ids, uint64_t n, uint32_t *start_node, uint32_t *end_node, uint64_t *len,
+                         uint8_t *first_base, uint8_t *alive);
+/* MapGraph.addNode(seq) (:172-176): a new node without edges (a node split creates nodes that share a sequence) */
+int gk_graph_add_node(gk_graph *g, uint64_t lo, uint64_t hi, uint32_t *node_id);
+/* MapGraph.replaceStart / replaceEnd (:197-209): re-attach one end of an edge to another node */
+int gk_graph_replace_start(gk_graph *g, uint32_t edge_id, uint32_t new_start_node);
+int gk_graph_replace_end(gk_graph *g, uint32_t edge_id, uint32_t new_end_node);
 /* live nodes, unspecified order */
 int gk_graph_export_nodes(gk_graph *g, uint64_t *lo, uint64_t *hi, uint64_t cap, uint64_t *n);
 /* live edges, unspecified order: start/end k-mer, length in bases, and the edge sequence as 2-bit

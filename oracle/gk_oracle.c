@@ -508,6 +508,7 @@ typedef struct {
 
 struct gko_graph {
     int k;
+    int64_t nsorted;       /* nodes[1..nsorted] are in ascending k-mer order (buildGraph's); addNode appends behind them */
     int64_t nnodes, ncap;  /* nodes[1..nnodes] */
     gnode *nodes;
     int64_t nedges, ecap;  /* edges[1..nedges] */
@@ -516,13 +517,19 @@ struct gko_graph {
 };
 
 static int64_t graph_find_node(const gko_graph *g, gko_kmer x) {
-    int64_t lo = 1, hi = g->nnodes;
+    int64_t lo = 1, hi = g->nsorted ? g->nsorted : g->nnodes;
+    const int64_t sorted = hi;
     while (lo <= hi) {
         int64_t mid = (lo + hi) / 2;
         int c = gko_kmer_cmp(g->nodes[mid].seq, x);
-        if (c == 0) return mid;
+        if (c == 0) {
+            if (g->nodes[mid].alive || sorted == g->nnodes) return mid;
+            break;                                         /* dead, and nodes were appended: one of those may carry the sequence */
+        }
         if (c < 0) lo = mid + 1; else hi = mid - 1;
     }
+    for (int64_t i = sorted + 1; i <= g->nnodes; i++)      /* nodes added later (addNode): first live one with this sequence */
+        if (g->nodes[i].alive && gko_kmer_cmp(g->nodes[i].seq, x) == 0) return i;
     return 0;
 }
 
@@ -868,3 +875,93 @@ int gko_graph_degree(const gko_graph *g, gko_kmer node, int *in_deg, int *out_de
     if (out_deg) *out_deg = g->nodes[id].nout;
     return 0;
 }
+
+/* ---- point edits by id and Graph.getGraphMap (GraphSimplifier's tools) ---- */
+int64_t gko_graph_find_node(const gko_graph *g, gko_kmer x) {
+    int64_t id = graph_find_node(g, x);
+    return id && g->nodes[id].alive ? id : 0;
+}
+int64_t gko_graph_find_out_edge(const gko_graph *g, int64_t node, int base) {
+    if (node < 1 || node > g->nnodes || !g->nodes[node].alive) return 0;
+    const gnode *n = &g->nodes[node];
+    for (int i = 0; i < n->nout; i++) if (n->out_base[i] == base) return n->out_edge[i];
+    return 0;
+}
+/* MapGraph.addNode :172-176 */
+int64_t gko_graph_add_node(gko_graph *g, gko_kmer seq) {
+    if (!g->nsorted) g->nsorted = g->nnodes;
+    if (g->nnodes + 2 >= g->ncap) {
+        g->ncap = g->ncap ? g->ncap * 2 : 64;
+        g->nodes = (gnode *)realloc(g->nodes, (size_t)g->ncap * sizeof(gnode));
+    }
+    gnode *n = &g->nodes[++g->nnodes];
+    memset(n, 0, sizeof(*n));
+    n->seq = seq;
+    n->alive = 1;
+    return g->nnodes;
+}
+/* MapGraph.replaceStart :197-202 */
+void gko_graph_replace_start(gko_graph *g, int64_t edge, int64_t new_start) {
+    gedge *e = &g->edges[edge];
+    gnode *s = &g->nodes[e->start];
+    const int b = e->seq[0];
+    for (int i = 0; i < s->nout; i++)                      /* edge.start.outEdgeIds -= edge.seq(0) */
+        if (s->out_base[i] == b) {
+            for (int j = i; j + 1 < s->nout; j++) { s->out_base[j] = s->out_base[j + 1]; s->out_edge[j] = s->out_edge[j + 1]; }
+            s->nout--;
+            break;
+        }
+    gnode *t = &g->nodes[new_start];                       /* newStart.outEdgeIds += edge.seq(0) -> edge.id */
+    int found = 0;
+    for (int i = 0; i < t->nout; i++) if (t->out_base[i] == b) { t->out_edge[i] = edge; found = 1; }
+    if (!found) { t->out_base[t->nout] = b; t->out_edge[t->nout] = edge; t->nout++; }
+    e->start = new_start;                                  /* edges(edge.id) = new Edge(edge.id, newStart.id, ...) */
+}
+/* MapGraph.replaceEnd :204-209 */
+void gko_graph_replace_end(gko_graph *g, int64_t edge, int64_t new_end) {
+    gedge *e = &g->edges[edge];
+    gnode *t = &g->nodes[e->end];
+    for (int i = 0; i < t->nin; i++) if (t->in[i] == edge) { t->in[i] = t->in[t->nin - 1]; t->nin--; break; }
+    gnode *n = &g->nodes[new_end];
+    if (n->nin == n->incap) {
+        n->incap = n->incap ? n->incap * 2 : 4;
+        n->in = (int64_t *)realloc(n->in, (size_t)n->incap * sizeof(int64_t));
+    }
+    n->in[n->nin++] = edge;
+    e->end = new_end;
+}
+/* Graph.getGraphMap :90-119 as the SEQUENCE of its putNew calls: for node in getNodes: (node.seq, NodeGraphPosition(id));
+ * for edge in getEdges: seq = start.seq.drop(1) :+ edge.seq.head; dist = 1; for base in edge.seq.tail: (seq, EdgeGraphPosition(id, dist));
+ * seq = seq.drop(1) :+ base; dist += 1.  Returns the number of calls; fills up to cap. */
+size_t gko_graph_get_graph_map(const gko_graph *g, uint64_t *lo, uint64_t *hi, uint8_t *is_edge, int64_t *id, int32_t *dist, size_t cap) {
+    size_t n = 0;
+    for (int64_t i = 1; i <= g->nnodes; i++) {
+        if (!g->nodes[i].alive) continue;
+        if (n < cap) { lo[n] = g->nodes[i].seq.lo; hi[n] = g->nodes[i].seq.hi; is_edge[n] = 0; id[n] = i; dist[n] = 0; }
+        n++;
+    }
+    for (int64_t e = 1; e <= g->nedges; e++) {
+        const gedge *ed = &g->edges[e];
+        if (!ed->alive) continue;
+        gko_kmer seq = gko_append(g->nodes[ed->start].seq, ed->seq[0], g->k);
+        int32_t d = 1;
+        for (int64_t j = 1; j < ed->len; j++) {
+            if (n < cap) { lo[n] = seq.lo; hi[n] = seq.hi; is_edge[n] = 1; id[n] = e; dist[n] = d; }
+            n++;
+            seq = gko_append(seq, ed->seq[j], g->k);
+            d++;
+        }
+    }
+    return n;
+}
+gko_kmer gko_graph_node_seq(const gko_graph *g, int64_t id) { return g->nodes[id].seq; }
+int gko_graph_edge_info(const gko_graph *g, int64_t id, int64_t *start, int64_t *end, int64_t *len, int *first) {
+    if (id < 1 || id > g->nedges) return 0;
+    const gedge *e = &g->edges[id];
+    if (start) *start = e->start;
+    if (end) *end = e->end;
+    if (len) *len = e->len;
+    if (first) *first = e->seq[0];
+    return e->alive;
+}
+

@@ -121,6 +121,17 @@ int gko_graph_out_order(const gko_graph *g, gko_kmer node, int *bases4);
 /* per-node degree for invariant checks; returns -1 if node unknown */
 int gko_graph_degree(const gko_graph *g, gko_kmer node, int *in_deg, int *out_deg);
 
+/* ---- ids, point edits, Graph.getGraphMap (what GraphSimplifier.scala:188-316 uses) ---- */
+int64_t gko_graph_find_node(const gko_graph *g, gko_kmer x);            /* first live node with this sequence, 0 if none */
+int64_t gko_graph_find_out_edge(const gko_graph *g, int64_t node, int base);
+int64_t gko_graph_add_node(gko_graph *g, gko_kmer seq);                 /* MapGraph.addNode      Graph.scala:172-176 */
+void gko_graph_replace_start(gko_graph *g, int64_t edge, int64_t new_start);  /* :197-202 */
+void gko_graph_replace_end(gko_graph *g, int64_t edge, int64_t new_end);      /* :204-209 */
+/* Graph.getGraphMap (:90-119) as the sequence of its putNew calls (key, NodeGraphPosition(id) | EdgeGraphPosition(id, dist)) */
+size_t gko_graph_get_graph_map(const gko_graph *g, uint64_t *lo, uint64_t *hi, uint8_t *is_edge, int64_t *id, int32_t *dist, size_t cap);
+gko_kmer gko_graph_node_seq(const gko_graph *g, int64_t id);
+int gko_graph_edge_info(const gko_graph *g, int64_t id, int64_t *start, int64_t *end, int64_t *len, int *first);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,14 @@ def lib():
                                                 u8p, C.c_size_t, C.POINTER(C.c_size_t)]),
         "gko_graph_out_order": (C.c_int, [vp, Kmer, C.POINTER(C.c_int)]),
         "gko_graph_degree": (C.c_int, [vp, Kmer, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "gko_graph_find_node": (C.c_int64, [vp, Kmer]),
+        "gko_graph_find_out_edge": (C.c_int64, [vp, C.c_int64, C.c_int]),
+        "gko_graph_add_node": (C.c_int64, [vp, Kmer]),
+        "gko_graph_replace_start": (None, [vp, C.c_int64, C.c_int64]),
+        "gko_graph_replace_end": (None, [vp, C.c_int64, C.c_int64]),
+        "gko_graph_get_graph_map": (C.c_size_t, [vp, u64p, u64p, u8p, i64p, i32p, C.c_size_t]),
+        "gko_graph_node_seq": (Kmer, [vp, C.c_int64]),
+        "gko_graph_edge_info": (C.c_int, [vp, C.c_int64, i64p, i64p, i64p, C.POINTER(C.c_int)]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -254,6 +262,39 @@ class Graph:
         arr = (C.c_int * 4)()
         n = lib().gko_graph_out_order(self.h, km(lo, hi), arr)
         return None if n < 0 else [arr[i] for i in range(n)]
+
+    # ---- ids, point edits, Graph.getGraphMap
+    def find_node(self, lo, hi=0) -> int:
+        return lib().gko_graph_find_node(self.h, km(lo, hi))
+
+    def find_out_edge(self, node: int, base: int) -> int:
+        return lib().gko_graph_find_out_edge(self.h, node, base)
+
+    def add_node(self, lo, hi=0) -> int:
+        return lib().gko_graph_add_node(self.h, km(lo, hi))
+
+    def replace_start(self, edge: int, node: int):
+        lib().gko_graph_replace_start(self.h, edge, node)
+
+    def replace_end(self, edge: int, node: int):
+        lib().gko_graph_replace_end(self.h, edge, node)
+
+    def node_seq(self, node: int):
+        r = lib().gko_graph_node_seq(self.h, node)
+        return r.lo, r.hi
+
+    def edge_info(self, edge: int):
+        s, e, ln, f = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
+        alive = lib().gko_graph_edge_info(self.h, edge, C.byref(s), C.byref(e), C.byref(ln), C.byref(f))
+        return {"start": s.value, "end": e.value, "len": ln.value, "first": f.value, "alive": bool(alive)}
+
+    def graph_map_calls(self):
+        """Graph.getGraphMap as its putNew sequence: arrays (lo, hi, is_edge, id, dist)."""
+        n = lib().gko_graph_get_graph_map(self.h, None, None, None, None, None, 0)
+        lo, hi = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+        ie, ident, dist = np.zeros(n, np.uint8), np.zeros(n, np.int64), np.zeros(n, np.int32)
+        lib().gko_graph_get_graph_map(self.h, _p(lo, C.c_uint64), _p(hi, C.c_uint64), _p(ie, C.c_uint8), _p(ident, C.c_int64), _p(dist, C.c_int32), n)
+        return lo, hi, ie, ident, dist
 
     def degree(self, lo, hi=0):
         i, o = C.c_int(0), C.c_int(0)

@@ -83,3 +83,8 @@ print(json.dumps({"reads": n, "genome": G, "err": err, "resident": resident, "oc
                   "count_kernel_ms": kernel_ms, "count_phases_ms": [round(float(x), 3) for x in phases],
                   "occ_per_s_count": occ / t["count_s"], "graph_built": c0, "build_stats": bstats, "after_bubbles": c1, "after_simplify": c2,
                   "components": comps, "largest": c3, "times": {k_: round(v, 4) for k_, v in t.items()}}))
+# release everything explicitly: a profiler attached to this process waits for the streams to go away
+g.close(); m.close()
+if pf:
+    pf.close()
+ctx.free(d); ctx.close()

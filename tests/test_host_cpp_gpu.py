@@ -75,6 +75,11 @@ def test_graph_builder_cli_retain_and_errors(exe, tmp_path):
     ref.count_reads(binb, fx["nreads"]); ref.delete_lt(2)
     og = O.Graph(ref)
     assert stats["components"] == og.num_components()
+    # GraphBuilder.scala:41-47: components by node count / by summed out-edge length (computed before retain)
+    h1, h2 = stats["components_histogram"], stats["components_histogram_2"]
+    assert sum(c for _, c in h1) == sum(c for _, c in h2) == og.num_components()
+    assert sum(v * c for v, c in h1) == og.num_nodes() and sum(v * c for v, c in h2) == og.total_edge_len()
+    assert h1 == sorted(h1) and h2 == sorted(h2)
     assert stats["max_component_size"] == og.retain_largest() == stats["retained_nodes"]
     nlo, nhi = og.nodes()
     assert open(str(tmp_path / "r") + ".nodes.txt").read().split() == [dna.unpack(int(a), int(b), 11) for a, b in zip(nlo, nhi)]
