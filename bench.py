@@ -198,6 +198,7 @@ def main():
     ap.add_argument("--sharded", action="store_true", help="run the N>1 code path (owner bucketing + all-to-all + owner insert) "
                     "even with one rank: the only way to exercise it on a 1-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="gk_ctx_set_option name=value (A/B switches of the insert pipeline)")
     ap.add_argument("--no-extras", action="store_true", help="skip the objects measured next to the headline at N=1: mode_G, pcie_inclusive, c3")
     args = ap.parse_args()
 
@@ -219,6 +220,9 @@ def main():
     nk = L - k + 1
     stride = synth.record_stride(L)
     ctx = Context(local_rank)
+    for kv in args.opt:
+        name, val = kv.split("=")
+        ctx.set_option(name, int(val))
     rec = ctx.alloc(n * stride + 64)
     G, err = 5_000_000 * world, 0.01
     ctx.synth_reads(rec, n, L, args.mode, 2, rank * n, G, err)     # config_id 2 = C2

@@ -66,6 +66,7 @@ struct gk_graph {
     gk_ctx *ctx = nullptr;
     int k = 0, W = 1;
     GraphView v{};
+    void *node_blob = nullptr, *edge_blob = nullptr;      // the node / edge arrays of `v` are carved out of these two allocations
     u64 node_cap = 0, edge_cap = 0, pool_cap = 0, pool_used = 0;
     u64 live_nodes = 0, live_edges = 0, live_len = 0;
     // wall time of the phases of gk_graph_build (every phase ends in a stream sync): classify, terminals -> nodes + edge
@@ -203,30 +204,41 @@ __global__ __launch_bounds__(BLOCK) void k_classify(Table<W> t, int k, unsigned 
     if (threadIdx.x == 0 && s_cnt) atomicAdd(n_term, (unsigned long long)s_cnt);
 }
 
+// The terminal slots, compacted.  One workgroup takes 16 slots per thread at a time and reserves its output with ONE atomic:
+// the cursor is a single address, and same-address atomics retire at ~88 per microsecond chip-wide — one per 256 slots
+// (1.25e6 of them over C3's 3.2e8-slot table) was 15 of this kernel's 16 ms.
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_collect_terminals(Table<W> t, int k, u64 *tslots, unsigned long long *cursor,
                                                              unsigned long long *n_edges) {
+    constexpr int PER = 16;
     __shared__ u32 lds4[BLOCK / 64];
     __shared__ unsigned long long s_base;
     __shared__ u32 s_edges;
     if (threadIdx.x == 0) s_edges = 0;
     const u64 ncap = t.capacity();
-    const u64 ngroups = (ncap + BLOCK - 1) / BLOCK;
+    const u64 ngroups = (ncap + (u64)BLOCK * PER - 1) / ((u64)BLOCK * PER);
     u32 edges = 0;
     for (u64 g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        u64 i = g * BLOCK + threadIdx.x;
-        bool sel = false;
-        if (i < ncap && slot_live(&t.slots[i])) {
-            u32 aux = t.slots[i].aux;
-            sel = (aux & AUX_TERMINAL) && !(aux & AUX_SECONDARY);
-            if (sel) {
-                // out(y) + out(rc y) = popc(out) + popc(in); a palindrome (y == rc y, even k) is ONE node
-                Kmer<W> y = slot_key(t.slots, i, t.tagged);
-                edges += (y == revcomp(y, k)) ? __popc((aux >> 4) & 15u) : __popc(aux & 0xffu);
+        // thread j takes slots j, j + BLOCK, ... of the group: coalesced loads
+        const u64 i0 = g * BLOCK * PER + threadIdx.x;
+        u32 selmask = 0;
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const u64 i = i0 + (u64)q * BLOCK;
+            if (i < ncap && slot_live(&t.slots[i])) {
+                const u32 aux = t.slots[i].aux;
+                if ((aux & AUX_TERMINAL) && !(aux & AUX_SECONDARY)) {
+                    selmask |= 1u << q;
+                    // out(y) + out(rc y) = popc(out) + popc(in); a palindrome (y == rc y, even k) is ONE node
+                    const Kmer<W> y = slot_key(t.slots, i, t.tagged);
+                    edges += (y == revcomp(y, k)) ? __popc((aux >> 4) & 15u) : __popc(aux & 0xffu);
+                }
             }
         }
-        u64 o = block_reserve(sel ? 1u : 0u, cursor, lds4, &s_base);
-        if (sel) tslots[o] = i;
+        u64 o = block_reserve((u32)__popc(selmask), cursor, lds4, &s_base);
+#pragma unroll
+        for (int q = 0; q < PER; q++)
+            if (selmask & (1u << q)) tslots[o++] = i0 + (u64)q * BLOCK;
     }
     if (edges) atomicAdd(&s_edges, edges);
     __syncthreads();
@@ -1094,11 +1106,48 @@ template <class T> static hipError_t dev_grow(T **p, u64 old_n, u64 new_n, hipSt
     return e;
 }
 
+// Node and edge arrays live in ONE allocation each (hipMalloc costs ~1 ms apiece at these sizes: twelve of them were 10 % of
+// gk_graph_build at C3); the view's pointers are carved out of the blobs, 256-byte aligned.
+static size_t al256g(size_t v) { return (v + 255) & ~(size_t)255; }
+struct NodeCarve { size_t lo, hi, alive, out_edge, out_order, in_deg, total; };
+struct EdgeCarve { size_t start, end, len, off, alive, first, total; };
+static NodeCarve node_carve(u64 c) {
+    NodeCarve k{};
+    size_t o = 0;
+    k.lo = o; o += al256g(c * 8);
+    k.hi = o; o += al256g(c * 8);
+    k.out_edge = o; o += al256g(c * 16);
+    k.out_order = o; o += al256g(c * 4);
+    k.in_deg = o; o += al256g(c * 4);
+    k.alive = o; o += al256g(c);
+    k.total = o;
+    return k;
+}
+static EdgeCarve edge_carve(u64 c) {
+    EdgeCarve k{};
+    size_t o = 0;
+    k.len = o; o += al256g(c * 8);
+    k.off = o; o += al256g(c * 8);
+    k.start = o; o += al256g(c * 4);
+    k.end = o; o += al256g(c * 4);
+    k.alive = o; o += al256g(c);
+    k.first = o; o += al256g(c);
+    k.total = o;
+    return k;
+}
+static void node_view(GraphView &v, char *blob, const NodeCarve &k) {
+    v.node_lo = (u64 *)(blob + k.lo); v.node_hi = (u64 *)(blob + k.hi); v.node_alive = (uint8_t *)(blob + k.alive);
+    v.out_edge = (u32 *)(blob + k.out_edge); v.out_order = (u32 *)(blob + k.out_order); v.in_deg = (u32 *)(blob + k.in_deg);
+}
+static void edge_view(GraphView &v, char *blob, const EdgeCarve &k) {
+    v.e_start = (u32 *)(blob + k.start); v.e_end = (u32 *)(blob + k.end); v.e_len = (u64 *)(blob + k.len); v.e_off = (u64 *)(blob + k.off);
+    v.e_alive = (uint8_t *)(blob + k.alive); v.e_first = (uint8_t *)(blob + k.first);
+}
+
 static void graph_free_arrays(gk_graph *g) {
     GraphView &v = g->v;
-    void *ptrs[] = {v.node_lo, v.node_hi, v.node_alive, v.out_edge, v.out_order, v.in_deg, v.e_start, v.e_end,
-                    v.e_len, v.e_off, v.e_alive, v.e_first, v.pool, v.nidx};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *p : {g->node_blob, g->edge_blob, (void *)v.pool, (void *)v.nidx}) if (p) (void)hipFree(p);
+    g->node_blob = g->edge_blob = nullptr;
     v = GraphView{};
 }
 
@@ -1106,16 +1155,12 @@ static int graph_alloc_nodes(gk_graph *g, u64 n) {
     gk_ctx *ctx = g->ctx;
     GraphView &v = g->v;
     const u64 c = std::max<u64>(n, 1);
-    GK_HIP(ctx, hipMalloc((void **)&v.node_lo, c * 8));
-    GK_HIP(ctx, hipMalloc((void **)&v.node_hi, c * 8));
-    GK_HIP(ctx, hipMalloc((void **)&v.node_alive, c));
-    GK_HIP(ctx, hipMalloc((void **)&v.out_edge, c * 16));
-    GK_HIP(ctx, hipMalloc((void **)&v.out_order, c * 4));
-    GK_HIP(ctx, hipMalloc((void **)&v.in_deg, c * 4));
-    GK_HIP(ctx, hipMemsetAsync(v.node_alive, 0, c, ctx->stream));
-    GK_HIP(ctx, hipMemsetAsync(v.in_deg, 0, c * 4, ctx->stream));
-    GK_HIP(ctx, hipMemsetAsync(v.out_order, 0, c * 4, ctx->stream));
+    const NodeCarve k = node_carve(c);
+    GK_HIP(ctx, hipMalloc(&g->node_blob, k.total));
+    node_view(v, (char *)g->node_blob, k);
+    // out_edge <- NONE (0xff..), out_order / in_deg / alive <- 0: two memsets over the two contiguous stretches
     GK_HIP(ctx, hipMemsetAsync(v.out_edge, 0xff, c * 16, ctx->stream));
+    GK_HIP(ctx, hipMemsetAsync((char *)g->node_blob + k.out_order, 0, k.total - k.out_order, ctx->stream));
     v.n_nodes = n;
     g->node_cap = c;
     return GK_OK;
@@ -1124,12 +1169,9 @@ static int graph_alloc_edges(gk_graph *g, u64 n) {
     gk_ctx *ctx = g->ctx;
     GraphView &v = g->v;
     const u64 c = std::max<u64>(n, 1);
-    GK_HIP(ctx, hipMalloc((void **)&v.e_start, c * 4));
-    GK_HIP(ctx, hipMalloc((void **)&v.e_end, c * 4));
-    GK_HIP(ctx, hipMalloc((void **)&v.e_len, c * 8));
-    GK_HIP(ctx, hipMalloc((void **)&v.e_off, c * 8));
-    GK_HIP(ctx, hipMalloc((void **)&v.e_alive, c));
-    GK_HIP(ctx, hipMalloc((void **)&v.e_first, c));
+    const EdgeCarve k = edge_carve(c);
+    GK_HIP(ctx, hipMalloc(&g->edge_blob, k.total));
+    edge_view(v, (char *)g->edge_blob, k);
     GK_HIP(ctx, hipMemsetAsync(v.e_alive, 0, c, ctx->stream));
     v.n_edges = n;
     g->edge_cap = c;
@@ -1140,13 +1182,25 @@ static int graph_grow_edges(gk_graph *g, u64 new_n) {
     GraphView &v = g->v;
     if (new_n <= g->edge_cap) { return GK_OK; }
     const u64 old = v.n_edges;
-    GK_HIP(ctx, dev_grow(&v.e_start, old, new_n, ctx->stream));
-    GK_HIP(ctx, dev_grow(&v.e_end, old, new_n, ctx->stream));
-    GK_HIP(ctx, dev_grow(&v.e_len, old, new_n, ctx->stream));
-    GK_HIP(ctx, dev_grow(&v.e_off, old, new_n, ctx->stream));
-    GK_HIP(ctx, dev_grow(&v.e_alive, old, new_n, ctx->stream));
-    GK_HIP(ctx, dev_grow(&v.e_first, old, new_n, ctx->stream));
-    GK_HIP(ctx, hipMemsetAsync(v.e_alive + old, 0, new_n - old, ctx->stream));
+    const EdgeCarve k = edge_carve(new_n);
+    void *blob = nullptr;
+    GK_HIP(ctx, hipMalloc(&blob, k.total));
+    GraphView nv = v;
+    edge_view(nv, (char *)blob, k);
+    hipError_t e = hipMemsetAsync(nv.e_alive, 0, new_n, ctx->stream);
+    if (e == hipSuccess && old) {
+        e = hipMemcpyAsync(nv.e_start, v.e_start, old * 4, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(nv.e_end, v.e_end, old * 4, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(nv.e_len, v.e_len, old * 8, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(nv.e_off, v.e_off, old * 8, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(nv.e_alive, v.e_alive, old, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(nv.e_first, v.e_first, old, hipMemcpyDeviceToDevice, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(blob); return hip_fail(ctx, e, "graph: growing the edge arrays"); }
+    (void)hipFree(g->edge_blob);
+    g->edge_blob = blob;
+    v = nv;
     g->edge_cap = new_n;
     return GK_OK;
 }
@@ -1229,7 +1283,7 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
     if (e == hipSuccess) e = hipMalloc((void **)&slot_node, m->capacity * 4);
     if (e == hipSuccess) e = hipMemsetAsync(slot_node, 0xff, m->capacity * 4, ctx->stream);
     if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: alloc nodes"));
-    hipLaunchKernelGGL(k_collect_terminals<W>, dim3(ggrid(ctx, m->capacity)), dim3(BLOCK), 0, ctx->stream, t, k, tslots, &d_cnt[1], &d_cnt[2]);
+    hipLaunchKernelGGL(k_collect_terminals<W>, dim3(ggrid(ctx, m->capacity / 16 + 1)), dim3(BLOCK), 0, ctx->stream, t, k, tslots, &d_cnt[1], &d_cnt[2]);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 24, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1737,13 +1791,25 @@ static int graph_grow_nodes(gk_graph *g, u64 new_cap) {
     GraphView &v = g->v;
     if (new_cap <= g->node_cap) return GK_OK;
     const u64 old = v.n_nodes;
-    GK_HIP(ctx, dev_grow(&v.node_lo, old, new_cap, ctx->stream));
-    GK_HIP(ctx, dev_grow(&v.node_hi, old, new_cap, ctx->stream));
-    GK_HIP(ctx, dev_grow(&v.node_alive, old, new_cap, ctx->stream));
-    GK_HIP(ctx, dev_grow(&v.out_edge, old * 4, new_cap * 4, ctx->stream));
-    GK_HIP(ctx, dev_grow(&v.out_order, old, new_cap, ctx->stream));
-    GK_HIP(ctx, dev_grow(&v.in_deg, old, new_cap, ctx->stream));
-    GK_HIP(ctx, hipMemsetAsync(v.node_alive + old, 0, new_cap - old, ctx->stream));
+    const NodeCarve k = node_carve(new_cap);
+    void *blob = nullptr;
+    GK_HIP(ctx, hipMalloc(&blob, k.total));
+    GraphView nv = v;
+    node_view(nv, (char *)blob, k);
+    hipError_t e = hipMemsetAsync(nv.node_alive, 0, new_cap, ctx->stream);
+    if (e == hipSuccess && old) {
+        e = hipMemcpyAsync(nv.node_lo, v.node_lo, old * 8, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(nv.node_hi, v.node_hi, old * 8, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(nv.node_alive, v.node_alive, old, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(nv.out_edge, v.out_edge, old * 16, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(nv.out_order, v.out_order, old * 4, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(nv.in_deg, v.in_deg, old * 4, hipMemcpyDeviceToDevice, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(blob); return hip_fail(ctx, e, "graph: growing the node arrays"); }
+    (void)hipFree(g->node_blob);
+    g->node_blob = blob;
+    v = nv;
     g->node_cap = new_cap;
     return GK_OK;
 }

@@ -23,6 +23,7 @@ struct gk_ctx {
     bool hook_no_reserve = false, hook_host_ragged = false, hook_part_exact = false;
     int hook_unitigs = 0;            // 0 auto, 1 walk, 2 pointer jumping
     int hook_p4_direct = -1;         // exact fine level: -1 auto (by nb2), 0 chunk sorted in LDS, 1 straight scatter with per-range cursors
+    int hook_p2_wide = -1;           // over-provisioned L1 scatter: 1 = 1024 threads per tile (A/B)
     int hook_p4_wide = -1;           // exact fine level, 8-byte keys: -1 auto (by nb2), 0 sort 4096 keys at a time, 1 sort 8192 (1024 threads)
     int hook_fine_exact = -1;        // -1 auto, 0 never unless forced by the data path, 1 always (A/B of the two fine levels)
     std::string err;
@@ -44,6 +45,10 @@ struct ReadSrc {
     // the upload of sub-chunk j+1 overlaps the L1 scatter (P2) of sub-chunk j; everything else in one piece (stage_source).
     const uint8_t *host = nullptr;
     size_t host_bytes = 0;
+    // the host did NOT walk this chunk's framing: it only saw that the byte count fits nreads records of the first record's
+    // length.  The L1 scatter then checks every length byte for equality, and a mismatch gives the chunk back (PART_NOT_UNIFORM)
+    // before anything but scratch has been touched.
+    bool verify_uniform = false;
 };
 int stage_source(gk_ctx *ctx, const ReadSrc &src);      // upload a host-fed source in one piece, stream-ordered on ctx->stream
 }
@@ -135,6 +140,7 @@ int map_add_counted_keys_dev(gk_map *m, const uint64_t *d_keys, const int32_t *d
 void *map_scratch(gk_map *m, size_t bytes);          // pooled scratch (grown, never shrunk); nullptr + error set on failure
 // partitioned path (part_count may return PART_RETRY_DIRECT: take the direct path for this batch)
 constexpr int PART_RETRY_DIRECT = 1;
+constexpr int PART_NOT_UNIFORM = 2;      // ReadSrc::verify_uniform failed: walk the framing on the host and come again
 // estimate: keep the distinct-key sample and wait for it between the two partition levels — the table is then sized for the
 // batch's NEW DISTINCT keys (and may be replaced, same lnb1) instead of having been sized for its windows up front;
 // fine_exact: take the exact (range-matrix) fine level even where over-provisioned segment regions could be tried

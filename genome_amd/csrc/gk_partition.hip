@@ -104,7 +104,8 @@ struct PartArrays {
     int op1, op2;
     unsigned long long cap1, cap2;  // keys per L1 region / per segment region
     u32 stripe_nb1;                 // op1: number of L1 regions interleaved in bufA (see l1_slot)
-    u32 range_chunks;               // chunks per range (exact fine level)
+    u32 range_chunks;               // TILE2-key chunks per range (exact fine level)
+    u32 chunk_keys;                 // keys per chunk of the over-provisioned fine level's P4 (TILE2, or 2 x TILE2 with 1024 threads)
     u64 *spill;                     // [spill_cap * W]
     unsigned long long *nspill;
     unsigned long long spill_cap;
@@ -398,9 +399,9 @@ __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_keys(const u64 *__rest
 static constexpr int OP_CAP = GK_OP_CAP;    // LDS key buffer, in 64-bit words (5632: 2 workgroups per CU)
 static constexpr int OP_TILE_READS = 128;
 static constexpr int OP_TILE_WORDS = OP_TILE_READS * 65 / 4 + 64;
-template <int W>
-__global__ __launch_bounds__(PBLOCK) void k_op_scatter1_reads(const uint8_t *__restrict__ rec, u64 nreads, u32 stride, int k, int group,
-                                                              int rs /* reads per tile */, int max_len, Table<W> t, PartArrays a,
+template <int W, int NT>
+__global__ __launch_bounds__(NT) void k_op_scatter1_reads(const uint8_t *__restrict__ rec, u64 nreads, u32 stride, int k, int group,
+                                                              int rs /* reads per tile */, int max_len, int exact_len, Table<W> t, PartArrays a,
                                                               Sampler sp, Counters *ctr, u64 *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) u32 tile[OP_TILE_WORDS];
     __shared__ u64 flat[OP_CAP];
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(PBLOCK) void k_op_scatter1_reads(const uint8_t *__r
     u32 occ = 0, claims = 0;
     const int nk_max = max_len - k + 1;         // the host sized rs so that rs * nk_max keys fit `flat`; lengths are clamped to max_len
     const u64 ntiles = (nreads + rs - 1) / rs;
-    const WindowLimits wl{max_len, &ctr->format};
+    const WindowLimits wl{max_len, &ctr->format, exact_len};
     GK_T0();
     for (u64 tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const u64 r0 = tl * rs;
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(PBLOCK) void k_op_scatter1_reads(const uint8_t *__r
         __syncthreads();
         GK_TICK(5);
         if (threadIdx.x < 256) { hist[threadIdx.x] = 0; rank[threadIdx.x] = 0; }
-        for (u32 i = threadIdx.x; i < nflat; i += PBLOCK) fbin[i] = 0xffff;
+        for (u32 i = threadIdx.x; i < nflat; i += NT) fbin[i] = 0xffff;
         const u64 a0 = stage_tile(tile, rec, r0 * stride, (r0 + nr) * stride);
         __syncthreads();
         GK_TICK(0);
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(PBLOCK) void k_op_scatter1_reads(const uint8_t *__r
         }
         __syncthreads();
         GK_TICK(3);
-        for (u32 i = threadIdx.x; i < nflat; i += PBLOCK) {
+        for (u32 i = threadIdx.x; i < nflat; i += NT) {
             const u32 b = fbin[i];
             if (b == 0xffff) continue;
             const u32 j = atomicAdd(&rank[b], 1u);
@@ -470,8 +471,8 @@ __global__ __launch_bounds__(256) void k_part_prefix1(PartArrays a, u32 nb1) {
     __shared__ unsigned long long s[256], c[256], r[256];
     const u32 i = threadIdx.x;
     s[i] = i < nb1 ? (a.op1 ? min(a.cursor1[i], a.cap1) : a.hist1[i]) : 0;
-    c[i] = (s[i] + TILE2 - 1) / TILE2;
-    r[i] = (c[i] + a.range_chunks - 1) / a.range_chunks;
+    c[i] = (s[i] + a.chunk_keys - 1) / a.chunk_keys;                                  // P4's unit of work (over-provisioned fine level)
+    r[i] = ((s[i] + TILE2 - 1) / TILE2 + a.range_chunks - 1) / a.range_chunks;        // ranges of range_chunks x TILE2 keys (exact fine level)
     __syncthreads();
     if (i == 0) {
         unsigned long long acc = 0, cacc = 0, racc = 0;
@@ -624,8 +625,8 @@ __global__ __launch_bounds__(NT) void k_part_scatter2(const u64 *__restrict__ bu
     } else {
         for (u64 c = blockIdx.x; c < total; c += gridDim.x) {
             const u32 b1 = chunk_bucket(s_ubase, c);
-            const u64 begin = (c - s_ubase[b1]) * TILE2;
-            const u32 cnt = (u32)min((u64)TILE2, s_l1n[b1] - begin);
+            const u64 begin = (c - s_ubase[b1]) * TILE;
+            const u32 cnt = (u32)min((u64)TILE, s_l1n[b1] - begin);
             scatter_chunk<W, 2, false, NT>(bufA, b1, begin, cnt, t, t.nb2, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a,
                                        (u64)b1 * t.nb2, bufB, nosp, noclaims, GK_TARGS);
         }
@@ -969,6 +970,7 @@ static int part_prepare_l1(gk_map *m, PartScratch *ps, u64 nkeys, bool op1, Part
     // a range = up to MAX_RANGE_CHUNKS chunks, fewer when the batch is small (enough ranges to fill the chip)
     const u64 nchunks = nkeys / TILE2 + 1;
     arr->range_chunks = (u32)std::min<u64>(MAX_RANGE_CHUNKS, std::max<u64>(1, nchunks / ((u64)ctx->cu_count * 6)));
+    arr->chunk_keys = TILE2;
     u64 wantA = nkeys, wantS = 0;
     if (op1) {
         // Bucket sizes of hashed keys concentrate: binomial for distinct keys (mean + 8 sigma never overflows); with
@@ -1057,6 +1059,7 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         if constexpr (W == 1) {
             const int wide_max = (int)ScatterLds<1, 1024>::bytes(MAX_NB2);
             GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<1, true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, wide_max));
+            GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<1, false, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, wide_max));
         }
         GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter1_keys<W>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)ScatterLds<W>::bytes(256u)));
@@ -1078,9 +1081,14 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         const int rs = (int)std::max<u64>(1, std::min<u64>(by_bytes, (u64)(OP_CAP / W) / (u64)max_windows));
         const u64 ntiles = (src.nreads + rs - 1) / rs;
         const int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)ctx->cu_count * 2);
+        const bool p2_wide = ctx->hook_p2_wide > 0;        // 1024 threads per tile: A/B option (gk_ctx_set_option "p2_wide")
         if (!src.host) {
-            hipLaunchKernelGGL(k_op_scatter1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, src.nreads, src.stride, m->k, src.group, rs,
-                               src.max_len, t, a, sp, m->d_ctr, ps->bufA);
+            if (p2_wide)
+                hipLaunchKernelGGL((k_op_scatter1_reads<W, 1024>), dim3(grid), dim3(1024), 0, ctx->stream, d_rec, src.nreads, src.stride, m->k, src.group, rs,
+                                   src.max_len, src.verify_uniform ? 1 : 0, t, a, sp, m->d_ctr, ps->bufA);
+            else
+                hipLaunchKernelGGL((k_op_scatter1_reads<W, PBLOCK>), dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, src.nreads, src.stride, m->k, src.group, rs,
+                                   src.max_len, src.verify_uniform ? 1 : 0, t, a, sp, m->d_ctr, ps->bufA);
         } else {
             // Host-fed: upload in sub-chunks on the copy stream, scatter each as soon as it has landed.  The L1 regions are
             // append-only (cursor1), so P2 can run once per sub-chunk; P4 and P5 then see one batch.  With the caller's buffer
@@ -1100,8 +1108,12 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
                 GK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ev, 0));
                 const u64 nt = (nr + rs - 1) / rs;
                 const int gsub = (int)std::min<u64>(std::max<u64>(nt, 1), (u64)ctx->cu_count * 2);
-                hipLaunchKernelGGL(k_op_scatter1_reads<W>, dim3(gsub), dim3(PBLOCK), 0, ctx->stream, d_rec + off, nr, src.stride, m->k, src.group, rs,
-                                   src.max_len, t, a, sp, m->d_ctr, ps->bufA);
+                if (p2_wide)
+                    hipLaunchKernelGGL((k_op_scatter1_reads<W, 1024>), dim3(gsub), dim3(1024), 0, ctx->stream, d_rec + off, nr, src.stride, m->k, src.group, rs,
+                                       src.max_len, src.verify_uniform ? 1 : 0, t, a, sp, m->d_ctr, ps->bufA);
+                else
+                    hipLaunchKernelGGL((k_op_scatter1_reads<W, PBLOCK>), dim3(gsub), dim3(PBLOCK), 0, ctx->stream, d_rec + off, nr, src.stride, m->k, src.group, rs,
+                                       src.max_len, src.verify_uniform ? 1 : 0, t, a, sp, m->d_ctr, ps->bufA);
             }
         }
     } else if (d_rec) {
@@ -1126,6 +1138,9 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         const int g2 = (int)std::min<u64>(std::max<u64>((nkeys_in + TILE2 - 1) / TILE2, 1), (u64)ctx->cu_count * 4);
         hipLaunchKernelGGL(k_part_scatter1_keys<W>, dim3(g2), dim3(PBLOCK), ScatterLds<W>::bytes(256u), ctx->stream, d_keys, nkeys_in, t, a, ps->bufA, sp);
     }
+    // over-provisioned fine level with 8-byte keys: 8192-key chunks on 1024 threads when asked for (gk_ctx_set_option "p4_wide")
+    const bool op_wide = W == 1 && ctx->hook_p4_wide > 0;
+    if (op_wide) a.chunk_keys = 2 * TILE2;
     if (op1) hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(256), 0, ctx->stream, a, nb1);     // chunk / range tables from the cursors
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipEventRecord(ctx->pev[2], ctx->stream));
@@ -1153,13 +1168,21 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
     // the spill list overflow, the table is simply cleared again); a table that holds data gets the exact fine level
     // unless the sample says the batch is near-distinct.
     bool fine_exact = !op1 || plan.fine_exact || !from_empty;
-    const bool sync_between = plan.estimate || (op1 && !from_empty);
+    if (src.verify_uniform && !(d_rec && op1)) return fail(ctx, GK_E_STATE, "unverified host stream reached a path that cannot verify it");
+    const bool sync_between = plan.estimate || (op1 && !from_empty) || src.verify_uniform;
     if (sync_between) {
         Counters c;
         GK_HIP(ctx, hipMemcpyAsync(&nspill, a.nspill, 8, hipMemcpyDeviceToHost, ctx->stream));
         GK_HIP(ctx, hipMemcpyAsync(&ovf, a.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
         GK_HIP(ctx, hipMemcpyAsync(&c, m->d_ctr, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
         GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (src.verify_uniform && c.format) {       // not the uniform stream it looked like: only scratch was touched
+            GK_HIP(ctx, hipMemsetAsync(&m->d_ctr->format, 0, sizeof(u32), ctx->stream));
+            GK_HIP(ctx, hipEventRecord(ctx->pev[5], ctx->stream));
+            abandon(false);
+            m->retries_direct--;
+            return PART_NOT_UNIFORM;
+        }
         if (ovf) {
             GK_HIP(ctx, hipEventRecord(ctx->pev[5], ctx->stream));
             return abandon(false);
@@ -1217,7 +1240,13 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
     } else {
         GK_HIP(ctx, hipEventRecord(ctx->pev[3], ctx->stream));
         const int gchunks = (int)std::min<u64>(max_chunks, (u64)ctx->cu_count * 4);
-        hipLaunchKernelGGL((k_part_scatter2<W, false, PBLOCK>), dim3(gchunks), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2), ctx->stream, ps->bufA, t, a, max_chunks, ps->bufB);
+        if (op_wide && op1) {
+            if constexpr (W == 1) {
+                const size_t wide_lds = ScatterLds<1, 1024>::bytes(m->nb2);
+                hipLaunchKernelGGL((k_part_scatter2<1, false, 1024>), dim3(std::min(gchunks, ctx->cu_count * 2)), dim3(1024), wide_lds, ctx->stream, ps->bufA, t, a, max_chunks, ps->bufB);
+            }
+        } else
+            hipLaunchKernelGGL((k_part_scatter2<W, false, PBLOCK>), dim3(gchunks), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2), ctx->stream, ps->bufA, t, a, max_chunks, ps->bufB);
     }
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipEventRecord(ctx->pev[4], ctx->stream));

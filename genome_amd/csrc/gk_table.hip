@@ -459,6 +459,7 @@ int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value) {
         if (value < 0 || value > 2) return fail(ctx, GK_E_INVALID, "graph_unitigs: 0 auto, 1 walk, 2 pointer jumping");
         ctx->hook_unitigs = (int)value;
     } else if (n == "p4_direct") ctx->hook_p4_direct = value < 0 ? -1 : value != 0;
+    else if (n == "p2_wide") ctx->hook_p2_wide = value < 0 ? -1 : value != 0;
     else if (n == "p4_wide") ctx->hook_p4_wide = value < 0 ? -1 : value != 0;
     else if (n == "fine_exact") ctx->hook_fine_exact = value < 0 ? -1 : value != 0;
     else return fail(ctx, GK_E_INVALID, "gk_ctx_set_option: unknown option '" + n + "'");
@@ -677,6 +678,7 @@ static int launch_partitioned(gk_map *m, const ReadSrc &src, const u64 *d_keys, 
         if (from_empty) { m->pending_clear = true; m->size = 0; }       // a half-built table is void: the map is empty again
         return prc;
     }
+    if (prc == PART_NOT_UNIFORM) { m->pending_clear = from_empty; return prc; }     // nothing but scratch was touched
     if (prc == PART_RETRY_DIRECT) {        // extreme skew: nothing but scratch (or a table that was being rebuilt from empty) was touched
         m->pending_clear = from_empty;
         m->skewed = true;
@@ -872,6 +874,7 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
     const size_t MAX_STAGE = 256u << 20;
     size_t pos = 0;
     u64 r = 0;
+    bool walk_this_chunk = false;
     std::vector<u32> offs;
     while (r < nreads) {
         const size_t chunk_begin = pos;
@@ -883,7 +886,7 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
         bool uniform = true;            // every record of the chunk has the same length: fixed stride, no offset table
         // Fast prefix: a run of equal-length records (one sequencing run) is recognised by comparing one byte per
         // record, with no offset table built; it becomes a chunk of its own when it is long enough to be worth it.
-        bool fast_prefix = false;
+        bool fast_prefix = false, unverified = false;
         if (pos < nbytes) {
             const int len0 = bin[pos];
             const size_t rb0 = 1 + (size_t)(len0 + 3) / 4;
@@ -893,6 +896,12 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
             if (nk0) cap = std::min<u64>(cap, std::max<u64>(1, occ_limit / nk0));
             const uint8_t *p0 = bin + pos;
             u64 run = 0;
+            // What is left is EXACTLY (reads left) records of this length: one sequencing run, almost surely.  Then the
+            // host does not walk a million length bytes (~1 ms per 39 MB: a third of the whole insert) — the L1 scatter
+            // checks them on the device as it goes, and gives the chunk back if one differs (PART_NOT_UNIFORM).
+            const bool looks_uniform = !walk_this_chunk && !ctx->hook_host_ragged && !ctx->hook_part_exact && nk0 && (nbytes - pos) == (size_t)(nreads - r) * rb0 &&
+                                       cap >= 4096 && use_partitioned(m, cap * nk0) && nk0 * (u64)m->W <= (u64)5632;
+            if (looks_uniform) { run = cap; unverified = true; }
             while (run < cap && p0[run * rb0] == (uint8_t)len0) run++;
             if (run >= 4096 || (run == nreads - r && run > 0)) {
                 fast_prefix = true;
@@ -940,6 +949,7 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
         src.nreads = creads;
         src.host = bin + chunk_begin;
         src.host_bytes = cbytes;
+        src.verify_uniform = unverified;
         if (uniform && first_len >= 0 && !ctx->hook_host_ragged) {
             src.stride = 1 + (u32)(first_len + 3) / 4;
             src.max_len = first_len;
@@ -948,7 +958,15 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
             src.off = (const u32 *)m->d_offsets;
             src.max_len = 255;             // the host has walked this framing: every length byte is what the offsets say
         }
-        if (int rc = insert_batch(m, src, nullptr, 0, occ)) return rc;
+        const int brc = insert_batch(m, src, nullptr, 0, occ);
+        if (brc == PART_NOT_UNIFORM) {       // take the chunk again, this time walking its framing
+            pos = chunk_begin;
+            r = r_begin;
+            walk_this_chunk = true;
+            continue;
+        }
+        if (brc) return brc;
+        walk_this_chunk = false;
     }
     uint64_t occ = 0;
     if (int rc = read_occ_counter(m, &occ)) return rc;

@@ -57,11 +57,12 @@ __device__ __forceinline__ u64 stage_tile(u32 *tile, const uint8_t *rec, u64 gb,
 struct WindowLimits {
     int max_len;     // bases
     u32 *bad;        // device flag, may be nullptr
+    int exact = 0;   // 1: every record must be EXACTLY max_len long (a host stream taken for uniform without walking its framing)
 };
 __device__ __forceinline__ int record_len(const uint8_t *tb, u32 ro, const WindowLimits &lim) {
     int len = (int)tb[ro];                            // [len:u8]
-    if (len > lim.max_len) {
-        len = lim.max_len;
+    if (lim.exact ? len != lim.max_len : len > lim.max_len) {
+        len = len > lim.max_len ? lim.max_len : len;
         if (lim.bad) *lim.bad = 1u;
     }
     return len;

@@ -207,3 +207,28 @@ def test_verbatim_noncanonical_keys_still_build_the_reference_graph(ctx, k):
     m2.update_inc(keys[:50])                      # verbatim but canonical keys: still clean
     assert m2.stats()["noncanonical_keys"] is False
     m2.close()
+
+
+@pytest.mark.parametrize("k", [21, 47])
+def test_host_stream_that_only_looks_uniform(ctx, k):
+    """gk_map_count_reads takes a stream whose byte count is exactly nreads x (first record's size) for uniform WITHOUT walking
+    its framing; the L1 scatter checks every length byte on the device.  Here one record in the middle is a base shorter (same
+    record size): the check must notice, the chunk must be taken again through the host walk, and the table must be exact —
+    from an empty map and on top of existing content."""
+    n, L_ = 9000, 100
+    rec = synth.reads_mode_g(n, L_, 30000, 0.01, config_id=k)
+    odd = rec.copy()
+    odd[n // 3, 0] = L_ - 1                       # 99 bases: still 26 bytes
+    odd[n // 3, -1] &= 0x3f                       # the dropped base's bits are padding now: zero (DNASeq.scala:277)
+    for stream in (rec, odd):
+        ref = O.PMap(k, 1)
+        occ = ref.count_reads(stream.tobytes(), n)
+        m = HipDNAMap(ctx, k, occ)
+        m.set_insert_path("partitioned")
+        assert m.count_reads(stream.tobytes(), n) == occ
+        assert_same_table(m.sorted_items(), ref.export_sorted())
+        assert m.count_reads(stream.tobytes(), n) == occ          # second pass: table holds data
+        lo, hi, cnt = ref.export_sorted()
+        assert_same_table(m.sorted_items(), (lo, hi, cnt * 2))
+        m.close()
+

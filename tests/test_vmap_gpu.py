@@ -81,7 +81,7 @@ def test_put_new_get_all_update_apply_vs_oracle(ctx, k):
     assert len(lo) == um.size() and len(set(zip(lo.tolist(), hi.tolist()))) == len(lo)
     # key length is checked like everywhere else (ArrayDNAMap.scala:182)
     with pytest.raises(AssertionError):
-        vm.putNew("A" * (k + 1), 1)
+        vm.putNew("T" * (k + 1), 1)
     O.lib().gko_map_free(om); O.lib().gko_map_free(ou)
     vm.close(); um.close()
 
@@ -229,5 +229,5 @@ def test_add_node_replace_start_end_vs_oracle(ctx, k, seed):
     with pytest.raises(L.GkError):
         g.replaceEnd(0, 0xfffffff0)
     with pytest.raises(L.GkError):
-        g.addNode("A" * (k + 1))
+        g.addNode("T" * (k + 1))
     g.close(); m.close()
