@@ -890,8 +890,8 @@ int64_t gko_graph_find_out_edge(const gko_graph *g, int64_t node, int base) {
 /* MapGraph.addNode :172-176 */
 int64_t gko_graph_add_node(gko_graph *g, gko_kmer seq) {
     if (!g->nsorted) g->nsorted = g->nnodes;
-    if (g->nnodes + 2 >= g->ncap) {
-        g->ncap = g->ncap ? g->ncap * 2 : 64;
+    if (g->nnodes + 2 >= g->ncap) {      /* (buildGraph sizes the array exactly and leaves ncap at what it allocated, possibly 0) */
+        g->ncap = (g->ncap > g->nnodes ? g->ncap : g->nnodes) * 2 + 64;
         g->nodes = (gnode *)realloc(g->nodes, (size_t)g->ncap * sizeof(gnode));
     }
     gnode *n = &g->nodes[++g->nnodes];

@@ -337,3 +337,76 @@ def test_hash_tie_vectors():
         pm = O.PMap(k, 1)
         pm.count_reads(R.reads_to_bin([s, s, rc]), 3)
         assert pm.get(*R.pack(rc)) == 2 and pm.get(lo, hi) == 1 and pm.size() == 2
+
+
+@pytest.mark.parametrize("k,seed", [(15, 5), (31, 6), (47, 7)])
+def test_oracle_graph_edits_and_graph_map_invariants(k, seed):
+    """gko_graph_add_node / replace_start / replace_end (Graph.scala:172-176, 197-209) and gko_graph_get_graph_map (:90-119):
+    the reference's own invariants hold before and after a node split — (start.seq ++ edge.seq) ends with end.seq
+    (application.conf:73), the map holds sum(len) + nodes - edges entries (:96, :117), every node k-mer is a key."""
+    import random
+    from genome_amd import dna, synth
+    rnd = random.Random(seed)
+    g = "".join(rnd.choice("AGCT") for _ in range(1800))
+    reads = []
+    for _ in range(400):
+        ln = rnd.randint(k + 5, min(255, k + 90))
+        s = rnd.randrange(0, len(g) - ln + 1)
+        r = g[s:s + ln]
+        r = "".join(c if rnd.random() >= 0.02 else rnd.choice([x for x in "AGCT" if x != c]) for c in r)
+        reads.append(R.rev_comp(r) if rnd.random() < 0.5 else r)
+    binb = dna.reads_to_bin(reads)
+    ref = O.PMap(k, 1)
+    ref.count_reads(binb, len(reads)); ref.delete_lt(2)
+    og = O.Graph(ref)
+
+    def edges_of():
+        e = og.edges()
+        out = []
+        for i in range(len(e["len"])):
+            seq = synth.bases_to_str(e["bases"][e["off"][i]:e["off"][i] + e["len"][i]])
+            out.append((dna.unpack(int(e["slo"][i]), int(e["shi"][i]), k), dna.unpack(int(e["elo"][i]), int(e["ehi"][i]), k), seq))
+        return out
+
+    def check():
+        es = edges_of()
+        assert all((s + q).endswith(t) for s, t, q in es)
+        lo, hi, ie, ident, dist = og.graph_map_calls()
+        assert len(lo) == og.total_edge_len() + og.num_nodes() - og.num_edges()
+        assert int((ie == 0).sum()) == og.num_nodes()
+        # an edge position at distance d names the window d bases into start.seq ++ edge.seq
+        for i in list(range(0, len(lo), max(1, len(lo) // 200))):
+            if ie[i]:
+                info = og.edge_info(int(ident[i]))
+                s = dna.unpack(*og.node_seq(info["start"]), k)
+                q = next(x[2] for x in es if x[0] == s and x[2][0] == dna.BASES[info["first"]])
+                assert (s + q)[int(dist[i]):int(dist[i]) + k] == dna.unpack(int(lo[i]), int(hi[i]), k)
+        return es
+
+    es = check()
+    n0, e0 = og.num_nodes(), og.num_edges()
+    by_start = {}
+    for s, t, q in es:
+        by_start.setdefault(s, []).append((s, t, q))
+    targets = [s for s, v in by_start.items() if len(v) >= 2][:6]
+    assert targets
+    for j, s in enumerate(targets):
+        oid = og.find_node(*dna.pack(s))
+        new = og.add_node(*dna.pack(s))
+        assert new == n0 + j + 1 and og.num_nodes() == n0 + j + 1
+        q = sorted(by_start[s], key=lambda x: dna.BASES.index(x[2][0]))[0][2]
+        oe = og.find_out_edge(oid, dna.BASES.index(q[0]))
+        og.replace_start(oe, new)
+        assert og.edge_info(oe)["start"] == new and og.find_out_edge(oid, dna.BASES.index(q[0])) == 0
+        assert og.find_out_edge(new, dna.BASES.index(q[0])) == oe
+        inc = [x for x in es if x[1] == s and x[0] != s]
+        if inc:
+            a, _, c = inc[0]
+            oae = og.find_out_edge(og.find_node(*dna.pack(a)), dna.BASES.index(c[0]))
+            if oae:
+                og.replace_end(oae, new)
+                assert og.edge_info(oae)["end"] == new
+        assert og.num_edges() == e0
+        check()
+    og.simplify()
+    check()
