@@ -13,6 +13,7 @@ struct gk_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // phase boundaries of the partitioned path
+    hipEvent_t gev = nullptr;                     // "the host is back": the fine level's first launch (the GPU idles from pev[2] to here)
     hipStream_t copy_stream = nullptr;            // host -> device copies that overlap kernels on `stream` (host-fed inserts)
     hipEvent_t cev[16] = {};                      // "sub-chunk j has landed" (round robin)
     int cu_count = 256;
@@ -94,6 +95,7 @@ struct gk_map {
     uint64_t part_launches = 0, direct_launches = 0;
     uint64_t spilled_keys = 0, failed_segments = 0, retries_direct = 0;   // partitioned-path skew counters
     float phase_ms[5] = {0, 0, 0, 0, 0};   // last insert: hist1, scatter1, hist2, scatter2, seg_insert (or [0] = direct kernel)
+    float gap_ms = 0.f;                    // of phase_ms[2]: GPU idle while the host read the sample / sized the table / prepared the fine level
 };
 
 namespace gk {

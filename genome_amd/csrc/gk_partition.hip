@@ -1139,7 +1139,8 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         hipLaunchKernelGGL(k_part_scatter1_keys<W>, dim3(g2), dim3(PBLOCK), ScatterLds<W>::bytes(256u), ctx->stream, d_keys, nkeys_in, t, a, ps->bufA, sp);
     }
     // over-provisioned fine level with 8-byte keys: 8192-key chunks on 1024 threads when asked for (gk_ctx_set_option "p4_wide")
-    const bool op_wide = W == 1 && ctx->hook_p4_wide > 0;
+    // (measured at C2, nb2 = 370: P4 0.66 -> 0.62 ms in mode U, 0.64 -> 0.62 in mode G: half the per-bin bookkeeping per key)
+    const bool op_wide = W == 1 && (ctx->hook_p4_wide >= 0 ? ctx->hook_p4_wide != 0 : m->nb2 >= 256);
     if (op_wide) a.chunk_keys = 2 * TILE2;
     if (op1) hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(256), 0, ctx->stream, a, nb1);     // chunk / range tables from the cursors
     GK_HIP(ctx, hipGetLastError());
@@ -1209,6 +1210,7 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
     if (m->nb2 > MAX_NB2) return fail(ctx, GK_E_CAPACITY, "table outgrew the partitioned insert path");   // (callers check part_supported first)
     if (int rc = part_prepare_fine(m, ps, nkeys_bound, !fine_exact, &a)) return rc;
     const u64 nseg = t.nseg();
+    GK_HIP(ctx, hipEventRecord(ctx->gev, ctx->stream));
 
     // ---- stage B: P3 + scans + P4 (the fine level) ---------------------------------------------------------
     const u64 max_chunks = nkeys_bound / TILE2 + 257;

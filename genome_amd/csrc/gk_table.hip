@@ -411,6 +411,7 @@ int gk_ctx_create(int device, gk_ctx **out) {
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&ctx->pev[i]);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->gev);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
     for (int i = 0; i < 16 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->cev[i], hipEventDisableTiming);
     hipDeviceProp_t prop;
@@ -441,6 +442,7 @@ void gk_ctx_destroy(gk_ctx *ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (int i = 0; i < 6; i++) if (ctx->pev[i]) (void)hipEventDestroy(ctx->pev[i]);
+    if (ctx->gev) (void)hipEventDestroy(ctx->gev);
     for (int i = 0; i < 16; i++) if (ctx->cev[i]) (void)hipEventDestroy(ctx->cev[i]);
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     delete ctx;
@@ -698,6 +700,11 @@ static int launch_partitioned(gk_map *m, const ReadSrc &src, const u64 *d_keys, 
         GK_HIP(ctx, hipEventElapsedTime(&pm, ctx->pev[i], ctx->pev[i + 1]));
         m->phase_ms[i] += pm;
     }
+    {
+        float gm = 0.f;
+        GK_HIP(ctx, hipEventElapsedTime(&gm, ctx->pev[2], ctx->gev));
+        m->gap_ms += gm;
+    }
     m->part_launches++;
     return GK_OK;
 }
@@ -772,6 +779,7 @@ static int insert_batch(gk_map *m, const ReadSrc &src, const u64 *d_keys, u64 nk
 }
 
 static void reset_call_stats(gk_map *m) {
+    m->gap_ms = 0.f;
     m->last_count_ms = 0.f;
     m->last_count_occ = 0;
     for (float &x : m->phase_ms) x = 0.f;
@@ -1244,14 +1252,14 @@ int gk_map_stats(gk_map *m, char *json, size_t cap) {
                      "\"load\":%.6f,\"occurrences\":%llu,\"grows\":%llu,\"last_count_kernel_ms\":%.6f,"
                      "\"last_count_occurrences\":%llu,\"partitioned_launches\":%llu,\"direct_launches\":%llu,"
                      "\"spilled_keys\":%llu,\"failed_segments\":%llu,\"retries_direct\":%llu,\"est_new_distinct_last_batch\":%llu,"
-                     "\"noncanonical_keys\":%s,\"repeat_heavy\":%s,\"device\":%d,\"cu_count\":%d}",
+                     "\"noncanonical_keys\":%s,\"repeat_heavy\":%s,\"last_count_host_gap_ms\":%.4f,\"device\":%d,\"cu_count\":%d}",
                      m->k, m->W, slot_bytes(m->W), (unsigned long long)m->capacity, (unsigned long long)m->size,
                      (unsigned long long)m->tombstones, m->capacity ? (double)m->size / (double)m->capacity : 0.0,
                      (unsigned long long)m->total_occurrences, (unsigned long long)m->grows, m->last_count_ms,
                      (unsigned long long)m->last_count_occ, (unsigned long long)m->part_launches,
                      (unsigned long long)m->direct_launches, (unsigned long long)m->spilled_keys,
                      (unsigned long long)m->failed_segments, (unsigned long long)m->retries_direct, (unsigned long long)m->est_distinct_last,
-                     m->dirty ? "true" : "false", m->repeats ? "true" : "false", m->ctx->device, m->ctx->cu_count);
+                     m->dirty ? "true" : "false", m->repeats ? "true" : "false", m->gap_ms, m->ctx->device, m->ctx->cu_count);
     if (w < 0 || (size_t)w >= cap) return fail(m->ctx, GK_E_CAPACITY, "stats buffer too small");
     return GK_OK;
 }

@@ -410,3 +410,21 @@ def test_oracle_graph_edits_and_graph_map_invariants(k, seed):
         check()
     og.simplify()
     check()
+
+
+FORMULA = "A"      # scala-library 2.9.1 primitive Long.##: "A" = (int)(v ^ (v >>> 32)); see tests/golden/kat/make_hash_bit31.py
+
+
+def test_long_hash_formula_is_one_visible_choice():
+    """k <= 31 k-mers with bit 31 set and a non-zero high word: the two candidate readings of `Long.##` give different hash
+    VALUES (every vector here) — the canonical orientation, a comparison of two such hashes, almost never differs (see the
+    generator's note).  Both restatements implement FORMULA; the vectors hold the other formula's answers too, so a switch
+    is one line per side plus this constant."""
+    vec = json.load(open(os.path.join(GOLDEN, "kat", "hash_bit31.json")))["vectors"]
+    assert len(vec) >= 20 and all(v["A"]["h_x"] != v["B"]["h_x"] or v["A"]["h_rc"] != v["B"]["h_rc"] for v in vec)
+    for v in vec:
+        k, want = v["k"], v[FORMULA]
+        assert O.hash_code(v["x_lo"], 0, k) == want["h_x"] == R.hash_code(v["x"])
+        assert O.hash_code(v["rc_lo"], 0, k) == want["h_rc"] == R.hash_code(v["rc"])
+        lo, _ = O.canon(v["x_lo"], 0, k)
+        assert R.canon(v["x"]) == want["canonical"] and lo == R.pack(want["canonical"])[0]
