@@ -15,7 +15,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgenome_amd.so")
+# GK_LIB_PATH: load another build of the SAME library (a -DGK_TIMERS or tuning variant under genome_amd/variants/) without
+# overwriting the product .so; there is still no fallback if the file is missing.
+LIB_PATH = os.environ.get("GK_LIB_PATH") or os.path.join(_HERE, "libgenome_amd.so")
 
 GK_OK = 0
 GK_E_INVALID, GK_E_KLEN, GK_E_UNSUPPORTED_K, GK_E_CAPACITY = -1, -2, -3, -4
@@ -94,6 +96,8 @@ SIGNATURES = {
     "gk_dist_barrier": (C.c_int, [vp]),
     "gk_dist_allreduce_f64": (C.c_int, [vp, C.POINTER(C.c_double), C.c_int, C.c_int]),
     "gk_dist_count_reads_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, u64p, u64p]),
+    "gk_dist_route_begin": (C.c_int, [vp, C.c_int, vp, C.c_uint64, C.c_int]),
+    "gk_dist_count_routed": (C.c_int, [vp, vp, u64p, u64p]),
     "gk_dist_last_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
     "gk_dist_size": (C.c_int, [vp, vp, u64p]),
     "gk_dist_gather_map": (C.c_int, [vp, vp, C.POINTER(vp)]),

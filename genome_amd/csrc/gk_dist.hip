@@ -87,10 +87,19 @@ struct gk_dist {
     gk_ctx *ctx = nullptr;
     int rank = 0, world = 1;
     ncclComm_t comm = nullptr;
-    // exchange scratch, kept between calls
-    uint8_t *d_send = nullptr, *d_recv = nullptr;
-    u64 send_records = 0, recv_records = 0;          // capacities in record slots (send: world regions of send_records / world)
+    // exchange scratch, kept between calls.  TWO send buffers: gk_dist_route_begin fills one on the second stream while the
+    // records of the previous batch still leave the other one.
+    uint8_t *d_sendbuf[2] = {nullptr, nullptr}, *d_recv = nullptr;
+    u64 send_cap[2] = {0, 0}, recv_records = 0;      // capacities in record slots (send: world regions of send_cap / world)
+    int cur = 0;                                     // the send buffer the next route goes to
     int slot = 0;                                    // record slot bytes the buffers were sized for
+    // routes that were begun and not yet consumed: at most two (one per send buffer), consumed first in, first out
+    struct Route { int k = 0, read_len = 0; const void *records = nullptr; u64 nreads = 0; };
+    Route route[2];
+    int npending = 0;                                // route[(cur - npending) & 1] is the oldest
+    unsigned long long *d_route_cnt = nullptr;       // [2][SKM_COUNT_WORDS] counters of the routing kernels on the second stream
+    unsigned long long *h_route_cnt = nullptr;       // pinned copy
+    hipEvent_t route_done[2] = {nullptr, nullptr};   // recorded behind each route's counter copy
     unsigned long long *d_cnt = nullptr;             // [4 * world]: (records, k-mers) per peer to send, then as received
     unsigned long long *h_cnt = nullptr;             // pinned mirror
     float last_ms[4] = {0, 0, 0, 0};                 // route, exchange, owner count, total (wall)
@@ -176,6 +185,9 @@ int gk_dist_create(gk_ctx *ctx, int rank, int world, const void *id128, gk_dist 
     }
     hipError_t e = hipMalloc((void **)&d->d_cnt, 4 * 64 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc((void **)&d->h_cnt, 4 * 64 * sizeof(unsigned long long), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void **)&d->d_route_cnt, 2 * SKM_COUNT_WORDS * sizeof(unsigned long long));
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&d->route_done[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&d->h_route_cnt, 2 * SKM_COUNT_WORDS * sizeof(unsigned long long), hipHostMallocDefault);
     if (e != hipSuccess) { int c = hip_fail(ctx, e, "gk_dist_create"); r->CommDestroy(d->comm); delete d; return c; }
     *out = d;
     return GK_OK;
@@ -185,8 +197,12 @@ void gk_dist_destroy(gk_dist *d) {
     if (!d) return;
     if (d->ctx) { (void)hipSetDevice(d->ctx->device); (void)hipStreamSynchronize(d->ctx->stream); }
     if (d->comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(d->comm);
-    if (d->d_send) (void)hipFree(d->d_send);
+    if (d->ctx && d->ctx->copy_stream) (void)hipStreamSynchronize(d->ctx->copy_stream);
+    for (int i = 0; i < 2; i++) if (d->d_sendbuf[i]) (void)hipFree(d->d_sendbuf[i]);
     if (d->d_recv) (void)hipFree(d->d_recv);
+    for (int i = 0; i < 2; i++) if (d->route_done[i]) (void)hipEventDestroy(d->route_done[i]);
+    if (d->d_route_cnt) (void)hipFree(d->d_route_cnt);
+    if (d->h_route_cnt) (void)hipHostFree(d->h_route_cnt);
     if (d->d_cnt) (void)hipFree(d->d_cnt);
     if (d->h_cnt) (void)hipHostFree(d->h_cnt);
     delete d;
@@ -238,45 +254,77 @@ static int dist_grow(gk_ctx *ctx, uint8_t **buf, u64 *have, u64 want_records, in
     return GK_OK;
 }
 
-int gk_dist_count_reads_dev(gk_dist *d, gk_map *local, const void *dev_records, uint64_t nreads, int read_len,
-                            uint64_t *occurrences_sent, uint64_t *occurrences_owned) {
+static u64 route_want_records(int k, int P, u64 nreads, int read_len) {
+    // a run of same-owner windows is about half a minimizer window long; a region that turns out too small is reported with
+    // the size it needs and the route is taken again
+    const u64 nk = read_len >= k ? (u64)(read_len - k + 1) : 0;
+    const double per_read = std::max(2.0, (double)nk / std::max(1.0, (k - 9) / 2.0)) * 1.5 + 1.0;
+    return std::max<u64>((u64)1024 * P, (u64)((double)nreads * per_read) / P * P);
+}
+
+// Route this rank's reads for the NEXT gk_dist_count_routed on the context's second stream and return at once: the routing
+// kernel (0.6 ms per 10^6 reads, issue-bound) then overlaps whatever the main stream is doing — in a streaming loop, the
+// owner pipeline of the previous batch.  The records buffer must stay valid until gk_dist_count_routed returns.
+int gk_dist_route_begin(gk_dist *d, int k, const void *dev_records, uint64_t nreads, int read_len) {
+    if (int rc = dist_check(d)) return rc;
+    gk_ctx *ctx = d->ctx;
+    if (d->npending >= 2) return fail(ctx, GK_E_STATE, "gk_dist_route_begin: two routes are already waiting (gk_dist_count_routed consumes one)");
+    if (!dev_records && nreads) return fail(ctx, GK_E_INVALID, "gk_dist_route_begin: null records");
+    if (read_len < 0 || read_len > 255) return fail(ctx, GK_E_FORMAT, "read_len must be 0..255 (one length byte per record)");
+    if (!k_supported(k)) return fail(ctx, GK_E_UNSUPPORTED_K, "k=" + std::to_string(k) + " unsupported");
+    const int P = d->world, slot = gk_skm_slot_bytes(k);
+    if (d->slot != slot) {       // key width changed: the buffers were sized in other slots
+        if (d->npending) return fail(ctx, GK_E_KLEN, "gk_dist_route_begin: a route for another key width is still waiting");
+        GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        GK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+        for (int i = 0; i < 2; i++) { if (d->d_sendbuf[i]) GK_HIP(ctx, hipFree(d->d_sendbuf[i])); d->d_sendbuf[i] = nullptr; d->send_cap[i] = 0; }
+        if (d->d_recv) { GK_HIP(ctx, hipFree(d->d_recv)); d->d_recv = nullptr; }
+        d->recv_records = 0;
+        d->slot = slot;
+    }
+    const int b = d->cur;
+    if (int rc = dist_grow(ctx, &d->d_sendbuf[b], &d->send_cap[b], std::max(route_want_records(k, P, nreads, read_len), d->send_cap[b]), slot)) return rc;
+    if (int rc = skm_route_launch(ctx, ctx->copy_stream, d->d_route_cnt + b * SKM_COUNT_WORDS, d->h_route_cnt + b * SKM_COUNT_WORDS, k, dev_records, nreads,
+                                  read_len, P, d->d_sendbuf[b], d->send_cap[b])) return rc;
+    GK_HIP(ctx, hipEventRecord(d->route_done[b], ctx->copy_stream));
+    d->route[b].k = k; d->route[b].read_len = read_len; d->route[b].records = dev_records; d->route[b].nreads = nreads;
+    d->npending++;
+    d->cur ^= 1;
+    return GK_OK;
+}
+
+// The rest of the batch begun by gk_dist_route_begin: wait for its route, exchange counts and records, count what arrived.
+int gk_dist_count_routed(gk_dist *d, gk_map *local, uint64_t *occurrences_sent, uint64_t *occurrences_owned) {
     if (int rc = dist_check(d)) return rc;
     gk_ctx *ctx = d->ctx;
     if (occurrences_sent) *occurrences_sent = 0;
     if (occurrences_owned) *occurrences_owned = 0;
-    if (!local || local->ctx != ctx) return fail(ctx, GK_E_INVALID, "gk_dist_count_reads_dev: the local map must live on the handle's context");
-    if (!dev_records && nreads) return fail(ctx, GK_E_INVALID, "gk_dist_count_reads_dev: null records");
-    if (read_len < 0 || read_len > 255) return fail(ctx, GK_E_FORMAT, "read_len must be 0..255 (one length byte per record)");
-    const int k = local->k, P = d->world;
-    const int slot = gk_skm_slot_bytes(k);
+    if (!d->npending) return fail(ctx, GK_E_STATE, "gk_dist_count_routed: no route was begun (gk_dist_route_begin)");
+    const int b = (d->cur - d->npending) & 1;
+    const gk_dist::Route rt = d->route[b];
+    if (!local || local->ctx != ctx) return fail(ctx, GK_E_INVALID, "gk_dist_count_routed: the local map must live on the handle's context");
+    if (local->k != rt.k) return fail(ctx, GK_E_KLEN, "gk_dist_count_routed: the route was begun for another k");
+    d->npending--;
+    const int k = rt.k, P = d->world, slot = d->slot;
+    unsigned long long *d_rc = d->d_route_cnt + b * SKM_COUNT_WORDS, *h_rc = d->h_route_cnt + b * SKM_COUNT_WORDS;
     const double t0 = now_ms();
-    if (d->slot != slot) {       // key width changed: the buffers were sized in other slots
-        if (d->d_send) { GK_HIP(ctx, hipFree(d->d_send)); d->d_send = nullptr; }
-        if (d->d_recv) { GK_HIP(ctx, hipFree(d->d_recv)); d->d_recv = nullptr; }
-        d->send_records = d->recv_records = 0;
-        d->slot = slot;
-    }
-    // ---- 1. route: super-k-mer records grouped by owner rank (region p of the send buffer).  A run of same-owner windows
-    //         is about half a minimizer window long; a region that turns out too small is reported with the size it needs.
+    // ---- 1. the route's counters (it ran on the second stream, possibly long ago)
     uint64_t recs[64], kmers[64];
-    const u64 nk = read_len >= k ? (u64)(read_len - k + 1) : 0;
-    for (int p = 0; p < P; p++) { recs[p] = 0; kmers[p] = 0; }
-    if (nreads && nk) {
-        const double per_read = std::max(2.0, (double)nk / std::max(1.0, (k - 9) / 2.0)) * 1.5 + 1.0;
-        u64 want = std::max<u64>((u64)1024 * P, (u64)((double)nreads * per_read) / P * P);
-        for (int attempt = 0;; attempt++) {
-            if (int rc = dist_grow(ctx, &d->d_send, &d->send_records, std::max(want, d->send_records), slot)) return rc;
-            int rc = gk_shard_superkmers_dev(ctx, k, dev_records, nreads, read_len, P, d->d_send, d->send_records, recs, kmers);
-            if (rc == GK_OK) break;
-            if (rc != GK_E_CAPACITY || attempt >= 4) return rc;
-            u64 worst = 0;
-            for (int p = 0; p < P; p++) worst = std::max<u64>(worst, recs[p]);
-            want = std::max<u64>(d->send_records * 2, (worst + worst / 8 + 1024) * P);     // the fullest region, with headroom, for every region
-        }
+    GK_HIP(ctx, hipEventSynchronize(d->route_done[b]));        // this route only: the next one may already be queued behind it
+    int rrc = skm_route_finish(ctx, h_rc, rt.nreads && rt.read_len >= k, P, d->send_cap[b], recs, kmers);
+    for (int attempt = 0; rrc == GK_E_CAPACITY && attempt < 4; attempt++) {       // a region was too small: route again, in place, bigger
+        u64 worst = 0;
+        for (int p = 0; p < P; p++) worst = std::max<u64>(worst, recs[p]);
+        const u64 want = std::max<u64>(d->send_cap[b] * 2, (worst + worst / 8 + 1024) * P);
+        if (int rc = dist_grow(ctx, &d->d_sendbuf[b], &d->send_cap[b], want, slot)) return rc;
+        if (int rc = skm_route_launch(ctx, ctx->copy_stream, d_rc, h_rc, k, rt.records, rt.nreads, rt.read_len, P, d->d_sendbuf[b], d->send_cap[b])) return rc;
+        GK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+        rrc = skm_route_finish(ctx, h_rc, true, P, d->send_cap[b], recs, kmers);
     }
+    if (rrc) return rrc;
     const double t1 = now_ms();
     // ---- 2. counts: (records, k-mers) for every peer, one tiny all-to-all; the sizes then reach the host
-    const u64 region = d->send_records / (u64)P;
+    const u64 region = d->send_cap[b] / (u64)P;
     u64 sent = 0;
     for (int p = 0; p < P; p++) { d->h_cnt[2 * p] = recs[p]; d->h_cnt[2 * p + 1] = kmers[p]; sent += kmers[p]; }
     unsigned long long *d_in = d->d_cnt, *d_out = d->d_cnt + 2 * 64;
@@ -298,7 +346,7 @@ int gk_dist_count_reads_dev(gk_dist *d, gk_map *local, const void *dev_records, 
     GK_NCCL(ctx, r->GroupStart());
     u64 roff = 0;
     for (int p = 0; p < P; p++) {
-        if (recs[p]) GK_NCCL(ctx, r->Send(d->d_send + (u64)p * region * slot, (size_t)recs[p] * slot, ncclUint8, p, d->comm, ctx->stream));
+        if (recs[p]) GK_NCCL(ctx, r->Send(d->d_sendbuf[b] + (u64)p * region * slot, (size_t)recs[p] * slot, ncclUint8, p, d->comm, ctx->stream));
         if (h_out[2 * p]) GK_NCCL(ctx, r->Recv(d->d_recv + roff * slot, (size_t)h_out[2 * p] * slot, ncclUint8, p, d->comm, ctx->stream));
         roff += h_out[2 * p];
     }
@@ -313,6 +361,16 @@ int gk_dist_count_reads_dev(gk_dist *d, gk_map *local, const void *dev_records, 
     if (occurrences_sent) *occurrences_sent = sent;
     if (occurrences_owned) *occurrences_owned = occ;
     return GK_OK;
+}
+
+int gk_dist_count_reads_dev(gk_dist *d, gk_map *local, const void *dev_records, uint64_t nreads, int read_len,
+                            uint64_t *occurrences_sent, uint64_t *occurrences_owned) {
+    if (int rc = dist_check(d)) return rc;
+    if (occurrences_sent) *occurrences_sent = 0;
+    if (occurrences_owned) *occurrences_owned = 0;
+    if (!local || local->ctx != d->ctx) return fail(d->ctx, GK_E_INVALID, "gk_dist_count_reads_dev: the local map must live on the handle's context");
+    if (int rc = gk_dist_route_begin(d, local->k, dev_records, nreads, read_len)) return rc;
+    return gk_dist_count_routed(d, local, occurrences_sent, occurrences_owned);
 }
 
 int gk_dist_last_ms(gk_dist *d, float *ms4) {

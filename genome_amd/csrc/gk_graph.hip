@@ -155,11 +155,14 @@ __global__ __launch_bounds__(BLOCK) void k_classify(Table<W> t, int k, unsigned 
         // sector; done one after the other a lane has ONE miss in flight (168 ms for 1.5e8 16-byte keys).
         // So: prepare all 8 (canonical orientation, segment, start slot), touch the 8 first sectors
         // back to back, then resolve — the later probes of a lookup mostly stay in the sector it opened.
+        // The first probed slot's key word is KEPT (eight registers): with 16 waves x 64 lanes x 8 lookups in flight per
+        // CU the touched lines (0.5 MB) do not survive in the 32 KiB L1 — nor, 32 CUs to an XCD, in its 4 MiB L2 — until the
+        // resolve loop comes back to them, and re-reading them there fetched most sectors from memory TWICE.
         Kmer<W> q[8];
         const Slot<W> *qseg[8];
         u32 qpos[8];
+        u64 w0v[8];
         u32 ties = 0;
-        u64 touched = 0;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const Kmer<W> x = (j & 1) ? append_base(y, j >> 1, k) : prepend_base(j >> 1, y, k);
@@ -169,11 +172,9 @@ __global__ __launch_bounds__(BLOCK) void k_classify(Table<W> t, int k, unsigned 
             q[j] = hx < hr ? x : rc;
             const u64 h = slot_hash(q[j]);
             qseg[j] = t.slots + ((u64)seg_of(t, h) << SegBits<W>::value);
-            qpos[j] = seg_pos<W>(h);
-            const u32 first = t.tagged ? ((qpos[j] & ~3u) | key_tag(q[j])) : qpos[j];
-            touched ^= qseg[j][first].w0;
+            qpos[j] = t.tagged ? ((seg_pos<W>(h) & ~3u) | key_tag(q[j])) : seg_pos<W>(h);
+            w0v[j] = qseg[j][qpos[j]].w0;
         }
-        if (touched == 0x5bd1e9955bd1e995ULL) in = 0;             // keeps the eight loads alive; changes nothing
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             bool hit;
@@ -182,7 +183,16 @@ __global__ __launch_bounds__(BLOCK) void k_classify(Table<W> t, int k, unsigned 
                 const Kmer<W> x = (j & 1) ? append_base(y, j >> 1, k) : prepend_base(j >> 1, y, k);
                 hit = table_find_either(t, x, k, &f) >= 0;
             } else {
-                hit = seg_find(qseg[j], qpos[j], q[j], t.tagged) >= 0;
+                // first slot from the register; only a slot that is occupied by ANOTHER key sends the probe on (to memory)
+                constexpr u32 smask = (1u << SegBits<W>::value) - 1u;
+                const u32 step = t.tagged ? 4u : 1u;
+                if (w0v[j] == KEY_EMPTY) hit = false;
+                else {
+                    bool first_is_it;
+                    if constexpr (W == 1) first_is_it = w0v[j] == q[j].lo;
+                    else { const Stored<2> sk = to_stored(q[j]); first_is_it = w0v[j] == sk.w0 && qseg[j][qpos[j]].w1 == sk.w1; }
+                    hit = first_is_it || seg_find(qseg[j], (qpos[j] + step) & smask, q[j], t.tagged) >= 0;
+                }
             }
             if (hit) { if (j & 1) out |= 1u << (j >> 1); else in |= 1u << (j >> 1); }
         }

@@ -25,6 +25,7 @@ struct gk_ctx {
     int hook_unitigs = 0;            // 0 auto, 1 walk, 2 pointer jumping
     int hook_p4_direct = -1;         // exact fine level: -1 auto (by nb2), 0 chunk sorted in LDS, 1 straight scatter with per-range cursors
     int hook_p2_wide = -1;           // over-provisioned L1 scatter: 1 = 1024 threads per tile (A/B)
+    int hook_p2_sorted = -1;         // over-provisioned L1 scatter: 1 = bucket-ordered write-out (A/B)
     int hook_p4_wide = -1;           // exact fine level, 8-byte keys: -1 auto (by nb2), 0 sort 4096 keys at a time, 1 sort 8192 (1024 threads)
     int hook_fine_exact = -1;        // -1 auto, 0 never unless forced by the data path, 1 always (A/B of the two fine levels)
     std::string err;
@@ -157,6 +158,12 @@ int map_ensure_sample(gk_map *m);                    // allocate the distinct-ke
 int map_make_room(gk_map *m, uint64_t new_distinct, uint64_t size_for, bool from_empty);
 uint64_t part_max_slots(int W);                      // largest table the partitioned path can address
 int ctx_check_format(gk_ctx *ctx);                   // GK_E_FORMAT (and reset) if a map-less kernel raised ctx->d_flags[0]
+// super-k-mer routing in two halves (gk_skm.hip): launch on any stream without waiting, finish after that stream was synchronised
+constexpr int SKM_COUNT_WORDS = 2 * 64 + 1;
+int skm_route_launch(gk_ctx *ctx, hipStream_t st, unsigned long long *d_counts, unsigned long long *h_counts, int k, const void *dev_records,
+                     uint64_t nreads, int read_len, int P, void *dev_out, uint64_t out_cap_records);
+int skm_route_finish(gk_ctx *ctx, const unsigned long long *h_counts, bool launched, int P, uint64_t out_cap_records, uint64_t *rec_counts_host,
+                     uint64_t *kmer_counts_host);
 // lanes per read in the window loops: 64 for reads, 32/16 for short records (super-k-mers)
 inline int lanes_per_read(int max_windows) { return max_windows > 32 ? 64 : max_windows > 16 ? 32 : 16; }
 bool part_supported(const gk_map *m);

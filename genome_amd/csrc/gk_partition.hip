@@ -280,24 +280,39 @@ __global__ __launch_bounds__(BLOCK) void k_part_hist1_keys(const u64 *__restrict
 // position [TILE2] u16, per-bin offset [nbins] u32, per-bin destination [nbins] u64.
 // RANGED (level 2, exact fine level): gb[] already holds this range's running destination of every bin (from the
 // range matrix), so nothing is reserved — no global atomic at all — and gb[] advances by the chunk's counts.
-template <int W, int LEVEL, bool RANGED, int NT>
-__device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u32 b1, u64 begin, u32 cnt, const Table<W> &t, u32 nbins,
-                                              u64 *sorted, uint16_t *binof, u32 *off, u32 *lim, unsigned long long *gb, u32 *wsum,
-                                              const PartArrays &a, u64 bin0, u64 *__restrict__ out, const Sampler &sp, u32 &claims,
-                                              GK_TARGS_DECL) {
-    Kmer<W> key[KEYS_PER_THREAD];
-    u32 bin[KEYS_PER_THREAD], rank[KEYS_PER_THREAD];
-    for (u32 b = threadIdx.x; b < nbins; b += NT) off[b] = 0;
-    __syncthreads();
-    GK_TICK(0);
-    // all loads first, unconditionally (index clamped): one memory round trip per chunk instead of
-    // one per key — a load inside `if (i < cnt)` is sunk next to its use and serialises
+// A chunk's keys into registers: all loads unconditionally (index clamped; cnt >= 1): one memory round trip per chunk
+// instead of one per key — a load inside `if (i < cnt)` is sunk next to its use and serialises.  P4 calls this for the
+// NEXT chunk before it sorts the current one, so the round trip hides behind a chunk's worth of LDS work.
+// lbase (LEVEL 2, exact L1 level only): l1_base[b1], handed in by the caller from its LDS copy — a global load of it here
+// would put a full vmcnt(0) wait, i.e. a wait for the previous chunk's stores, in front of the prefetch.
+template <int W, int LEVEL, int NT>
+__device__ __forceinline__ void load_chunk(Kmer<W> (&key)[KEYS_PER_THREAD], const u64 *__restrict__ in, const PartArrays &a, u32 b1, u64 lbase,
+                                           u64 begin, u32 cnt) {
 #pragma unroll
     for (int j = 0; j < KEYS_PER_THREAD; j++) {
         const u32 i = threadIdx.x + j * NT;
         const u64 src = begin + (i < cnt ? i : cnt - 1);
-        key[j] = load_key<W>(in, LEVEL == 2 ? l1_key_index(a, b1, src) : src);
+        key[j] = load_key<W>(in, LEVEL == 2 ? (a.op1 ? l1_slot(a, b1, src) : lbase + src) : src);
     }
+}
+// prefetch(): the caller's request for the NEXT chunk's keys, issued before this chunk is sorted.  On gfx9-family parts loads
+// and stores share vmcnt and may complete out of order with respect to each other, so any wait for a load while stores are
+// pending is a full vmcnt(0), stores included.  The prefetched keys are therefore waited for HERE, explicitly, right before
+// the write-out issues its stores (they were requested a sort earlier and have long landed): the next chunk then starts
+// without waiting for this chunk's stores.
+struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
+static constexpr bool is_prefetching(const NoPrefetch &) { return false; }
+template <class F> static constexpr bool is_prefetching(const F &) { return true; }
+template <int W, int LEVEL, bool RANGED, int NT, class Prefetch = NoPrefetch>
+__device__ __forceinline__ void scatter_chunk(const Kmer<W> (&key)[KEYS_PER_THREAD], u32 cnt, const Table<W> &t, u32 nbins,
+                                              u64 *sorted, uint16_t *binof, u32 *off, u32 *lim, unsigned long long *gb, u32 *wsum,
+                                              const PartArrays &a, u64 bin0, u64 *__restrict__ out, const Sampler &sp, u32 &claims,
+                                              GK_TARGS_DECL, Prefetch prefetch = Prefetch()) {
+    u32 bin[KEYS_PER_THREAD], rank[KEYS_PER_THREAD];
+    prefetch();
+    for (u32 b = threadIdx.x; b < nbins; b += NT) off[b] = 0;
+    __syncthreads();
+    GK_TICK(0);
 #pragma unroll
     for (int j = 0; j < KEYS_PER_THREAD; j++) {
         const u32 i = threadIdx.x + j * NT;
@@ -342,6 +357,7 @@ __device__ __forceinline__ void scatter_chunk(const u64 *__restrict__ in, u32 b1
             store_key<W>(sorted, pos, key[j]);
             binof[pos] = (uint16_t)bin[j];
         }
+    if (is_prefetching(prefetch)) __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): the next chunk's keys are in
     __syncthreads();
     GK_TICK(5);
     for (u32 i = threadIdx.x; i < cnt; i += NT) {          // linear, coalesced write-out
@@ -385,7 +401,9 @@ __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_keys(const u64 *__rest
     for (u64 c = blockIdx.x; c < nchunks; c += gridDim.x) {
         const u64 begin = c * TILE2;
         const u32 cnt = (u32)min((u64)TILE2, n - begin);
-        scatter_chunk<W, 1, false, PBLOCK>(keys, 0u, begin, cnt, t, 256u, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a, 0, out, sp, claims, GK_TARGS);
+        Kmer<W> key[KEYS_PER_THREAD];
+        load_chunk<W, 1, PBLOCK>(key, keys, a, 0u, 0ull, begin, cnt);
+        scatter_chunk<W, 1, false, PBLOCK>(key, cnt, t, 256u, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a, 0, out, sp, claims, GK_TARGS);
     }
     if (sp.set) block_add_global(claims, &L.off[0], sp.claims);
 }
@@ -397,10 +415,19 @@ __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_keys(const u64 *__rest
 #define GK_OP_CAP 5632
 #endif
 static constexpr int OP_CAP = GK_OP_CAP;    // LDS key buffer, in 64-bit words (5632: 2 workgroups per CU)
-static constexpr int OP_TILE_READS = 128;
+#ifndef GK_OP_TILE_READS
+#define GK_OP_TILE_READS 128
+#endif
+static constexpr int OP_TILE_READS = GK_OP_TILE_READS;
 static constexpr int OP_TILE_WORDS = OP_TILE_READS * 65 / 4 + 64;
-template <int W, int NT>
-__global__ __launch_bounds__(NT) void k_op_scatter1_reads(const uint8_t *__restrict__ rec, u64 nreads, u32 stride, int k, int group,
+// SORTED: the write-out walks the tile's keys in BUCKET order (a u16 permutation built in LDS), so that consecutive lanes store
+// consecutive addresses of a bucket's run (a tile holds ~22 keys per bucket): a store instruction then touches a handful of
+// lines instead of 64.  The unsorted form stores in window order, every lane into another bucket.
+#ifndef GK_OP_MIN_WAVES
+#define GK_OP_MIN_WAVES 1
+#endif
+template <int W, int NT, bool SORTED>
+__global__ __launch_bounds__(NT, GK_OP_MIN_WAVES) void k_op_scatter1_reads(const uint8_t *__restrict__ rec, u64 nreads, u32 stride, int k, int group,
                                                               int rs /* reads per tile */, int max_len, int exact_len, Table<W> t, PartArrays a,
                                                               Sampler sp, Counters *ctr, u64 *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) u32 tile[OP_TILE_WORDS];
@@ -408,10 +435,15 @@ __global__ __launch_bounds__(NT) void k_op_scatter1_reads(const uint8_t *__restr
     __shared__ uint16_t fbin[OP_CAP / W];      // 0xffff = hole (bucket ids use all 256 byte values)
     __shared__ u32 hist[256], rank[256], lim[256];
     __shared__ unsigned long long gb[256];
+    __shared__ uint16_t perm[SORTED ? OP_CAP / W : 1];
+    __shared__ u32 wsum[NT / 64];
     u32 occ = 0, claims = 0;
     const int nk_max = max_len - k + 1;         // the host sized rs so that rs * nk_max keys fit `flat`; lengths are clamped to max_len
     const u64 ntiles = (nreads + rs - 1) / rs;
     const WindowLimits wl{max_len, &ctr->format, exact_len};
+    // (Tried and dropped, round 2: requesting the NEXT tile's record bytes into registers before the extraction and parking
+    //  them in the LDS tile after it.  The staging share of the phase timers fell from 14.5 % to 10.5 %, the kernel went from
+    //  0.585 to 0.639 ms.  Smaller tiles with more workgroups per CU lose as well: 0.75 ms at 4224 keys, 1.05 ms at 2816.)
     GK_T0();
     for (u64 tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
         const u64 r0 = tl * rs;
@@ -447,17 +479,36 @@ __global__ __launch_bounds__(NT) void k_op_scatter1_reads(const uint8_t *__restr
                 fit = at >= a.cap1 ? 0u : (u32)min((unsigned long long)c, a.cap1 - at);
             }
             lim[threadIdx.x] = fit;
+            if (SORTED) rank[threadIdx.x] = c;
         }
         __syncthreads();
         GK_TICK(3);
-        for (u32 i = threadIdx.x; i < nflat; i += NT) {
-            const u32 b = fbin[i];
-            if (b == 0xffff) continue;
-            const u32 j = atomicAdd(&rank[b], 1u);
-            const Kmer<W> x = load_key<W>(flat, i);
-            if (j < lim[b]) store_key<W>(out, l1_slot(a, b, gb[b] + j), x);
-            else if constexpr (W == 1) spill_key<1>(a, x.lo, 0);
-            else spill_key<2>(a, x.lo, x.hi);
+        if constexpr (SORTED) {
+            block_scan_inplace<NT>(rank, 256u, wsum);               // rank[b] = first sorted position of bucket b
+            for (u32 i = threadIdx.x; i < nflat; i += NT) {
+                const u32 b = fbin[i];
+                if (b != 0xffff) perm[atomicAdd(&rank[b], 1u)] = (uint16_t)i;      // rank[b] ends as the END of bucket b
+            }
+            __syncthreads();
+            const u32 ntot = rank[255];
+            for (u32 pos = threadIdx.x; pos < ntot; pos += NT) {
+                const u32 i = perm[pos], b = fbin[i];
+                const u32 j = pos - (b ? rank[b - 1] : 0u);
+                const Kmer<W> x = load_key<W>(flat, i);
+                if (j < lim[b]) store_key<W>(out, l1_slot(a, b, gb[b] + j), x);
+                else if constexpr (W == 1) spill_key<1>(a, x.lo, 0);
+                else spill_key<2>(a, x.lo, x.hi);
+            }
+        } else {
+            for (u32 i = threadIdx.x; i < nflat; i += NT) {
+                const u32 b = fbin[i];
+                if (b == 0xffff) continue;
+                const u32 j = atomicAdd(&rank[b], 1u);
+                const Kmer<W> x = load_key<W>(flat, i);
+                if (j < lim[b]) store_key<W>(out, l1_slot(a, b, gb[b] + j), x);
+                else if constexpr (W == 1) spill_key<1>(a, x.lo, 0);
+                else spill_key<2>(a, x.lo, x.hi);
+            }
         }
         GK_TICK(4);
     }
@@ -603,32 +654,66 @@ __global__ __launch_bounds__(NT) void k_part_scatter2(const u64 *__restrict__ bu
     constexpr u32 TILE = NT * KEYS_PER_THREAD;          // keys this workgroup sorts at a time (ranges and the chunk table stay in TILE2 units)
     // chunk / range table and L1 bucket extents: LDS copies (the binary search below was eight dependent global
     // loads per chunk: 16 % of the kernel by the phase timers)
-    __shared__ unsigned long long s_ubase[257], s_l1n[256];
+    __shared__ unsigned long long s_ubase[257], s_l1n[256], s_l1b[256];
     for (u32 b = threadIdx.x; b < 257u; b += NT) s_ubase[b] = RANGED ? a.rbase[b] : a.cbase[b];
-    for (u32 b = threadIdx.x; b < 256u; b += NT) s_l1n[b] = b < (1u << t.lnb1) ? l1_count(a, b) : 0ull;
+    for (u32 b = threadIdx.x; b < 256u; b += NT) {
+        s_l1n[b] = b < (1u << t.lnb1) ? l1_count(a, b) : 0ull;
+        s_l1b[b] = l1_begin(a, b);
+    }
     __syncthreads();
     const u64 total = min((u64)s_ubase[256], max_units);
     const Sampler nosp{nullptr, 0, nullptr};
     u32 noclaims = 0;
     GK_T0();
+    // Software pipeline: a chunk is a chain global load -> LDS sort -> global store with six barriers in between, and two or
+    // three workgroups per CU do not cover the load's round trip (phase timers: 46 % of the kernel was the load and the
+    // barrier behind it).  The NEXT chunk's keys are requested into a second register set before the current chunk is
+    // sorted (see scatter_chunk's prefetch hook); the two sets swap roles from chunk to chunk (a copy would wait for
+    // the loads at once).
     if constexpr (RANGED) {
+        // (the exact fine level keeps the plain form: it has no atomics, hence nothing in a chunk that waits on vmcnt but the
+        //  loads themselves; measured at C3 and at C2 with fine_exact = 1, the prefetching form is 3-7 % SLOWER there)
         for (u64 r = blockIdx.x; r < total; r += gridDim.x) {
             const RangeGeom g = range_geom(s_ubase, s_l1n, r, a.range_chunks);
             const u64 bin0 = (u64)g.b1 * t.nb2;
             const u32 *row = a.rmat + r * t.nb2;
             for (u32 b = threadIdx.x; b < t.nb2; b += NT) L.gb[b] = a.fine_base[bin0 + b] + row[b];
-            for (u32 cb = 0; cb < g.cnt; cb += TILE)           // (scatter_chunk opens with a barrier: gb[] is visible)
-                scatter_chunk<W, 2, true, NT>(bufA, g.b1, g.begin + cb, min(TILE, g.cnt - cb), t, t.nb2, L.sorted, L.binof, L.off, L.lim,
-                                          L.gb, L.wsum, a, bin0, bufB, nosp, noclaims, GK_TARGS);
+            for (u32 cb = 0; cb < g.cnt; cb += TILE) {          // (scatter_chunk opens with a barrier: gb[] is visible)
+                Kmer<W> key[KEYS_PER_THREAD];
+                load_chunk<W, 2, NT>(key, bufA, a, g.b1, s_l1b[g.b1], g.begin + cb, min(TILE, g.cnt - cb));
+                scatter_chunk<W, 2, true, NT>(key, min(TILE, g.cnt - cb), t, t.nb2, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a, bin0, bufB,
+                                              nosp, noclaims, GK_TARGS);
+            }
             __syncthreads();
         }
     } else {
-        for (u64 c = blockIdx.x; c < total; c += gridDim.x) {
-            const u32 b1 = chunk_bucket(s_ubase, c);
-            const u64 begin = (c - s_ubase[b1]) * TILE;
-            const u32 cnt = (u32)min((u64)TILE, s_l1n[b1] - begin);
-            scatter_chunk<W, 2, false, NT>(bufA, b1, begin, cnt, t, t.nb2, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a,
-                                       (u64)b1 * t.nb2, bufB, nosp, noclaims, GK_TARGS);
+        struct Pos { u64 c; u32 b1; u64 begin; u32 cnt; };
+        auto geom = [&](u64 c) {
+            Pos p{c, 0u, 0ull, 0u};
+            if (c < total) {
+                p.b1 = chunk_bucket(s_ubase, c);
+                p.begin = (c - s_ubase[p.b1]) * TILE;
+                p.cnt = (u32)min((u64)TILE, s_l1n[p.b1] - p.begin);
+            }
+            return p;
+        };
+        auto request = [&](Kmer<W> (&kk)[KEYS_PER_THREAD], const Pos &p) {
+            if (p.c < total) load_chunk<W, 2, NT>(kk, bufA, a, p.b1, s_l1b[p.b1], p.begin, p.cnt);
+        };
+        Pos cur = geom(blockIdx.x);
+        auto step = [&](Kmer<W> (&kc)[KEYS_PER_THREAD], Kmer<W> (&kn)[KEYS_PER_THREAD]) {
+            const Pos nxt = geom(cur.c + gridDim.x);
+            scatter_chunk<W, 2, false, NT>(kc, cur.cnt, t, t.nb2, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a, (u64)cur.b1 * t.nb2, bufB,
+                                           nosp, noclaims, GK_TARGS, [&]() { request(kn, nxt); });
+            cur = nxt;
+        };
+        Kmer<W> keyA[KEYS_PER_THREAD], keyB[KEYS_PER_THREAD];
+        request(keyA, cur);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0), once: both halves of the loop then know their keys are in
+        while (cur.c < total) {
+            step(keyA, keyB);
+            if (cur.c >= total) break;
+            step(keyB, keyA);
         }
     }
     GK_TFLUSH(8);
@@ -1082,13 +1167,20 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         const u64 ntiles = (src.nreads + rs - 1) / rs;
         const int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)ctx->cu_count * 2);
         const bool p2_wide = ctx->hook_p2_wide > 0;        // 1024 threads per tile: A/B option (gk_ctx_set_option "p2_wide")
+        const bool p2_sorted = ctx->hook_p2_sorted > 0;    // bucket-ordered write-out: A/B option ("p2_sorted")
+        const int vu = src.verify_uniform ? 1 : 0;
+        auto launch_p2 = [&](int g, const uint8_t *recs, u64 nr) {
+#define GK_P2(NT, SORTED)                                                                                                                 \
+    hipLaunchKernelGGL((k_op_scatter1_reads<W, NT, SORTED>), dim3(g), dim3(NT), 0, ctx->stream, recs, nr, src.stride, m->k, src.group, rs, \
+                       src.max_len, vu, t, a, sp, m->d_ctr, ps->bufA)
+            if (p2_wide && p2_sorted) GK_P2(1024, true);
+            else if (p2_wide) GK_P2(1024, false);
+            else if (p2_sorted) GK_P2(PBLOCK, true);
+            else GK_P2(PBLOCK, false);
+#undef GK_P2
+        };
         if (!src.host) {
-            if (p2_wide)
-                hipLaunchKernelGGL((k_op_scatter1_reads<W, 1024>), dim3(grid), dim3(1024), 0, ctx->stream, d_rec, src.nreads, src.stride, m->k, src.group, rs,
-                                   src.max_len, src.verify_uniform ? 1 : 0, t, a, sp, m->d_ctr, ps->bufA);
-            else
-                hipLaunchKernelGGL((k_op_scatter1_reads<W, PBLOCK>), dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, src.nreads, src.stride, m->k, src.group, rs,
-                                   src.max_len, src.verify_uniform ? 1 : 0, t, a, sp, m->d_ctr, ps->bufA);
+            launch_p2(grid, d_rec, src.nreads);
         } else {
             // Host-fed: upload in sub-chunks on the copy stream, scatter each as soon as it has landed.  The L1 regions are
             // append-only (cursor1), so P2 can run once per sub-chunk; P4 and P5 then see one batch.  With the caller's buffer
@@ -1108,12 +1200,7 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
                 GK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ev, 0));
                 const u64 nt = (nr + rs - 1) / rs;
                 const int gsub = (int)std::min<u64>(std::max<u64>(nt, 1), (u64)ctx->cu_count * 2);
-                if (p2_wide)
-                    hipLaunchKernelGGL((k_op_scatter1_reads<W, 1024>), dim3(gsub), dim3(1024), 0, ctx->stream, d_rec + off, nr, src.stride, m->k, src.group, rs,
-                                       src.max_len, src.verify_uniform ? 1 : 0, t, a, sp, m->d_ctr, ps->bufA);
-                else
-                    hipLaunchKernelGGL((k_op_scatter1_reads<W, PBLOCK>), dim3(gsub), dim3(PBLOCK), 0, ctx->stream, d_rec + off, nr, src.stride, m->k, src.group, rs,
-                                       src.max_len, src.verify_uniform ? 1 : 0, t, a, sp, m->d_ctr, ps->bufA);
+                launch_p2(gsub, d_rec + off, nr);
             }
         }
     } else if (d_rec) {

@@ -228,6 +228,56 @@ __global__ __launch_bounds__(BLOCK) void k_skm_route(const uint8_t *__restrict__
     if (threadIdx.x < (u32)P && h_kmer[threadIdx.x]) atomicAdd(&kmer_counts[threadIdx.x], (unsigned long long)h_kmer[threadIdx.x]);
 }
 
+namespace gk {
+// The routing kernel, launched on `st` with its counters in d_counts (SKM_COUNT_WORDS words: cursors, k-mer counts, overflow)
+// and their copy-back to h_counts queued behind it; nothing is waited for.  skm_route_finish reads h_counts once the stream
+// has been synchronised.  (gk_dist routes batch i+1 on a second stream while the owner pipeline of batch i runs.)
+int skm_route_launch(gk_ctx *ctx, hipStream_t st, unsigned long long *d_counts, unsigned long long *h_counts, int k, const void *dev_records,
+                     uint64_t nreads, int read_len, int P, void *dev_out, uint64_t out_cap_records) {
+    if (!k_supported(k)) return fail(ctx, GK_E_UNSUPPORTED_K, "k=" + std::to_string(k) + " unsupported");
+    if (P < 1 || P > MAX_PARTS) return fail(ctx, GK_E_INVALID, "P must be 1.." + std::to_string(MAX_PARTS));
+    if (!dev_records && nreads) return fail(ctx, GK_E_INVALID, "null argument");
+    if (read_len < 0 || read_len > 255) return fail(ctx, GK_E_FORMAT, "read_len must be 0..255");
+    GK_HIP(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < SKM_COUNT_WORDS; i++) h_counts[i] = 0;
+    const u64 nk = read_len >= k ? (u64)(read_len - k + 1) : 0;
+    if (nreads == 0 || nk == 0) return GK_OK;
+    if (!dev_out) return fail(ctx, GK_E_INVALID, "null record buffer");
+    const u64 region_cap = out_cap_records / (u64)P;
+    if (region_cap == 0) return fail(ctx, GK_E_CAPACITY, "record buffer too small: out_cap_records must be at least P");
+    GK_HIP(ctx, hipMemsetAsync(d_counts, 0, SKM_COUNT_WORDS * sizeof(unsigned long long), st));
+    const u32 stride = 1 + (read_len + 3) / 4;
+    const u64 ntiles = (nreads + TILE_READS - 1) / TILE_READS;
+    const int grid = (int)std::min<u64>(ntiles, (u64)ctx->cu_count * 6);
+    const uint8_t *rec = (const uint8_t *)dev_records;
+    u32 *d_overflow = reinterpret_cast<u32 *>(d_counts + 2 * MAX_PARTS);
+    if (skm_slot_bytes(k) == 16)
+        hipLaunchKernelGGL(k_skm_route<16>, dim3(grid), dim3(BLOCK), 0, st, rec, nreads, stride, k, P, WindowLimits{read_len, ctx->d_flags}, region_cap, d_counts,
+                           d_counts + MAX_PARTS, d_overflow, (uint8_t *)dev_out);
+    else
+        hipLaunchKernelGGL(k_skm_route<32>, dim3(grid), dim3(BLOCK), 0, st, rec, nreads, stride, k, P, WindowLimits{read_len, ctx->d_flags}, region_cap, d_counts,
+                           d_counts + MAX_PARTS, d_overflow, (uint8_t *)dev_out);
+    GK_HIP(ctx, hipGetLastError());
+    GK_HIP(ctx, hipMemcpyAsync(h_counts, d_counts, SKM_COUNT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    return GK_OK;
+}
+int skm_route_finish(gk_ctx *ctx, const unsigned long long *h, bool launched, int P, uint64_t out_cap_records, uint64_t *rec_counts_host,
+                     uint64_t *kmer_counts_host) {
+    const u64 region_cap = out_cap_records / (u64)std::max(P, 1);
+    unsigned long long worst = 0;
+    for (int p = 0; p < P; p++) {
+        rec_counts_host[p] = h[p];
+        kmer_counts_host[p] = h[MAX_PARTS + p];
+        worst = std::max(worst, h[p]);
+    }
+    if (!launched) return GK_OK;
+    if ((u32)h[2 * MAX_PARTS] || worst > region_cap)
+        return fail(ctx, GK_E_CAPACITY, "record buffer too small: the fullest owner region needs " + std::to_string(worst) +
+                                            " records, out_cap_records / P = " + std::to_string(region_cap));
+    return ctx_check_format(ctx);
+}
+}  // namespace gk
+
 extern "C" {
 
 int gk_skm_slot_bytes(int k) { return k_supported(k) ? skm_slot_bytes(k) : 0; }
@@ -235,45 +285,12 @@ int gk_skm_slot_bytes(int k) { return k_supported(k) ? skm_slot_bytes(k) : 0; }
 int gk_shard_superkmers_dev(gk_ctx *ctx, int k, const void *dev_records, uint64_t nreads, int read_len, int P,
                             void *dev_out, uint64_t out_cap_records, uint64_t *rec_counts_host, uint64_t *kmer_counts_host) {
     if (!ctx) return fail(nullptr, GK_E_INVALID, "null ctx");
-    if (!k_supported(k)) return fail(ctx, GK_E_UNSUPPORTED_K, "k=" + std::to_string(k) + " unsupported");
-    if (P < 1 || P > MAX_PARTS) return fail(ctx, GK_E_INVALID, "P must be 1.." + std::to_string(MAX_PARTS));
-    if (!rec_counts_host || !kmer_counts_host || (!dev_records && nreads)) return fail(ctx, GK_E_INVALID, "null argument");
-    if (read_len < 0 || read_len > 255) return fail(ctx, GK_E_FORMAT, "read_len must be 0..255");
-    GK_HIP(ctx, hipSetDevice(ctx->device));
-    for (int p = 0; p < P; p++) { rec_counts_host[p] = 0; kmer_counts_host[p] = 0; }
-    const u64 nk = read_len >= k ? (u64)(read_len - k + 1) : 0;
-    if (nreads == 0 || nk == 0) return GK_OK;
-    if (!dev_out) return fail(ctx, GK_E_INVALID, "null record buffer");
-    const u64 region_cap = out_cap_records / (u64)P;
-    if (region_cap == 0) return fail(ctx, GK_E_CAPACITY, "record buffer too small: out_cap_records must be at least P");
-    if (!ctx->skm_counts) GK_HIP(ctx, hipMalloc(&ctx->skm_counts, (2 * MAX_PARTS + 1) * sizeof(unsigned long long)));
-    unsigned long long *tls_counts = (unsigned long long *)ctx->skm_counts;   // [2 * MAX_PARTS + 1]: cursors, k-mer counts, overflow
-    GK_HIP(ctx, hipMemsetAsync(tls_counts, 0, (2 * MAX_PARTS + 1) * sizeof(unsigned long long), ctx->stream));
-    const u32 stride = 1 + (read_len + 3) / 4;
-    const u64 ntiles = (nreads + TILE_READS - 1) / TILE_READS;
-    const int grid = (int)std::min<u64>(ntiles, (u64)ctx->cu_count * 6);
-    const uint8_t *rec = (const uint8_t *)dev_records;
-    u32 *d_overflow = reinterpret_cast<u32 *>(tls_counts + 2 * MAX_PARTS);
-    if (skm_slot_bytes(k) == 16)
-        hipLaunchKernelGGL(k_skm_route<16>, dim3(grid), dim3(BLOCK), 0, ctx->stream, rec, nreads, stride, k, P, WindowLimits{read_len, ctx->d_flags}, region_cap, tls_counts,
-                           tls_counts + MAX_PARTS, d_overflow, (uint8_t *)dev_out);
-    else
-        hipLaunchKernelGGL(k_skm_route<32>, dim3(grid), dim3(BLOCK), 0, ctx->stream, rec, nreads, stride, k, P, WindowLimits{read_len, ctx->d_flags}, region_cap, tls_counts,
-                           tls_counts + MAX_PARTS, d_overflow, (uint8_t *)dev_out);
-    GK_HIP(ctx, hipGetLastError());
-    unsigned long long h[2 * MAX_PARTS + 1];
-    GK_HIP(ctx, hipMemcpyAsync(h, tls_counts, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    if (!rec_counts_host || !kmer_counts_host) return fail(ctx, GK_E_INVALID, "null argument");
+    if (!ctx->skm_counts) GK_HIP(ctx, hipMalloc(&ctx->skm_counts, SKM_COUNT_WORDS * sizeof(unsigned long long)));
+    unsigned long long h[SKM_COUNT_WORDS];
+    if (int rc = skm_route_launch(ctx, ctx->stream, (unsigned long long *)ctx->skm_counts, h, k, dev_records, nreads, read_len, P, dev_out, out_cap_records)) return rc;
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    unsigned long long worst = 0;
-    for (int p = 0; p < P; p++) {
-        rec_counts_host[p] = h[p];
-        kmer_counts_host[p] = h[MAX_PARTS + p];
-        worst = std::max(worst, h[p]);
-    }
-    if ((u32)h[2 * MAX_PARTS] || worst > region_cap)
-        return fail(ctx, GK_E_CAPACITY, "record buffer too small: the fullest owner region needs " + std::to_string(worst) +
-                                            " records, out_cap_records / P = " + std::to_string(region_cap));
-    return ctx_check_format(ctx);
+    return skm_route_finish(ctx, h, nreads && read_len >= k, P, out_cap_records, rec_counts_host, kmer_counts_host);
 }
 
 }  // extern "C"

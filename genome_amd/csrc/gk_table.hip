@@ -462,6 +462,7 @@ int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value) {
         ctx->hook_unitigs = (int)value;
     } else if (n == "p4_direct") ctx->hook_p4_direct = value < 0 ? -1 : value != 0;
     else if (n == "p2_wide") ctx->hook_p2_wide = value < 0 ? -1 : value != 0;
+    else if (n == "p2_sorted") ctx->hook_p2_sorted = value < 0 ? -1 : value != 0;
     else if (n == "p4_wide") ctx->hook_p4_wide = value < 0 ? -1 : value != 0;
     else if (n == "fine_exact") ctx->hook_fine_exact = value < 0 ? -1 : value != 0;
     else return fail(ctx, GK_E_INVALID, "gk_ctx_set_option: unknown option '" + n + "'");

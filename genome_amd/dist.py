@@ -54,7 +54,7 @@ class HipDist:
     def last_ms(self):
         ms = (C.c_float * 4)()
         L.check(L.lib().gk_dist_last_ms(self.h, ms), self.ctx.h)
-        return dict(zip(("route", "exchange", "owner_count", "total"), (float(x) for x in ms)))
+        return dict(zip(("route_wait", "exchange", "owner_count", "total"), (float(x) for x in ms)))
 
 
 class DistDNAMap:
@@ -71,6 +71,17 @@ class DistDNAMap:
         """FreqFilter.add over this rank's reads -> (windows sent, windows this rank counted as owner)."""
         sent, owned = C.c_uint64(), C.c_uint64()
         L.check(L.lib().gk_dist_count_reads_dev(self.dist.h, self.local.h, d_records, nreads, read_len, C.byref(sent), C.byref(owned)), self.ctx.h)
+        return sent.value, owned.value
+
+    def route_begin(self, d_records: int, nreads: int, read_len: int):
+        """First half of count_reads_dev, asynchronous: route the batch on the second stream.  Call it for batch i+1 before
+        count_routed() of batch i and the routing kernel hides behind the owner pipeline."""
+        L.check(L.lib().gk_dist_route_begin(self.dist.h, self.k, d_records, nreads, read_len), self.ctx.h)
+
+    def count_routed(self):
+        """Second half: exchange and count the batch route_begin started -> (windows sent, windows counted as owner)."""
+        sent, owned = C.c_uint64(), C.c_uint64()
+        L.check(L.lib().gk_dist_count_routed(self.dist.h, self.local.h, C.byref(sent), C.byref(owned)), self.ctx.h)
         return sent.value, owned.value
 
     def size(self) -> int:                                    # PartitionedDNAMap.scala:31

@@ -200,6 +200,15 @@ class PartitionedDNAMap {
         check(gk_dist_count_reads_dev(d_, local_.handle(), devRecords, nreads, readLen, &sent, &owned), ctx_.handle());
         return {sent, owned};
     }
+    // the same in two halves for a streaming loop: routeBegin(batch i+1) before countRouted() of batch i
+    void routeBegin(const void *devRecords, uint64_t nreads, int readLen) {
+        check(gk_dist_route_begin(d_, local_.k(), devRecords, nreads, readLen), ctx_.handle());
+    }
+    std::pair<uint64_t, uint64_t> countRouted() {
+        uint64_t sent = 0, owned = 0;
+        check(gk_dist_count_routed(d_, local_.handle(), &sent, &owned), ctx_.handle());
+        return {sent, owned};
+    }
     uint64_t size() {                                              // :31
         uint64_t n = 0;
         check(gk_dist_size(d_, local_.handle(), &n), ctx_.handle());

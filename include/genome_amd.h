@@ -64,8 +64,8 @@ int gk_ctx_sync(gk_ctx *ctx);                    /* hipStreamSynchronize on the 
 /* Test / A-B switches (never needed in production).  Their defaults are read from the environment ONCE, in
  * gk_ctx_create (GK_TEST_NO_RESERVE, GK_HOST_RAGGED, GK_PART_EXACT, GK_GRAPH_UNITIGS=walk|pj); no entry point
  * consults the environment afterwards.  Names: "test_no_reserve", "host_ragged", "part_exact" (0/1),
- * "graph_unitigs" (0 auto, 1 one lane per edge, 2 pointer jumping), "p4_direct" / "fine_exact" (-1 auto, 0, 1: A/B of the
- * partitioned insert's fine level, gk_partition.hip). */
+ * "graph_unitigs" (0 auto, 1 one lane per edge, 2 pointer jumping), "p4_direct" / "fine_exact" / "p4_wide" / "p2_wide" /
+ * "p2_sorted" (-1 auto, 0, 1: A/B of the partitioned insert's kernels, gk_partition.hip). */
 int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value);
 /* Pinned host memory: gk_map_count_reads / gk_prefilter_add_reads read the caller's `.bin` buffer with asynchronous copies
  * that overlap the insert kernels only if the buffer is page-locked — allocate it here, or register an existing one (a JNI
@@ -234,7 +234,16 @@ int gk_dist_allreduce_f64(gk_dist *d, double *values, int n, int op_max);
  * *occurrences_sent = windows of this rank's reads, *occurrences_owned = windows this rank counted (sums over ranks agree). */
 int gk_dist_count_reads_dev(gk_dist *d, gk_map *local, const void *dev_records, uint64_t nreads, int read_len,
                             uint64_t *occurrences_sent, uint64_t *occurrences_owned);
-/* wall ms of the last gk_dist_count_reads_dev on this rank: {route, exchange, owner count, total} */
+/* The same in two halves, for a streaming loop: gk_dist_route_begin launches the routing of a batch on the context's second
+ * stream and returns at once; gk_dist_count_routed waits for it, exchanges and counts.  Calling route_begin for batch i+1
+ * BEFORE count_routed for batch i overlaps the routing kernel with the owner pipeline (send buffers are double-buffered).
+ * The records of a begun batch must stay valid until its count_routed returns.  At most two batches may be begun and not
+ * yet counted (GK_E_STATE otherwise; count_routed with none begun is GK_E_STATE too); they are counted first in, first out:
+ * begin(0), [begin(i+1), count_routed(i)]*, count_routed(last).  A malformed record in a begun batch (GK_E_FORMAT) may be
+ * reported by whichever count call on the context checks the flags next. */
+int gk_dist_route_begin(gk_dist *d, int k, const void *dev_records, uint64_t nreads, int read_len);
+int gk_dist_count_routed(gk_dist *d, gk_map *local, uint64_t *occurrences_sent, uint64_t *occurrences_owned);
+/* wall ms of the last gk_dist_count_routed on this rank: {waiting for the route, exchange, owner count, total} */
 int gk_dist_last_ms(gk_dist *d, float *ms4);
 int gk_dist_size(gk_dist *d, gk_map *local, uint64_t *total);         /* PartitionedDNAMap.size (:31): sum over the partitions */
 /* deleteAll / filter_lt, stats, export are LOCAL: call gk_map_filter_lt etc. on `local` on every rank (:49-51 scatter, no data moves). */

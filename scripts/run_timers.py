@@ -8,6 +8,10 @@ from genome_amd import synth, _lib
 from genome_amd.dnamap import Context, HipDNAMap, skm_slot_bytes
 n, L, k, steps = 1_000_000, 150, 31, 5
 ctx = Context(0)
+for o in sys.argv[1:]:                      # name=value context options (gk_ctx_set_option), e.g. p2_sorted=1
+    nm, val = o.split("=")
+    ctx.set_option(nm, int(val))
+print("options:", sys.argv[1:])
 d = ctx.alloc(n * synth.record_stride(L) + 64)
 ctx.synth_reads(d, n, L, "U", 2, 0, 0, 0.0)
 lib = _lib.lib()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn the PMC passes of scripts/profile_round.sh <tag> (gpurun_out/<tag>_pmc_{fetch,write,req}) into
-profiles/r01/pmc_pipeline_<tag>.json (the file bench.py reads `roofline.traffic` from) and copy the raw
+profiles/r02/pmc_pipeline_<tag>.json (the file bench.py reads `roofline.traffic` from) and copy the raw
 counter CSVs, the kernel stats and the bench line next to it.  Corrections: FETCH_SIZE x2 (gfx950 tallies
 128-B read requests at 64 B; calibrated on k_part_hist2 in v3/v4), WRITE_SIZE as reported; both are
 counted in KiB-like units of 1024 B by rocprofv3 (`*_SIZE` counters are KB)."""
@@ -14,7 +14,7 @@ import sys
 
 tag = sys.argv[1]
 note = sys.argv[2] if len(sys.argv) > 2 else ""
-out_dir = "profiles/r01"
+out_dir = sys.argv[3] if len(sys.argv) > 3 else "profiles/r02"
 PIPE = ("k_op_scatter1_reads", "k_part_hist1_reads", "k_part_scatter1_reads", "k_part_hist2", "k_part_scatter2", "k_seg_insert")
 
 

@@ -1,8 +1,6 @@
 #!/bin/bash
-# usage: build genome_amd/variants/<name>.so with -DGK_TIMERS (see sweep_variants.sh), then: sweep_timers.sh <name>...
-R=$GRAFT_REPO_ROOT; cp $R/genome_amd/libgenome_amd.so /tmp/orig.so
+# usage: build genome_amd/variants/<name>.so with -DGK_TIMERS (scripts/build_variant.sh <name> -DGK_TIMERS), then: sweep_timers.sh <name>...
+R=$GRAFT_REPO_ROOT
 for v in "$@"; do
-  cp $R/genome_amd/variants/$v.so $R/genome_amd/libgenome_amd.so
-  echo "== $v"; python3 $R/scripts/run_timers.py || exit 1
+  echo "== $v"; GK_LIB_PATH=$R/genome_amd/variants/$v.so python3 $R/scripts/run_timers.py || exit 1
 done
-cp /tmp/orig.so $R/genome_amd/libgenome_amd.so

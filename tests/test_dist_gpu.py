@@ -64,6 +64,42 @@ def test_one_rank_communicator_matches_oracle(dist, k, L_):
     g.close(); full.close(); pm.close(); ctx.free(d)
 
 
+@pytest.mark.parametrize("k,L_", [(31, 150), (47, 120)])
+def test_streaming_route_begin_count_routed(dist, k, L_):
+    """The two-halves form of FreqFilter.add over a partitioned map: the route of batch i+1 is launched before batch i is
+    exchanged and counted (two send buffers).  Same table as one count over all the reads."""
+    ctx = dist.ctx
+    n, nb = 40000, 4
+    rec = synth.reads_mode_g(n, L_, 60000, 0.01, config_id=500 + k)
+    d = ctx.alloc(rec.size + 64)
+    ctx.upload(d, rec)
+    ref = O.PMap(k, 1)
+    occ = ref.count_reads(rec.tobytes(), n)
+    pm = DistDNAMap(dist, k, 1 << 10)                # small hint: the table also grows while routes are in flight
+    per = n // nb
+    at = lambda i: d + i * per * rec.shape[1]
+    with pytest.raises(L.GkError) as e:
+        pm.count_routed()                            # nothing begun
+    assert e.value.code == L.GK_E_STATE
+    pm.route_begin(at(0), per, L_)
+    tot_s = tot_o = 0
+    for i in range(nb):
+        if i + 1 < nb:
+            pm.route_begin(at(i + 1), per, L_)
+            if i == 0:
+                with pytest.raises(L.GkError) as e:
+                    pm.route_begin(at(2), per, L_)   # a third one: both send buffers are taken
+                assert e.value.code == L.GK_E_STATE
+        s_, o_ = pm.count_routed()
+        tot_s += s_; tot_o += o_
+    assert tot_s == tot_o == occ
+    assert pm.size() == ref.size()
+    for a, b in zip(pm.local.sorted_items(), ref.export_sorted()):
+        assert np.array_equal(a, b)
+    assert pm.local.verify()[1] == 0
+    pm.close(); ctx.free(d)
+
+
 def test_collectives_and_errors(dist):
     assert np.array_equal(dist.allreduce([1.5, 2.5, -3.0]), [1.5, 2.5, -3.0])
     assert np.array_equal(dist.allreduce([4.0], "max"), [4.0])
