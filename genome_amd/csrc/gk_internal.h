@@ -13,6 +13,7 @@ struct gk_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // phase boundaries of the partitioned path
+    hipEvent_t gev2 = nullptr;                    // joins the second stream back into the first (striped P4/P5)
     hipEvent_t gev = nullptr;                     // "the host is back": the fine level's first launch (the GPU idles from pev[2] to here)
     hipStream_t copy_stream = nullptr;            // host -> device copies that overlap kernels on `stream` (host-fed inserts)
     hipEvent_t cev[16] = {};                      // "sub-chunk j has landed" (round robin)
@@ -26,6 +27,8 @@ struct gk_ctx {
     int hook_p4_direct = -1;         // exact fine level: -1 auto (by nb2), 0 chunk sorted in LDS, 1 straight scatter with per-range cursors
     int hook_p2_wide = -1;           // over-provisioned L1 scatter: 1 = 1024 threads per tile (A/B)
     int hook_p2_sorted = -1;         // over-provisioned L1 scatter: 1 = bucket-ordered write-out (A/B)
+    int hook_p45_stripes = -1;       // over-provisioned fine level: stripes of L1 buckets whose P5 overlaps the next stripe's P4 (-1/1: none)
+    int hook_p4_grid = -1;           // over-provisioned fine level: P4 workgroups per CU (-1: 4, or 2 of the 1024-thread form)
     int hook_p4_wide = -1;           // exact fine level, 8-byte keys: -1 auto (by nb2), 0 sort 4096 keys at a time, 1 sort 8192 (1024 threads)
     int hook_fine_exact = -1;        // -1 auto, 0 never unless forced by the data path, 1 always (A/B of the two fine levels)
     std::string err;
@@ -65,6 +68,10 @@ struct gk_map {
     uint32_t nb2 = 1, lnb1 = 0;  // segment geometry (gk::Table)
     void *slots = nullptr;       // Slot<W>[capacity]
     gk::Counters *d_ctr = nullptr;
+    // pinned host landing area of the small device->host reads a batch ends with: [Counters][PartStatus] (a copy into
+    // pageable memory is staged and synchronous: five of them cost 0.12 ms of a 2.1 ms step)
+    unsigned char *h_status = nullptr;
+    uint64_t occ_cached = 0;     // d_ctr->occurrences as of the last map_sync_counters (every launch path ends with one)
     uint64_t size = 0;           // host mirror of d_ctr->size (valid after every public call)
     uint64_t tombstones = 0;
     uint64_t total_occurrences = 0;

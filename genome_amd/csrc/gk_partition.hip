@@ -426,6 +426,9 @@ static constexpr int OP_TILE_WORDS = OP_TILE_READS * 65 / 4 + 64;
 #ifndef GK_OP_MIN_WAVES
 #define GK_OP_MIN_WAVES 1
 #endif
+#ifndef GK_OP_WGS_PER_CU
+#define GK_OP_WGS_PER_CU 2          // workgroups of the persistent grid per CU: what the LDS tile and the VGPR count let reside
+#endif
 template <int W, int NT, bool SORTED>
 __global__ __launch_bounds__(NT, GK_OP_MIN_WAVES) void k_op_scatter1_reads(const uint8_t *__restrict__ rec, u64 nreads, u32 stride, int k, int group,
                                                               int rs /* reads per tile */, int max_len, int exact_len, Table<W> t, PartArrays a,
@@ -441,6 +444,10 @@ __global__ __launch_bounds__(NT, GK_OP_MIN_WAVES) void k_op_scatter1_reads(const
     const int nk_max = max_len - k + 1;         // the host sized rs so that rs * nk_max keys fit `flat`; lengths are clamped to max_len
     const u64 ntiles = (nreads + rs - 1) / rs;
     const WindowLimits wl{max_len, &ctr->format, exact_len};
+    // What bounds this kernel (0.60 ms per 1.2e8 windows) is NOT any one of the obvious suspects — timing-only builds, round 2
+    // (profiles/r02/p2_elimination.md): no canonical form and no hash 0.63 ms; every store into one 8 KiB run 0.57 ms; eight
+    // cursors per bucket instead of one 0.56 ms; the CU's second workgroup started half a tile late 0.60 ms; three or four
+    // smaller workgroups per CU 0.61-0.75 ms; bucket-ordered write-out ("p2_sorted") 0.60 ms.
     // (Tried and dropped, round 2: requesting the NEXT tile's record bytes into registers before the extraction and parking
     //  them in the LDS tile after it.  The staging share of the phase timers fell from 14.5 % to 10.5 %, the kernel went from
     //  0.585 to 0.639 ms.  Smaller tiles with more workgroups per CU lose as well: 0.75 ms at 4224 keys, 1.05 ms at 2816.)
@@ -500,14 +507,23 @@ __global__ __launch_bounds__(NT, GK_OP_MIN_WAVES) void k_op_scatter1_reads(const
                 else spill_key<2>(a, x.lo, x.hi);
             }
         } else {
-            for (u32 i = threadIdx.x; i < nflat; i += NT) {
-                const u32 b = fbin[i];
-                if (b == 0xffff) continue;
-                const u32 j = atomicAdd(&rank[b], 1u);
-                const Kmer<W> x = load_key<W>(flat, i);
-                if (j < lim[b]) store_key<W>(out, l1_slot(a, b, gb[b] + j), x);
-                else if constexpr (W == 1) spill_key<1>(a, x.lo, 0);
-                else spill_key<2>(a, x.lo, x.hi);
+            // four keys per thread and round: each key is a chain LDS read -> LDS atomic -> LDS reads -> store, and with
+            // four waves per SIMD one chain at a time leaves the LDS pipe idle most of the time
+            constexpr int U = 4;
+            for (u32 i0 = threadIdx.x; i0 < nflat; i0 += U * NT) {
+                u32 b[U], j[U];
+#pragma unroll
+                for (int q = 0; q < U; q++) { const u32 i = i0 + q * NT; b[q] = i < nflat ? (u32)fbin[i] : 0xffffu; }
+#pragma unroll
+                for (int q = 0; q < U; q++) j[q] = b[q] != 0xffffu ? atomicAdd(&rank[b[q]], 1u) : 0u;
+#pragma unroll
+                for (int q = 0; q < U; q++) {
+                    if (b[q] == 0xffffu) continue;
+                    const Kmer<W> x = load_key<W>(flat, i0 + q * NT);
+                    if (j[q] < lim[b[q]]) store_key<W>(out, l1_slot(a, b[q], gb[b[q]] + j[q]), x);
+                    else if constexpr (W == 1) spill_key<1>(a, x.lo, 0);
+                    else spill_key<2>(a, x.lo, x.hi);
+                }
             }
         }
         GK_TICK(4);
@@ -524,19 +540,27 @@ __global__ __launch_bounds__(256) void k_part_prefix1(PartArrays a, u32 nb1) {
     s[i] = i < nb1 ? (a.op1 ? min(a.cursor1[i], a.cap1) : a.hist1[i]) : 0;
     c[i] = (s[i] + a.chunk_keys - 1) / a.chunk_keys;                                  // P4's unit of work (over-provisioned fine level)
     r[i] = ((s[i] + TILE2 - 1) / TILE2 + a.range_chunks - 1) / a.range_chunks;        // ranges of range_chunks x TILE2 keys (exact fine level)
+    // three exclusive scans over 256 entries: inclusive inside each wave by shuffles, then the four wave totals
+    // (this kernel sits between P2 and P4 on the critical path; the serial loop it replaces took 10 us)
+    unsigned long long v = s[i], cv = c[i], rv = r[i];
+    unsigned long long iv = v, icv = cv, irv = rv;
+    const int lane = i & 63, wave = i >> 6;
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long t0 = __shfl_up(iv, d), t1 = __shfl_up(icv, d), t2 = __shfl_up(irv, d);
+        if (lane >= d) { iv += t0; icv += t1; irv += t2; }
+    }
+    __syncthreads();                       // s, c, r are read: reuse their first words for the wave totals
+    if (lane == 63) { s[wave] = iv; c[wave] = icv; r[wave] = irv; }
     __syncthreads();
-    if (i == 0) {
-        unsigned long long acc = 0, cacc = 0, racc = 0;
-        for (u32 b = 0; b < 256; b++) {
-            const unsigned long long v = s[b], cv = c[b], rv = r[b];
-            a.l1_base[b] = acc;
-            a.cbase[b] = cacc;
-            a.rbase[b] = racc;
-            acc += v; cacc += cv; racc += rv;
-        }
-        a.l1_base[256] = acc;
-        a.cbase[256] = cacc;
-        a.rbase[256] = racc;
+    unsigned long long p0 = 0, p1 = 0, p2 = 0;
+    for (int w = 0; w < wave; w++) { p0 += s[w]; p1 += c[w]; p2 += r[w]; }
+    a.l1_base[i] = p0 + iv - v;
+    a.cbase[i] = p1 + icv - cv;
+    a.rbase[i] = p2 + irv - rv;
+    if (i == 255) {
+        a.l1_base[256] = p0 + iv;
+        a.cbase[256] = p1 + icv;
+        a.rbase[256] = p2 + irv;
     }
 }
 
@@ -646,9 +670,11 @@ __global__ __launch_bounds__(256) void k_part_prefix2(PartArrays a, u32 nb1, u32
 // ---------------------------------------------------------------------------------------------
 // P4: L1 regions -> keys in segment order
 // ---------------------------------------------------------------------------------------------
+// [b_lo, b_hi): the L1 buckets this launch covers (over-provisioned fine level only: a stripe of the batch, so that P5 of one
+// stripe can run beside P4 of the next; the exact fine level always covers all of them)
 template <int W, bool RANGED, int NT>
 __global__ __launch_bounds__(NT) void k_part_scatter2(const u64 *__restrict__ bufA, Table<W> t, PartArrays a, u64 max_units,
-                                                          u64 *__restrict__ bufB) {
+                                                          u64 *__restrict__ bufB, u32 b_lo, u32 b_hi) {
     extern __shared__ unsigned long long lds_dyn[];
     ScatterLds<W, NT> L(lds_dyn, t.nb2);
     constexpr u32 TILE = NT * KEYS_PER_THREAD;          // keys this workgroup sorts at a time (ranges and the chunk table stay in TILE2 units)
@@ -661,7 +687,8 @@ __global__ __launch_bounds__(NT) void k_part_scatter2(const u64 *__restrict__ bu
         s_l1b[b] = l1_begin(a, b);
     }
     __syncthreads();
-    const u64 total = min((u64)s_ubase[256], max_units);
+    const u64 first = RANGED ? 0ull : (u64)s_ubase[b_lo];
+    const u64 total = min((u64)s_ubase[RANGED ? 256u : b_hi], max_units);
     const Sampler nosp{nullptr, 0, nullptr};
     u32 noclaims = 0;
     GK_T0();
@@ -700,7 +727,7 @@ __global__ __launch_bounds__(NT) void k_part_scatter2(const u64 *__restrict__ bu
         auto request = [&](Kmer<W> (&kk)[KEYS_PER_THREAD], const Pos &p) {
             if (p.c < total) load_chunk<W, 2, NT>(kk, bufA, a, p.b1, s_l1b[p.b1], p.begin, p.cnt);
         };
-        Pos cur = geom(blockIdx.x);
+        Pos cur = geom(first + blockIdx.x);
         auto step = [&](Kmer<W> (&kc)[KEYS_PER_THREAD], Kmer<W> (&kn)[KEYS_PER_THREAD]) {
             const Pos nxt = geom(cur.c + gridDim.x);
             scatter_chunk<W, 2, false, NT>(kc, cur.cnt, t, t.nb2, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a, (u64)cur.b1 * t.nb2, bufB,
@@ -852,7 +879,8 @@ __device__ __forceinline__ int lds_add_look(Slot<2> *seg, u32 pos, Kmer<2> key) 
 #endif
 static constexpr int SBLOCK = GK_SBLOCK;               // threads per segment workgroup
 template <int W>
-__global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W> t, const u64 *__restrict__ keys, PartArrays a, int from_empty, Counters *ctr) {
+__global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W> t, const u64 *__restrict__ keys, PartArrays a, int from_empty, Counters *ctr,
+                                                          u64 seg_lo, u64 seg_hi /* this launch's segments: [seg_lo, seg_hi) */) {
     extern __shared__ uint4 lds_raw[];
     constexpr u32 S = 1u << SegBits<W>::value;
     constexpr u32 NVEC = S * sizeof(Slot<W>) / 16;
@@ -860,7 +888,7 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W> t, const u64 
     constexpr u32 KBLK = (u32)SBLOCK * KPT;                         // keys per register block (= S)
     Slot<W> *seg = reinterpret_cast<Slot<W> *>(lds_raw);
     u32 *flags = reinterpret_cast<u32 *>(lds_raw + NVEC);         // [0] claims, [1] overflow, [2] free slots found while loading
-    const u64 nseg = t.nseg();
+    const u64 nseg = min(seg_hi, t.nseg());
     u32 wg_claims = 0;      // thread 0 only: ONE global atomic per workgroup at the end (a same-address
                             // atomic per segment caps the kernel at ~88 segments/us chip-wide)
     // Software pipeline over this workgroup's segments.  One segment is a chain of dependent round
@@ -971,7 +999,7 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W> t, const u64 
         kb = kbn; cnt = cntn; kbn = kbnn; cntn = cntnn;
     };
     Kmer<W> keyA[KPT], keyB[KPT];
-    u64 s = blockIdx.x;
+    u64 s = seg_lo + blockIdx.x;
     range_of(s, kb, cnt);
     range_of(s + gridDim.x, kbn, cntn);
     request_keys(keyA, kb, cnt, 0u);
@@ -1032,8 +1060,9 @@ static int part_prepare_l1(gk_map *m, PartScratch *ps, u64 nkeys, bool op1, Part
     const u64 nb1 = 1ull << m->lnb1;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    // (nspill, overflow, n_failed are read back together at the end of a batch: contiguous, one copy)
     const size_t o_hist1 = take(256 * 8), o_l1 = take(257 * 8), o_cur1 = take(256 * 8), o_cb = take(257 * 8), o_rb = take(257 * 8),
-                 o_nf = take(4), o_nsp = take(8), o_ovf = take(4);
+                 o_nsp = take(16), o_ovf = o_nsp + 8, o_nf = o_nsp + 12;
     if (int rc = grow_raw(ctx, &ps->blob, &ps->blob_bytes, off)) return rc;
     GK_HIP(ctx, hipMemsetAsync(ps->blob, 0, off, ctx->stream));
     char *b = (char *)ps->blob;
@@ -1165,7 +1194,7 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         const u64 by_bytes = ((u64)OP_TILE_WORDS * 4 - 96) / src.stride;
         const int rs = (int)std::max<u64>(1, std::min<u64>(by_bytes, (u64)(OP_CAP / W) / (u64)max_windows));
         const u64 ntiles = (src.nreads + rs - 1) / rs;
-        const int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)ctx->cu_count * 2);
+        const int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)ctx->cu_count * GK_OP_WGS_PER_CU);
         const bool p2_wide = ctx->hook_p2_wide > 0;        // 1024 threads per tile: A/B option (gk_ctx_set_option "p2_wide")
         const bool p2_sorted = ctx->hook_p2_sorted > 0;    // bucket-ordered write-out: A/B option ("p2_sorted")
         const int vu = src.verify_uniform ? 1 : 0;
@@ -1199,7 +1228,7 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
                 GK_HIP(ctx, hipEventRecord(ev, ctx->copy_stream));
                 GK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ev, 0));
                 const u64 nt = (nr + rs - 1) / rs;
-                const int gsub = (int)std::min<u64>(std::max<u64>(nt, 1), (u64)ctx->cu_count * 2);
+                const int gsub = (int)std::min<u64>(std::max<u64>(nt, 1), (u64)ctx->cu_count * GK_OP_WGS_PER_CU);
                 launch_p2(gsub, d_rec + off, nr);
             }
         }
@@ -1241,12 +1270,21 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
     // With plan.estimate the round trip is taken anyway: it brings the distinct-key sample back.
     unsigned long long nspill = 0;
     u32 ovf = 0;
+    // [nspill u64][overflow u32][n_failed u32] of the blob -> the pinned area behind the counters' mirror; the caller syncs
+    struct PartStatus { unsigned long long nspill; u32 overflow, n_failed; };
+    PartStatus *h_st = reinterpret_cast<PartStatus *>(m->h_status + 64);
+    static_assert(sizeof(Counters) <= 64 && sizeof(PartStatus) == 16, "pinned status area layout");
+    auto request_status = [&]() -> int {
+        GK_HIP(ctx, hipMemcpyAsync(h_st, a.nspill, sizeof(PartStatus), hipMemcpyDeviceToHost, ctx->stream));
+        return GK_OK;
+    };
     auto abandon = [&](bool table_touched) -> int {
         unsigned long long occ = 0;
         if (d_rec) {   // P2 already counted this batch's windows
             GK_HIP(ctx, hipMemcpy(&occ, &m->d_ctr->occurrences, 8, hipMemcpyDeviceToHost));
             occ -= std::min<unsigned long long>(occ, nkeys_bound);
             GK_HIP(ctx, hipMemcpy(&m->d_ctr->occurrences, &occ, 8, hipMemcpyHostToDevice));
+            m->occ_cached = occ;
         }
         if (table_touched) GK_HIP(ctx, hipMemset(&m->d_ctr->size, 0, 8));     // from empty: whatever P5 claimed is void
         m->retries_direct++;
@@ -1259,11 +1297,12 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
     if (src.verify_uniform && !(d_rec && op1)) return fail(ctx, GK_E_STATE, "unverified host stream reached a path that cannot verify it");
     const bool sync_between = plan.estimate || (op1 && !from_empty) || src.verify_uniform;
     if (sync_between) {
-        Counters c;
-        GK_HIP(ctx, hipMemcpyAsync(&nspill, a.nspill, 8, hipMemcpyDeviceToHost, ctx->stream));
-        GK_HIP(ctx, hipMemcpyAsync(&ovf, a.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
-        GK_HIP(ctx, hipMemcpyAsync(&c, m->d_ctr, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+        Counters *hc = reinterpret_cast<Counters *>(m->h_status);
+        if (int rc = request_status()) return rc;
+        GK_HIP(ctx, hipMemcpyAsync(hc, m->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, ctx->stream));
         GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const Counters c = *hc;
+        nspill = h_st->nspill; ovf = h_st->overflow;
         if (src.verify_uniform && c.format) {       // not the uniform stream it looked like: only scratch was touched
             GK_HIP(ctx, hipMemsetAsync(&m->d_ctr->format, 0, sizeof(u32), ctx->stream));
             GK_HIP(ctx, hipEventRecord(ctx->pev[5], ctx->stream));
@@ -1322,35 +1361,68 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
             if constexpr (W == 1) {
                 const size_t wide_lds = ScatterLds<1, 1024>::bytes(m->nb2);
                 const int gw = (int)std::min<u64>(max_ranges, (u64)ctx->cu_count * 2);
-                hipLaunchKernelGGL((k_part_scatter2<1, true, 1024>), dim3(gw), dim3(1024), wide_lds, ctx->stream, ps->bufA, t, a, max_ranges, ps->bufB);
+                hipLaunchKernelGGL((k_part_scatter2<1, true, 1024>), dim3(gw), dim3(1024), wide_lds, ctx->stream, ps->bufA, t, a, max_ranges, ps->bufB, 0u, 256u);
             }
         } else
-            hipLaunchKernelGGL((k_part_scatter2<W, true, PBLOCK>), dim3(gr), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2), ctx->stream, ps->bufA, t, a, max_ranges, ps->bufB);
-    } else {
-        GK_HIP(ctx, hipEventRecord(ctx->pev[3], ctx->stream));
-        const int gchunks = (int)std::min<u64>(max_chunks, (u64)ctx->cu_count * 4);
+            hipLaunchKernelGGL((k_part_scatter2<W, true, PBLOCK>), dim3(gr), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2), ctx->stream, ps->bufA, t, a, max_ranges, ps->bufB, 0u, 256u);
+    }
+    auto launch_p4_op = [&](u32 b_lo, u32 b_hi, u64 share) {          // over-provisioned fine level, L1 buckets [b_lo, b_hi)
+        const int per_cu = ctx->hook_p4_grid > 0 ? ctx->hook_p4_grid : 4;           // ("p4_grid": workgroups per CU, A/B)
+        const int gchunks = (int)std::min<u64>(max_chunks / share + 1, (u64)ctx->cu_count * per_cu);
         if (op_wide && op1) {
             if constexpr (W == 1) {
                 const size_t wide_lds = ScatterLds<1, 1024>::bytes(m->nb2);
-                hipLaunchKernelGGL((k_part_scatter2<1, false, 1024>), dim3(std::min(gchunks, ctx->cu_count * 2)), dim3(1024), wide_lds, ctx->stream, ps->bufA, t, a, max_chunks, ps->bufB);
+                hipLaunchKernelGGL((k_part_scatter2<1, false, 1024>), dim3(std::min(gchunks, ctx->cu_count * std::min(per_cu, 2))), dim3(1024), wide_lds, ctx->stream, ps->bufA, t, a,
+                                   max_chunks, ps->bufB, b_lo, b_hi);
             }
         } else
-            hipLaunchKernelGGL((k_part_scatter2<W, false, PBLOCK>), dim3(gchunks), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2), ctx->stream, ps->bufA, t, a, max_chunks, ps->bufB);
+            hipLaunchKernelGGL((k_part_scatter2<W, false, PBLOCK>), dim3(gchunks), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2), ctx->stream, ps->bufA, t, a, max_chunks,
+                               ps->bufB, b_lo, b_hi);
+    };
+    auto launch_p5 = [&](hipStream_t st, u64 seg_lo, u64 seg_hi) {
+        const int gseg = (int)std::min<u64>(seg_hi - seg_lo, (u64)ctx->cu_count * 24);
+        hipLaunchKernelGGL(k_seg_insert<W>, dim3(gseg), dim3(SBLOCK), lds, st, t, fine_keys, a, from_empty ? 1 : 0, m->d_ctr, seg_lo, seg_hi);
+    };
+    // Stripes (over-provisioned fine level): P4 is bound by its LDS sort and leaves half the memory system idle, P5 streams
+    // the table and leaves the ALUs idle.  With the L1 buckets cut into stripes, P5 of stripe i runs on the second stream
+    // beside P4 of stripe i+1 (option "p45_stripes": 1 = one after the other).
+    int stripes = fine_exact ? 1 : std::max(1, std::min<int>({ctx->hook_p45_stripes > 0 ? ctx->hook_p45_stripes : 1, (int)nb1, 16}));
+    while (nb1 % (u64)stripes) stripes--;
+    if (!fine_exact && stripes == 1) {
+        GK_HIP(ctx, hipEventRecord(ctx->pev[3], ctx->stream));
+        launch_p4_op(0u, (u32)nb1, 1);
     }
-    GK_HIP(ctx, hipGetLastError());
-    GK_HIP(ctx, hipEventRecord(ctx->pev[4], ctx->stream));
-    // ---- P5 ------------------------------------------------------------------------------------------------
-    const int gseg = (int)std::min<u64>(nseg, (u64)ctx->cu_count * 24);
-    hipLaunchKernelGGL(k_seg_insert<W>, dim3(gseg), dim3(SBLOCK), lds, ctx->stream, t, fine_keys, a, from_empty ? 1 : 0, m->d_ctr);
-    GK_HIP(ctx, hipGetLastError());
-    GK_HIP(ctx, hipEventRecord(ctx->pev[5], ctx->stream));
+    if (stripes == 1) {
+        GK_HIP(ctx, hipGetLastError());
+        GK_HIP(ctx, hipEventRecord(ctx->pev[4], ctx->stream));
+        // ---- P5 --------------------------------------------------------------------------------------------
+        launch_p5(ctx->stream, 0, nseg);
+        GK_HIP(ctx, hipGetLastError());
+        GK_HIP(ctx, hipEventRecord(ctx->pev[5], ctx->stream));
+    } else {
+        // (phase events: [3,4] = the P4 launches with the overlapped P5s beside them, [4,5] = what is left of P5 after the last P4)
+        GK_HIP(ctx, hipEventRecord(ctx->pev[3], ctx->stream));
+        const u32 per = (u32)(nb1 / (u64)stripes);
+        for (int s = 0; s < stripes; s++) {
+            launch_p4_op(s * per, (s + 1) * per, (u64)stripes);
+            GK_HIP(ctx, hipGetLastError());
+            hipEvent_t ev = ctx->cev[s % 16];
+            GK_HIP(ctx, hipEventRecord(ev, ctx->stream));
+            GK_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ev, 0));
+            launch_p5(ctx->copy_stream, (u64)s * per * m->nb2, (u64)(s + 1) * per * m->nb2);
+            GK_HIP(ctx, hipGetLastError());
+        }
+        GK_HIP(ctx, hipEventRecord(ctx->pev[4], ctx->stream));
+        GK_HIP(ctx, hipEventRecord(ctx->gev2, ctx->copy_stream));
+        GK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->gev2, 0));
+        GK_HIP(ctx, hipEventRecord(ctx->pev[5], ctx->stream));
+    }
     // the spill list may also have grown in P4 (over-provisioned fine level): read it (again) behind P5
-    GK_HIP(ctx, hipMemcpyAsync(&nspill, a.nspill, 8, hipMemcpyDeviceToHost, ctx->stream));
-    GK_HIP(ctx, hipMemcpyAsync(&ovf, a.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
     // failures (a segment filled up): grow, then replay those buckets through the direct path
-    u32 n_failed = 0;
-    GK_HIP(ctx, hipMemcpyAsync(&n_failed, a.n_failed, 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (int rc = map_sync_counters(m)) return rc;
+    if (int rc = request_status()) return rc;
+    if (int rc = map_sync_counters(m)) return rc;              // (one stream sync for both copies)
+    nspill = h_st->nspill; ovf = h_st->overflow;
+    const u32 n_failed = h_st->n_failed;
     if (ovf) {
         if (from_empty) return abandon(true);
         // P4's regions overflowed into a full spill list while the table held data: the keys that did not fit are lost

@@ -267,10 +267,12 @@ static int alloc_table(gk_ctx *ctx, int W, uint64_t cap, void **out) {
 namespace gk {
 
 int map_sync_counters(gk_map *m) {
-    Counters c;
-    GK_HIP(m->ctx, hipMemcpyAsync(&c, m->d_ctr, sizeof(c), hipMemcpyDeviceToHost, m->ctx->stream));
+    Counters *hc = reinterpret_cast<Counters *>(m->h_status);
+    GK_HIP(m->ctx, hipMemcpyAsync(hc, m->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, m->ctx->stream));
     GK_HIP(m->ctx, hipStreamSynchronize(m->ctx->stream));
+    const Counters c = *hc;
     m->size = c.size;
+    m->occ_cached = c.occurrences;
     if (c.noncanon) m->dirty = true;
     if (c.error || c.format) {
         GK_HIP(m->ctx, hipMemsetAsync(&m->d_ctr->error, 0, 2 * sizeof(u32), m->ctx->stream));
@@ -412,6 +414,7 @@ int gk_ctx_create(int device, gk_ctx **out) {
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev1);
     for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipEventCreate(&ctx->pev[i]);
     if (e == hipSuccess) e = hipEventCreate(&ctx->gev);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->gev2, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
     for (int i = 0; i < 16 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->cev[i], hipEventDisableTiming);
     hipDeviceProp_t prop;
@@ -428,6 +431,7 @@ int gk_ctx_create(int device, gk_ctx **out) {
     ctx->hook_no_reserve = getenv("GK_TEST_NO_RESERVE") != nullptr;
     ctx->hook_host_ragged = getenv("GK_HOST_RAGGED") != nullptr;
     ctx->hook_part_exact = getenv("GK_PART_EXACT") != nullptr;
+    if (const char *u = getenv("GK_P45_STRIPES")) ctx->hook_p45_stripes = atoi(u);
     if (const char *u = getenv("GK_GRAPH_UNITIGS")) ctx->hook_unitigs = !strcmp(u, "walk") ? 1 : !strcmp(u, "pj") ? 2 : 0;
     *out = ctx;
     return GK_OK;
@@ -443,6 +447,7 @@ void gk_ctx_destroy(gk_ctx *ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (int i = 0; i < 6; i++) if (ctx->pev[i]) (void)hipEventDestroy(ctx->pev[i]);
     if (ctx->gev) (void)hipEventDestroy(ctx->gev);
+    if (ctx->gev2) (void)hipEventDestroy(ctx->gev2);
     for (int i = 0; i < 16; i++) if (ctx->cev[i]) (void)hipEventDestroy(ctx->cev[i]);
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     delete ctx;
@@ -464,6 +469,8 @@ int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value) {
     else if (n == "p2_wide") ctx->hook_p2_wide = value < 0 ? -1 : value != 0;
     else if (n == "p2_sorted") ctx->hook_p2_sorted = value < 0 ? -1 : value != 0;
     else if (n == "p4_wide") ctx->hook_p4_wide = value < 0 ? -1 : value != 0;
+    else if (n == "p45_stripes") ctx->hook_p45_stripes = (int)value;
+    else if (n == "p4_grid") ctx->hook_p4_grid = (int)value;
     else if (n == "fine_exact") ctx->hook_fine_exact = value < 0 ? -1 : value != 0;
     else return fail(ctx, GK_E_INVALID, "gk_ctx_set_option: unknown option '" + n + "'");
     return GK_OK;
@@ -536,6 +543,7 @@ int gk_map_create(gk_ctx *ctx, int k, uint64_t capacity_hint, gk_map **out) {
     int rc = alloc_table(ctx, m->W, m->capacity, &m->slots);
     if (rc == GK_OK) {
         hipError_t e = hipMalloc((void **)&m->d_ctr, sizeof(Counters));
+        if (e == hipSuccess) e = hipHostMalloc((void **)&m->h_status, 256, hipHostMallocDefault);
         if (e == hipSuccess) e = hipMemsetAsync(m->d_ctr, 0, sizeof(Counters), ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = hip_fail(ctx, e, "gk_map_create");
@@ -543,6 +551,7 @@ int gk_map_create(gk_ctx *ctx, int k, uint64_t capacity_hint, gk_map **out) {
     if (rc != GK_OK) {
         if (m->slots) (void)hipFree(m->slots);
         if (m->d_ctr) (void)hipFree(m->d_ctr);
+        if (m->h_status) (void)hipHostFree(m->h_status);
         delete m;
         return rc == GK_E_HIP ? fail(ctx, GK_E_CAPACITY, "cannot allocate table: " + ctx->err) : rc;
     }
@@ -556,6 +565,7 @@ void gk_map_destroy(gk_map *m) {
     (void)hipStreamSynchronize(m->ctx->stream);
     if (m->slots) (void)hipFree(m->slots);
     if (m->d_ctr) (void)hipFree(m->d_ctr);
+    if (m->h_status) (void)hipHostFree(m->h_status);
     if (m->d_stage) (void)hipFree(m->d_stage);
     if (m->d_offsets) (void)hipFree(m->d_offsets);
     if (m->d_sample) (void)hipFree(m->d_sample);
@@ -634,13 +644,13 @@ static int launch_count(gk_map *m, const ReadSrc &src) {
 
 static int reset_occ_counter(gk_map *m) {
     GK_HIP(m->ctx, hipMemsetAsync(&m->d_ctr->occurrences, 0, sizeof(unsigned long long), m->ctx->stream));
+    m->occ_cached = 0;
     return GK_OK;
 }
+// Every path that counts windows (launch_count, launch_partitioned, add_keys_dev) ends with map_sync_counters, which
+// brings `occurrences` back with the rest of the counters: no further device read here.
 static int read_occ_counter(gk_map *m, uint64_t *occ) {
-    unsigned long long v = 0;
-    GK_HIP(m->ctx, hipMemcpyAsync(&v, &m->d_ctr->occurrences, sizeof(v), hipMemcpyDeviceToHost, m->ctx->stream));
-    GK_HIP(m->ctx, hipStreamSynchronize(m->ctx->stream));
-    *occ = v;
+    *occ = m->occ_cached;
     return GK_OK;
 }
 
