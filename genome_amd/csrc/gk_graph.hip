@@ -141,14 +141,36 @@ __device__ __forceinline__ u64 block_reserve(u32 v, unsigned long long *cursor, 
 // through `contains` on both strands (:270-282), 8 lookups per key; result kept in the slot.
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_classify(Table<W> t, int k, unsigned long long *n_term) {
-    __shared__ u32 s_cnt;
+    // The table this runs on is 40 % full (map_compact): walking the slots directly leaves 60 % of every wave idle through
+    // the eight lookups.  A workgroup therefore takes CLASSIFY_SPT slots per thread at a time, compacts the live ones'
+    // indices into LDS (ballot + one LDS atomic per wave) and classifies from that dense list: every lane has work, and a
+    // wave keeps 64 x 8 independent sectors in flight instead of ~26 x 8.
+    constexpr int SPT = 8;
+    __shared__ u32 s_cnt, s_n;
+    __shared__ uint16_t s_idx[BLOCK * SPT];
     if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
     u32 cnt = 0;
     const u64 ncap = t.capacity();
-    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < ncap; i += (u64)gridDim.x * BLOCK) {
+    const int lane = threadIdx.x & 63;
+    for (u64 base = (u64)blockIdx.x * (BLOCK * SPT); base < ncap; base += (u64)gridDim.x * (BLOCK * SPT)) {
+        __syncthreads();                                    // the previous round's list has been consumed
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < SPT; q++) {
+            const u64 i = base + (u64)q * BLOCK + threadIdx.x;
+            const bool live = i < ncap && slot_live(&t.slots[i]);
+            const unsigned long long mask = __ballot(live);
+            u32 wbase = 0;
+            if (lane == 0 && mask) wbase = atomicAdd(&s_n, (u32)__popcll(mask));
+            wbase = __shfl(wbase, 0);
+            if (live) s_idx[wbase + (u32)__popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)(q * BLOCK + threadIdx.x);
+        }
+        __syncthreads();
+        const u32 nlive = s_n;
+    for (u32 li = threadIdx.x; li < nlive; li += BLOCK) {
+        const u64 i = base + s_idx[li];
         Slot<W> *s = &t.slots[i];
-        if (!slot_live(s)) continue;
         Kmer<W> y = slot_key(t.slots, i, t.tagged);
         u32 in = 0, out = 0;
         // The 8 lookups are independent, but each is a dependent chain that starts with a cold random
@@ -209,6 +231,8 @@ __global__ __launch_bounds__(BLOCK) void k_classify(Table<W> t, int k, unsigned 
         s->aux = aux;
         if (term && !secondary) cnt++;
     }
+    }
+    __syncthreads();
     if (cnt) atomicAdd(&s_cnt, cnt);
     __syncthreads();
     if (threadIdx.x == 0 && s_cnt) atomicAdd(n_term, (unsigned long long)s_cnt);
@@ -379,6 +403,134 @@ __global__ __launch_bounds__(BLOCK) void k_walk(Table<W> t, int k, GraphView g, 
 #pragma unroll
             for (int j = 0; j < 8; j++)
                 if ((u64)(w * 8 + j) < bytes) g.pool[o + w * 8 + j] = (uint8_t)(word >> (8 * j));
+        }
+    }
+}
+
+// The same walk, fed from a queue.  With one edge per lane a wave lasts as long as its LONGEST edge: on an error graph the
+// mean edge is 7 bases and the longest of 64 is ten times that, so nine lanes in ten idle (17 of C3's 59 ms).  Here a lane
+// that finishes its edge takes the next one: a wave claims 1024 consecutive edges from the global queue with one atomic
+// (a claim per edge, or per refill, would be millions of atomics on ONE address at ~88 per microsecond) and hands them to
+// its idle lanes by ballot.  Nothing else in the loop is shared: the first WALK_BUF bases of an edge go to a 32-byte staging
+// slot per edge, and k_place_edges afterwards assigns the pool offsets (one atomic per 2048 edges) and copies the staged
+// bases.  Edges longer than WALK_BUF are emitted by k_walk's pass 1 as before.
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_walk_q(Table<W> t, int k, GraphView g, const u32 *slot_node, u64 max_steps,
+                                                  unsigned long long *queue, ulonglong2 *stage, unsigned long long *n_long, u32 *err) {
+    constexpr u64 CHUNK = 1024;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    u64 loc_next = 0, loc_end = 0;                 // wave-uniform: claimed edges not yet handed to a lane
+    bool drained = false;                          // wave-uniform: the global queue is empty
+    bool have = false;
+    u64 e = 0, len = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+    Kmer<W> cur{};
+    u32 longs = 0;
+    for (;;) {
+        // ---- idle lanes take edges
+        for (int attempt = 0; attempt < 2; attempt++) {
+            const unsigned long long need = __ballot(!have);
+            if (!need) break;
+            const u64 avail = loc_end - loc_next;
+            const u64 rank = (u64)__popcll(need & lt_mask);
+            if (!have && rank < avail) {
+                e = loc_next + rank;
+                const u32 n = g.e_start[e];
+                const int first = g.e_first[e];
+                cur = append_base(node_kmer<W>(g, n), first, k);           // read.drop(1) :+ base  :353
+                len = 1;
+                b0 = (u64)first; b1 = b2 = b3 = 0;                          // builder += base        :352
+                have = true;
+            }
+            loc_next += min((u64)__popcll(need), avail);
+            if (loc_next < loc_end || drained) break;
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(queue, (unsigned long long)CHUNK);
+            base = __shfl(base, 0);
+            if (base >= g.n_edges) { drained = true; loc_next = loc_end = 0; break; }
+            loc_next = base;
+            loc_end = min((u64)base + CHUNK, g.n_edges);
+        }
+        if (!__ballot(have)) { if (drained) break; else continue; }
+        // ---- one step of every lane that holds an edge
+        if (have) {
+            bool fwd;
+            const i64 slot = table_find_either(t, cur, k, &fwd);
+            u32 end = NONE;
+            bool finished = false;
+            if (slot < 0) { *err = 1; finished = true; }
+            else {
+                const u32 aux = t.slots[slot].aux;
+                if (aux & AUX_TERMINAL) {                                   // nodeMap.contains(seq)  :355
+                    end = slot_node[slot] + (fwd ? 0u : 1u);
+                    finished = true;
+                } else {
+                    const u32 om = fwd ? ((aux >> 4) & 15u) : rev4(aux & 15u);  // outcoming(seq)     :356
+                    if (__popc(om) != 1) { *err = 2; finished = true; }     // assert(out.size == 1)  :357
+                    else if (len > max_steps) { *err = 3; finished = true; }
+                    else {
+                        const int nb = __ffs(om) - 1;
+                        if (len < WALK_BUF) {
+                            const u64 bits = (u64)nb << ((len & 31) * 2);
+                            if (len < 32) b0 |= bits; else if (len < 64) b1 |= bits; else if (len < 96) b2 |= bits; else b3 |= bits;
+                        }
+                        len++;
+                        cur = append_base(cur, nb, k);                      // seq.drop(1) :+ out(0)  :360
+                    }
+                }
+            }
+            if (finished) {
+                g.e_end[e] = end;
+                g.e_len[e] = len;
+                if (end != NONE) atomicAdd(&g.in_deg[end], 1u);             // end.inEdgeIds += id    :181
+                else *err = 3;
+                if (len > WALK_BUF) longs++;
+                else {
+                    stage[2 * e] = make_ulonglong2(b0, b1);
+                    if (len > 64) stage[2 * e + 1] = make_ulonglong2(b2, b3);
+                }
+                have = false;
+            }
+        }
+    }
+    for (int d = 32; d; d >>= 1) longs += __shfl_down(longs, d);
+    if (lane == 0 && longs) atomicAdd(n_long, (unsigned long long)longs);
+}
+
+// pool offsets of all edges (each starts on a byte boundary) + the staged bases of the short ones into the pool.
+// A workgroup takes 8 consecutive edges per thread and reserves their bytes with ONE atomic.
+__global__ __launch_bounds__(BLOCK) void k_place_edges(GraphView g, const ulonglong2 *stage, unsigned long long *cursor) {
+    __shared__ u32 lds4[BLOCK / 64];
+    __shared__ unsigned long long s_base;
+    constexpr int EPT = 8;
+    const u64 per_block = (u64)BLOCK * EPT;
+    const u64 ngroups = (g.n_edges + per_block - 1) / per_block;
+    for (u64 grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const u64 e0 = grp * per_block + (u64)threadIdx.x * EPT;
+        u64 bytes[EPT];
+        u32 small = 0;
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+            bytes[j] = e0 + j < g.n_edges ? (g.e_len[e0 + j] + 3) / 4 : 0;
+            if (bytes[j] < (1u << 22)) small += (u32)bytes[j];       // (per-block totals stay < 2^32; a longer edge reserves alone)
+        }
+        u64 o = block_reserve(small, cursor, lds4, &s_base);
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+            const u64 e = e0 + j;
+            if (e >= g.n_edges) break;
+            const u64 nb = bytes[j];
+            u64 at = o;
+            if (nb < (1u << 22)) o += nb; else at = atomicAdd(cursor, (unsigned long long)nb);
+            g.e_off[e] = at;
+            if (nb > WALK_BUF / 4) continue;                          // a long edge: k_walk pass 1 emits it
+            const ulonglong2 lo = stage[2 * e];
+            ulonglong2 hi = make_ulonglong2(0, 0);
+            if (nb > 16) hi = stage[2 * e + 1];
+            for (u64 q = 0; q < nb; q++) {
+                const u64 word = q < 8 ? lo.x : q < 16 ? lo.y : q < 24 ? hi.x : hi.y;
+                g.pool[at + q] = (uint8_t)(word >> (8 * (q & 7)));
+            }
         }
     }
 }
@@ -1320,9 +1472,11 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
         const bool use_pj = ctx->hook_unitigs ? ctx->hook_unitigs == 2 : (m->size / std::max<u64>(nE, 1) >= 16);   // (hook: gk_ctx_set_option "graph_unitigs")
         PjState *stA = nullptr, *stB = nullptr;
         u64 *active = nullptr;
+        ulonglong2 *stage = nullptr;           // queue-fed walk: the first WALK_BUF bases of every edge, 32 bytes each
         u64 n_active = 0;
         auto pj_free = [&]() {
-            for (void *p : {(void *)stA, (void *)stB, (void *)active}) if (p) (void)hipFree(p);
+            for (void *p : {(void *)stA, (void *)stB, (void *)active, (void *)stage}) if (p) (void)hipFree(p);
+            stA = stB = nullptr; active = nullptr; stage = nullptr;
         };
         if (use_pj) {
             const u64 nid = 2 * m->capacity;
@@ -1355,7 +1509,15 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
             g->pool_cap = ((nE + 2 * m->size) / 4 + nE + 16) / 4 * 4;
             e = hipMalloc((void **)&g->v.pool, g->pool_cap);
             if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: pool")); }
-            hipLaunchKernelGGL(k_walk<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node, 0, m->capacity + 1, &d_cnt[4], &d_cnt[6], d_err);
+            if (ctx->hook_walk_queue == 0)        // ("graph_walk_queue": 0 = one edge per lane, the round-1 form; A/B)
+                hipLaunchKernelGGL(k_walk<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node, 0, m->capacity + 1, &d_cnt[4], &d_cnt[6], d_err);
+            else {
+                e = hipMalloc((void **)&stage, std::max<u64>(nE, 1) * 32);
+                if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: edge staging")); }
+                const int gq = (int)std::min<u64>((nE + 4 * BLOCK - 1) / (4 * BLOCK), (u64)ctx->cu_count * 8);
+                hipLaunchKernelGGL(k_walk_q<W>, dim3(std::max(gq, 1)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node, m->capacity + 1, &d_cnt[7], stage, &d_cnt[6], d_err);
+                hipLaunchKernelGGL(k_place_edges, dim3(ggrid(ctx, nE / 8 + 1)), dim3(BLOCK), 0, ctx->stream, g->v, stage, &d_cnt[4]);
+            }
         }
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

@@ -471,6 +471,8 @@ int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value) {
     else if (n == "p4_wide") ctx->hook_p4_wide = value < 0 ? -1 : value != 0;
     else if (n == "p45_stripes") ctx->hook_p45_stripes = (int)value;
     else if (n == "p4_grid") ctx->hook_p4_grid = (int)value;
+    else if (n == "graph_walk_queue") ctx->hook_walk_queue = (int)value;
+    else if (n == "graph_load_pct") ctx->hook_graph_load_pct = (int)value;
     else if (n == "fine_exact") ctx->hook_fine_exact = value < 0 ? -1 : value != 0;
     else return fail(ctx, GK_E_INVALID, "gk_ctx_set_option: unknown option '" + n + "'");
     return GK_OK;
@@ -691,7 +693,7 @@ static int launch_partitioned(gk_map *m, const ReadSrc &src, const u64 *d_keys, 
         if (from_empty) { m->pending_clear = true; m->size = 0; }       // a half-built table is void: the map is empty again
         return prc;
     }
-    if (prc == PART_NOT_UNIFORM) { m->pending_clear = from_empty; return prc; }     // nothing but scratch was touched
+    if (prc == PART_NOT_UNIFORM) { m->pending_clear = from_empty; return prc; }     // nothing but scratch (or a table that was being rebuilt from empty) was touched
     if (prc == PART_RETRY_DIRECT) {        // extreme skew: nothing but scratch (or a table that was being rebuilt from empty) was touched
         m->pending_clear = from_empty;
         m->skewed = true;
@@ -1116,8 +1118,17 @@ static int map_compact(gk_map *m) {
     uint64_t ncap;
     // What follows deleteAll is the read-only graph phase: 8 lookups per key of which ~6 MISS, and a miss in a linearly
     // probed table walks (1 + 1/(1-load)^2)/2 slots — 4.6 at load 0.65, i.e. a second, DEPENDENT 64-byte sector for most
-    // misses.  HBM is not what is scarce here: the compacted table is sized for load 0.4 (1.9 slots per miss).
-    const double graph_load = m->k == 64 ? 0.3 : 0.4;
+    // misses.  HBM is not what is scarce here: the compacted table is sized for load 0.25 (1.4 slots per miss) when that
+    // takes less than a third of the free memory, else for 0.4.  Measured at C3 (1.28e8 keys), classify / unitig walk /
+    // buildGraph in ms: load 0.25 35 / 17 / 59, 0.40 44 / 21 / 70, 0.60 75 / 29 / 109, 0.75 171 / 44 / 219 — the footprint
+    // (8.2 GB at 0.25, 5.1 GB at 0.4) costs nothing, the probe length everything.
+    // ("graph_load_pct": A/B of the compacted table's load factor)
+    double graph_load = ctx->hook_graph_load_pct > 0 ? ctx->hook_graph_load_pct / 100.0 : (m->k == 64 ? 0.2 : 0.25);
+    if (ctx->hook_graph_load_pct <= 0) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        if ((double)m->size / graph_load * (double)slot_bytes(m->W) > (double)free_b / 3.0) graph_load = m->k == 64 ? 0.3 : 0.4;
+    }
     plan_segments(m->W, (uint64_t)((double)m->size / graph_load) + 1, &nnb2, &nlnb1, &ncap);
     if (ncap > m->capacity) { nnb2 = m->nb2; nlnb1 = m->lnb1; ncap = m->capacity; }
     void *nslots = nullptr;

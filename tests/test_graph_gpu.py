@@ -29,9 +29,12 @@ def ctx():
 def unitig_mode(ctx):
     """Force one of the two unitig constructions for the duration of a test (gk_ctx_set_option)."""
     def _set(mode):
-        ctx.set_option("graph_unitigs", {"auto": 0, "walk": 1, "pj": 2}[mode])
+        # "walk" = lanes fed from a queue (k_walk_q, the default walk), "walk1" = one edge per lane (k_walk pass 0), "pj" = pointer jumping
+        ctx.set_option("graph_unitigs", {"auto": 0, "walk": 1, "walk1": 1, "pj": 2}[mode])
+        ctx.set_option("graph_walk_queue", 0 if mode == "walk1" else -1)
     yield _set
     ctx.set_option("graph_unitigs", 0)
+    ctx.set_option("graph_walk_queue", -1)
 
 
 def oracle_canonical(og):
@@ -217,7 +220,7 @@ def test_graph_at_scale_properties(ctx):
     g.close(); m.close(); ctx.free(d)
 
 
-@pytest.mark.parametrize("mode", ["walk", "pj"])
+@pytest.mark.parametrize("mode", ["walk", "walk1", "pj"])
 @pytest.mark.parametrize("k,seed,hap", [(11, 2, 2), (31, 5, 2), (35, 6, 2), (64, 9, 1)])
 def test_unitig_construction_modes_agree_with_oracle(ctx, unitig_mode, mode, k, seed, hap):
     """Both unitig constructions — one lane walking each edge (k_walk) and pointer jumping
@@ -296,12 +299,14 @@ def test_hash_tie_kmers_table_and_graph(ctx, idx, rounds):
     m.deleteAll_lt(rounds); ref.delete_lt(rounds)
     for a, b in zip(m.sorted_items(), ref.export_sorted()):
         assert np.array_equal(a, b)
-    for mode in ("walk", "pj"):
-        ctx.set_option("graph_unitigs", {"walk": 1, "pj": 2}[mode])
+    for mode in ("walk", "walk1", "pj"):
+        ctx.set_option("graph_unitigs", {"walk": 1, "walk1": 1, "pj": 2}[mode])
+        ctx.set_option("graph_walk_queue", 0 if mode == "walk1" else -1)
         try:
             g, og = buildGraph(k, m), O.Graph(ref)
         finally:
             ctx.set_option("graph_unitigs", 0)
+            ctx.set_option("graph_walk_queue", -1)
         assert g.canonical() == oracle_canonical(og)
         g.removeBubbles(); og.remove_bubbles(); g.simplifyGraph(); og.simplify()
         assert g.canonical() == oracle_canonical(og)
