@@ -121,6 +121,28 @@ def c2_variant(ctx, rec_ptr, n, L, k, mode, steps, warmup, host_buf=None):
     return out
 
 
+def numa_of(addr):
+    """NUMA node(s) holding the pages of the mapping that contains `addr` (/proc/self/numa_maps), e.g. {"N0": 9589}; {} if unknown."""
+    try:
+        best = None
+        for line in open("/proc/self/numa_maps"):
+            f = line.split()
+            start = int(f[0], 16)
+            if start <= addr and (best is None or start > best[0]):
+                best = (start, {x.split("=")[0]: int(x.split("=")[1]) for x in f[1:] if x.startswith("N") and "=" in x})
+        return best[1] if best else {}
+    except Exception:
+        return {}
+
+
+def gpu_numa_node():
+    try:
+        import glob
+        return sorted({open(f).read().strip() for f in glob.glob("/sys/class/drm/card*/device/numa_node")})
+    except Exception:
+        return []
+
+
 def c3_object(ctx):
     """BASELINE.json configs[2] measured in THIS run: 50 M x 150 bp reads over a 4.6 Mbp genome (~1600x, 0.5 % error), k = 31, one
     GPU, all reads resident in HBM (1.95 GB): FreqFilter.extractFilteredKmers(.., 3) -> Graph.buildGraph -> removeBubbles ->
@@ -223,6 +245,12 @@ def main():
     for kv in args.opt:
         name, val = kv.split("=")
         ctx.set_option(name, int(val))
+    # The pinned host buffer of the pcie_inclusive object is taken NOW, the way an application takes its I/O buffers at start-up:
+    # pinned late, after the process has churned through host memory, the same buffer uploaded at 26 instead of 56 GB/s in three
+    # runs out of four (pages on the right NUMA node both times: presumably small pages behind the IOMMU instead of large ones).
+    want_extras = (world == 1 and not (world > 1 or args.sharded) and not args.no_extras
+                   and args.mode == "U" and n == 1_000_000 and L == 150 and k == 31)
+    hb = ctx.host_alloc(n * stride) if want_extras else None
     rec = ctx.alloc(n * stride + 64)
     G, err = 5_000_000 * world, 0.01
     ctx.synth_reads(rec, n, L, args.mode, 2, rank * n, G, err)     # config_id 2 = C2
@@ -326,7 +354,7 @@ def main():
         avg_kernel_ms = kernel_time_ms
         achieved = abytes / (avg_kernel_ms * 1e-3) / 1e9
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r02", "pmc_pipeline_v9.json") if partitioned else os.path.join(ROOT, "profiles", "r01", "pmc_count_reads_v2.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r02", "pmc_pipeline_v10.json") if partitioned else os.path.join(ROOT, "profiles", "r01", "pmc_count_reads_v2.json")
         if partitioned and not os.path.exists(pmc_file):
             pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_pipeline_v8.json")
         if not sharded and args.mode == "U" and n == 1_000_000 and L == 150 and k == 31 and os.path.exists(pmc_file):
@@ -367,9 +395,10 @@ def main():
             out["mode_G"] = c2_variant(ctx, recg, n, L, k, "G", 5, 2)
             out["mode_G"]["workload"] = "C2 mode G: 5 Mbp genome, 30x, 1 % error (SURVEY.md §8d) — the same reads count, with repeats"
             ctx.free(recg)
-            hb = ctx.host_alloc(n * stride)
             hb[:] = ctx.download(rec, n * stride)
             out["pcie_inclusive"] = c2_variant(ctx, None, n, L, k, "U", 10, 2, host_buf=hb)
+            out["pcie_inclusive"]["host_buffer_pages_per_numa_node"] = numa_of(hb.ctypes.data)
+            out["pcie_inclusive"]["gpu_numa_nodes_sysfs"] = gpu_numa_node()
             out["pcie_inclusive"]["workload"] = ("SURVEY.md §8(d) reading of the metric: the headline's reads as a `.bin` stream in PINNED HOST memory -> complete "
                                                  "table in HBM (gk_map_count_reads; host framing walk + PCIe upload in sub-chunks overlapped with the L1 scatter)")
             ctx.host_free(hb)

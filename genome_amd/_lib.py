@@ -51,6 +51,7 @@ SIGNATURES = {
     "gk_ctx_destroy": (None, [vp]),
     "gk_last_error": (C.c_char_p, [vp]),
     "gk_ctx_device": (C.c_int, [vp]),
+    "gk_ctx_trim": (C.c_int, [vp]),
     "gk_ctx_sync": (C.c_int, [vp]),
     "gk_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
     "gk_map_verify": (C.c_int, [vp, u64p, u64p, u64p, u64p]),

@@ -195,6 +195,7 @@ int gk_dist_create(gk_ctx *ctx, int rank, int world, const void *id128, gk_dist 
 
 void gk_dist_destroy(gk_dist *d) {
     if (!d) return;
+    gk_ctx *ctx = d->ctx;
     if (d->ctx) { (void)hipSetDevice(d->ctx->device); (void)hipStreamSynchronize(d->ctx->stream); }
     if (d->comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(d->comm);
     if (d->ctx && d->ctx->copy_stream) (void)hipStreamSynchronize(d->ctx->copy_stream);

@@ -1257,7 +1257,7 @@ static inline int ggrid(const gk_ctx *ctx, u64 items) {
     return (int)std::min<u64>(blocks, (u64)ctx->cu_count * 8);
 }
 
-template <class T> static hipError_t dev_grow(T **p, u64 old_n, u64 new_n, hipStream_t st) {
+template <class T> static hipError_t dev_grow(gk_ctx *ctx, T **p, u64 old_n, u64 new_n, hipStream_t st) {
     T *np_ = nullptr;
     hipError_t e = hipMalloc((void **)&np_, std::max<u64>(new_n, 1) * sizeof(T));
     if (e != hipSuccess) return e;
@@ -1307,6 +1307,7 @@ static void edge_view(GraphView &v, char *blob, const EdgeCarve &k) {
 }
 
 static void graph_free_arrays(gk_graph *g) {
+    gk_ctx *ctx = g->ctx;
     GraphView &v = g->v;
     for (void *p : {g->node_blob, g->edge_blob, (void *)v.pool, (void *)v.nidx}) if (p) (void)hipFree(p);
     g->node_blob = g->edge_blob = nullptr;
@@ -1653,7 +1654,7 @@ int gk_graph_simplify(gk_graph *g) {
         if (old_edges + h_cnt[0] >= (u64)NONE) return done(fail(ctx, GK_E_CAPACITY, "more than 2^32 graph edges"));
         if (int rc = graph_grow_edges(g, old_edges + h_cnt[0])) return done(rc);
         if (old_pool + h_cnt[1] > g->pool_cap) {
-            e = dev_grow(&v.pool, old_pool, old_pool + h_cnt[1], ctx->stream);
+            e = dev_grow(ctx, &v.pool, old_pool, old_pool + h_cnt[1], ctx->stream);
             if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_simplify: pool"));
             g->pool_cap = old_pool + h_cnt[1];
         }

@@ -3,7 +3,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <map>
 #include <string>
+#include <unordered_map>
 
 #include "../../include/genome_amd.h"
 #include "gk_device.h"
@@ -33,6 +35,14 @@ struct gk_ctx {
     int hook_p4_grid = -1;           // over-provisioned fine level: P4 workgroups per CU (-1: 4, or 2 of the 1024-thread form)
     int hook_p4_wide = -1;           // exact fine level, 8-byte keys: -1 auto (by nb2), 0 sort 4096 keys at a time, 1 sort 8192 (1024 threads)
     int hook_fine_exact = -1;        // -1 auto, 0 never unless forced by the data path, 1 always (A/B of the two fine levels)
+    // Block pool (gk::pool_malloc / pool_free): the big device buffers — tables, key scratch, graph arrays — are handed back
+    // here instead of hipFree and reused by size.  hipMalloc / hipFree of multi-GB blocks cost milliseconds to seconds on this
+    // platform and freed VRAM is scrubbed in the background on the copy engines: a second count over the same map paid 20 ms of
+    // host time between the levels, and host-fed inserts right after a map was destroyed ran their uploads at half speed.
+    std::multimap<size_t, void *> pool_free_blocks;          // by size
+    std::unordered_map<void *, size_t> pool_sizes;           // every block the pool has handed out or holds
+    size_t pool_held = 0, pool_limit = 0;                    // bytes parked; cap (a third of the device's memory)
+    uint64_t pool_hits = 0, pool_misses = 0;
     std::string err;
 };
 
@@ -60,7 +70,14 @@ struct ReadSrc {
 int stage_source(gk_ctx *ctx, const ReadSrc &src);      // upload a host-fed source in one piece, stream-ordered on ctx->stream
 }
 
-namespace gk { struct PartScratch; }
+namespace gk {
+struct PartScratch;
+// pooled device memory of a context (blocks of 1 MiB and more; smaller requests go straight to hipMalloc).  pool_free waits
+// for the context's two streams first, like the hipFree it replaces.  hipErrorOutOfMemory only after the pool was emptied.
+hipError_t pool_malloc(gk_ctx *ctx, void **p, size_t bytes);
+hipError_t pool_free(gk_ctx *ctx, void *p);
+void pool_release(gk_ctx *ctx);                              // hipFree everything parked
+}
 
 struct gk_map {
     gk_ctx *ctx = nullptr;
@@ -176,7 +193,7 @@ int skm_route_finish(gk_ctx *ctx, const unsigned long long *h_counts, bool launc
 // lanes per read in the window loops: 64 for reads, 32/16 for short records (super-k-mers)
 inline int lanes_per_read(int max_windows) { return max_windows > 32 ? 64 : max_windows > 16 ? 32 : 16; }
 bool part_supported(const gk_map *m);
-void part_scratch_free(PartScratch *ps);
+void part_scratch_free(gk_ctx *ctx, PartScratch *ps);
 
 }  // namespace gk
 
@@ -206,3 +223,11 @@ void part_scratch_free(PartScratch *ps);
 #define GK_TICK(i) do {} while (0)
 #define GK_TFLUSH(base) do {} while (0)
 #endif
+
+// Inside the library every device allocation goes through the context's block pool: the HIP names are redirected here, and a
+// translation unit that really means the runtime's own writes (hipMalloc)(...) / (hipFree)(...).  Needs `ctx` in scope.
+#ifndef GK_NO_POOL_REDIRECT
+#define hipMalloc(p, n) gk::pool_malloc(ctx, (void **)(p), (size_t)(n))
+#define hipFree(p) gk::pool_free(ctx, (void *)(p))
+#endif
+

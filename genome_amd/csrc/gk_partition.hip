@@ -1140,7 +1140,7 @@ static int part_prepare_fine(gk_map *m, PartScratch *ps, u64 nkeys, bool op2, Pa
     return grow_buf(ctx, &ps->bufB, &ps->bufB_keys, wantB, m->W);
 }
 
-void part_scratch_free(PartScratch *ps) {
+void part_scratch_free(gk_ctx *ctx, PartScratch *ps) {
     if (!ps) return;
     for (void *p : {ps->blob, ps->fblob, (void *)ps->rmat, (void *)ps->bufA, (void *)ps->bufB, (void *)ps->spill})
         if (p) (void)hipFree(p);

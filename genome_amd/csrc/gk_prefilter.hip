@@ -309,6 +309,7 @@ int gk_prefilter_create(gk_ctx *ctx, int k, uint64_t expected_distinct, gk_prefi
 
 void gk_prefilter_destroy(gk_prefilter *pf) {
     if (!pf) return;
+    gk_ctx *ctx = pf->ctx;
     if (pf->ctx) (void)hipSetDevice(pf->ctx->device);
     if (pf->words) (void)hipFree(pf->words);
     if (pf->keybuf) (void)hipFree(pf->keybuf);

@@ -12,6 +12,8 @@
 // Roofline: every kernel here is HBM-bound integer work (random 64-B sector touches for probes,
 // streaming for scans); no MFMA.  Algorithmic bytes per unit are stated in DESIGN.md.
 #include <algorithm>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -266,6 +268,51 @@ static int alloc_table(gk_ctx *ctx, int W, uint64_t cap, void **out) {
 
 namespace gk {
 
+static constexpr size_t POOL_MIN_BLOCK = 1u << 20;
+hipError_t pool_malloc(gk_ctx *ctx, void **p, size_t bytes) {
+    *p = nullptr;
+    if (bytes < POOL_MIN_BLOCK) return (hipMalloc)(p, bytes ? bytes : 1);
+    // best fit, but never a block more than half again as big as asked for (a 12 GB table must not sit in a 50 GB block)
+    auto it = ctx->pool_free_blocks.lower_bound(bytes);
+    if (it != ctx->pool_free_blocks.end() && it->first <= bytes + bytes / 2) {
+        *p = it->second;
+        ctx->pool_held -= it->first;
+        ctx->pool_free_blocks.erase(it);
+        ctx->pool_hits++;
+        return hipSuccess;
+    }
+    hipError_t e = (hipMalloc)(p, bytes);
+    if (e != hipSuccess && !ctx->pool_free_blocks.empty()) {         // out of memory with blocks parked: give them back, once
+        (void)hipGetLastError();
+        pool_release(ctx);
+        e = (hipMalloc)(p, bytes);
+    }
+    if (e == hipSuccess) { ctx->pool_sizes[*p] = bytes; ctx->pool_misses++; }
+    return e;
+}
+hipError_t pool_free(gk_ctx *ctx, void *p) {
+    if (!p) return hipSuccess;
+    auto it = ctx->pool_sizes.find(p);
+    if (it == ctx->pool_sizes.end()) return (hipFree)(p);
+    const size_t bytes = it->second;
+    // (hipFree waits for the device; a parked block may be handed out again at once, so wait for this context's work here)
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && ctx->copy_stream) e = hipStreamSynchronize(ctx->copy_stream);
+    if (e != hipSuccess || ctx->pool_held + bytes > ctx->pool_limit) {
+        ctx->pool_sizes.erase(it);
+        const hipError_t e2 = (hipFree)(p);
+        return e != hipSuccess ? e : e2;
+    }
+    ctx->pool_free_blocks.emplace(bytes, p);
+    ctx->pool_held += bytes;
+    return hipSuccess;
+}
+void pool_release(gk_ctx *ctx) {
+    for (auto &b : ctx->pool_free_blocks) { ctx->pool_sizes.erase(b.second); (void)(hipFree)(b.second); }
+    ctx->pool_free_blocks.clear();
+    ctx->pool_held = 0;
+}
+
 int map_sync_counters(gk_map *m) {
     Counters *hc = reinterpret_cast<Counters *>(m->h_status);
     GK_HIP(m->ctx, hipMemcpyAsync(hc, m->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, m->ctx->stream));
@@ -352,7 +399,11 @@ int map_reserve(gk_map *m, uint64_t extra_keys) {
 // the partitioned pipeline's mid-batch form: room for `new_distinct` more keys; from_empty = the table's contents are void
 int map_make_room(gk_map *m, uint64_t new_distinct, uint64_t size_for, bool from_empty) {
     const uint64_t have = from_empty ? 0 : m->size + m->tombstones;
-    if ((double)(have + new_distinct) <= max_load(m) * (double)m->capacity) return GK_OK;
+    // (a table whose contents are void is replaced for free — nothing to rehash — so it is sized for what the whole call
+    //  is expected to bring, `size_for`, right away: the second count over a map that had been compacted in between kept
+    //  the small table for two batches and then paid a 20 ms rehash of 4e8 keys in the third)
+    const uint64_t fit_now = from_empty ? std::max(new_distinct, size_for) : new_distinct;
+    if ((double)(have + fit_now) <= max_load(m) * (double)m->capacity) return GK_OK;
     const uint64_t want = std::max<uint64_t>((uint64_t)((double)(have + std::max(new_distinct, size_for)) / target_load(m)) + 1,
                                              from_empty ? 0 : m->capacity + m->capacity / 2);
     return map_grow_to(m, want, !from_empty);
@@ -427,6 +478,7 @@ int gk_ctx_create(int device, gk_ctx **out) {
         return rc;
     }
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->pool_limit = (size_t)prop.totalGlobalMem / 3;
     // test / A-B hooks: the environment is read HERE, once (see gk_ctx_set_option for the programmatic form)
     ctx->hook_no_reserve = getenv("GK_TEST_NO_RESERVE") != nullptr;
     ctx->hook_host_ragged = getenv("GK_HOST_RAGGED") != nullptr;
@@ -440,7 +492,10 @@ int gk_ctx_create(int device, gk_ctx **out) {
 void gk_ctx_destroy(gk_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    gk::pool_release(ctx);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->skm_counts) (void)hipFree(ctx->skm_counts);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -451,6 +506,15 @@ void gk_ctx_destroy(gk_ctx *ctx) {
     for (int i = 0; i < 16; i++) if (ctx->cev[i]) (void)hipEventDestroy(ctx->cev[i]);
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     delete ctx;
+}
+
+int gk_ctx_trim(gk_ctx *ctx) {
+    if (!ctx) return fail(nullptr, GK_E_INVALID, "gk_ctx_trim: null context");
+    GK_HIP(ctx, hipSetDevice(ctx->device));
+    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    gk::pool_release(ctx);
+    return GK_OK;
 }
 
 const char *gk_last_error(const gk_ctx *ctx) { return ctx ? ctx->err.c_str() : tls_err.c_str(); }
@@ -483,10 +547,24 @@ int gk_ctx_sync(gk_ctx *ctx) {
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GK_OK;
 }
+// The pages go to the NUMA node next to the GPU: on a two-socket host a pinned buffer that lands on the far socket uploads
+// at half the rate (26 instead of 56 GB/s measured; where the default allocation lands varies from process to process).
+// set_mempolicy(MPOL_PREFERRED) for the duration of the allocation; if the policy call is refused (seccomp) or the runtime
+// does not know the node, the default placement is taken.
 int gk_host_alloc(gk_ctx *ctx, size_t nbytes, void **host_ptr) {
     if (!ctx || !host_ptr) return fail(ctx, GK_E_INVALID, "gk_host_alloc: null argument");
     GK_HIP(ctx, hipSetDevice(ctx->device));
-    GK_HIP(ctx, hipHostMalloc(host_ptr, nbytes ? nbytes : 1, hipHostMallocDefault));
+    int node = -1;
+    if (hipDeviceGetAttribute(&node, hipDeviceAttributeHostNumaId, ctx->device) != hipSuccess) { (void)hipGetLastError(); node = -1; }
+    bool bound = false;
+    if (node >= 0 && node < 1024) {
+        unsigned long mask[16] = {0};
+        mask[node / 64] |= 1ul << (node % 64);
+        bound = syscall(SYS_set_mempolicy, 1 /* MPOL_PREFERRED */, mask, 1025ul) == 0;
+    }
+    const hipError_t e = hipHostMalloc(host_ptr, nbytes ? nbytes : 1, bound ? hipHostMallocNumaUser : hipHostMallocDefault);
+    if (bound) (void)syscall(SYS_set_mempolicy, 0 /* MPOL_DEFAULT */, nullptr, 0ul);
+    GK_HIP(ctx, e);
     return GK_OK;
 }
 int gk_host_free(gk_ctx *ctx, void *host_ptr) {
@@ -563,6 +641,7 @@ int gk_map_create(gk_ctx *ctx, int k, uint64_t capacity_hint, gk_map **out) {
 
 void gk_map_destroy(gk_map *m) {
     if (!m) return;
+    gk_ctx *ctx = m->ctx;
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     if (m->slots) (void)hipFree(m->slots);
@@ -572,7 +651,7 @@ void gk_map_destroy(gk_map *m) {
     if (m->d_offsets) (void)hipFree(m->d_offsets);
     if (m->d_sample) (void)hipFree(m->d_sample);
     if (m->d_scratch) (void)hipFree(m->d_scratch);
-    part_scratch_free(m->part);
+    part_scratch_free(ctx, m->part);
     delete m;
 }
 
@@ -745,7 +824,7 @@ static u64 part_batch_keys(gk_map *m) {
         (void)ps;
         const double per_key = 8.0 * m->W * (1.125 + 1.0 + 1.0 / 16) + 1.0;      // bufA + bufB + spill (+ range matrix, bounded above)
         // the scratch a previous batch left allocated is reused, so it counts as available: approximate by a share of the whole card
-        const double avail = std::max((double)free_b, 0.35 * (double)total_b);
+        const double avail = std::max((double)free_b + (double)m->ctx->pool_held, 0.35 * (double)total_b);
         cap = std::min<u64>(cap, (u64)(0.5 * avail / per_key));
     }
     return std::max<u64>(cap, 1ull << 20);
@@ -1127,6 +1206,7 @@ static int map_compact(gk_map *m) {
     if (ctx->hook_graph_load_pct <= 0) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        free_b += ctx->pool_held;               // (what the context's pool has parked is as good as free)
         if ((double)m->size / graph_load * (double)slot_bytes(m->W) > (double)free_b / 3.0) graph_load = m->k == 64 ? 0.3 : 0.4;
     }
     plan_segments(m->W, (uint64_t)((double)m->size / graph_load) + 1, &nnb2, &nlnb1, &ncap);
@@ -1255,8 +1335,9 @@ int gk_map_trim(gk_map *m) {
     if (m->d_stage) { (void)hipFree(m->d_stage); m->d_stage = nullptr; m->stage_bytes = 0; }
     if (m->d_offsets) { (void)hipFree(m->d_offsets); m->d_offsets = nullptr; m->offsets_bytes = 0; }
     if (m->d_scratch) { (void)hipFree(m->d_scratch); m->d_scratch = nullptr; m->scratch_bytes = 0; }
-    part_scratch_free(m->part);
+    part_scratch_free(ctx, m->part);
     m->part = nullptr;
+    pool_release(ctx);                  // "release" means back to the device, not parked in the context's pool
     return GK_OK;
 }
 

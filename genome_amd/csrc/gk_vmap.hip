@@ -243,6 +243,8 @@ int vm_check_keys(const gk_vmap *m, const uint64_t *lo, const uint64_t *hi, uint
 }
 
 struct DevBuf {      // a few device arrays for one call, freed together
+    gk_ctx *ctx;
+    explicit DevBuf(gk_ctx *c) : ctx(c) {}
     std::vector<void *> ptrs;
     ~DevBuf() { for (void *p : ptrs) if (p) (void)hipFree(p); }
     template <class T> hipError_t get(T **p, u64 n) {
@@ -299,6 +301,7 @@ int gk_vmap_create(gk_ctx *ctx, int k, uint64_t capacity_hint, gk_vmap **out) {
 
 void gk_vmap_destroy(gk_vmap *m) {
     if (!m) return;
+    gk_ctx *ctx = m->ctx;
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     if (m->slots) (void)hipFree(m->slots);
@@ -321,7 +324,7 @@ int gk_vmap_put_new_batch(gk_vmap *m, const uint64_t *lo, const uint64_t *hi, co
     if (n == 0) return GK_OK;
     if (!values) return fail(ctx, GK_E_INVALID, "null value array");
     if (int rc = vm_check_keys(m, lo, hi, n)) return rc;
-    DevBuf b;
+    DevBuf b(ctx);
     u64 *d_lo = nullptr, *d_hi = nullptr, *d_val = nullptr;
     hipError_t e = b.get(&d_lo, n);
     if (e == hipSuccess && m->W == 2) e = b.get(&d_hi, n);
@@ -341,7 +344,7 @@ int gk_vmap_update_batch(gk_vmap *m, const uint64_t *lo, const uint64_t *hi, con
     if (!values) return fail(ctx, GK_E_INVALID, "null value array");
     if (int rc = vm_check_keys(m, lo, hi, n)) return rc;
     if (int rc = vm_reserve(m, n)) return rc;
-    DevBuf b;
+    DevBuf b(ctx);
     u64 *d_lo = nullptr, *d_hi = nullptr, *d_val = nullptr, *d_slot = nullptr;
     u32 *d_win = nullptr;
     hipError_t e = b.get(&d_lo, n);
@@ -375,7 +378,7 @@ int gk_vmap_get_all_batch(gk_vmap *m, const uint64_t *lo, const uint64_t *hi, ui
     offsets_out[0] = 0;
     if (n == 0) return GK_OK;
     if (int rc = vm_check_keys(m, lo, hi, n)) return rc;
-    DevBuf b;
+    DevBuf b(ctx);
     u64 *d_lo = nullptr, *d_hi = nullptr, *d_out = nullptr;
     u32 *d_cnt = nullptr;
     unsigned long long *d_off = nullptr;
@@ -417,7 +420,7 @@ int gk_vmap_get_batch(gk_vmap *m, const uint64_t *lo, const uint64_t *hi, uint64
     if (n == 0) return GK_OK;
     if (!values_out) return fail(ctx, GK_E_INVALID, "null value buffer");
     if (int rc = vm_check_keys(m, lo, hi, n)) return rc;
-    DevBuf b;
+    DevBuf b(ctx);
     u64 *d_lo = nullptr, *d_hi = nullptr, *d_out = nullptr;
     u32 *d_cnt = nullptr;
     unsigned long long *d_off = nullptr;
@@ -455,7 +458,7 @@ int gk_vmap_export(gk_vmap *m, uint64_t *lo, uint64_t *hi, uint64_t *values, uin
     if (m->size > cap) return fail(ctx, GK_E_CAPACITY, "export buffer too small: need " + std::to_string(m->size));
     if (m->size == 0) return GK_OK;
     if (!lo || !values || (m->W == 2 && !hi)) return fail(ctx, GK_E_INVALID, "null export buffer");
-    DevBuf b;
+    DevBuf b(ctx);
     u64 *d_lo = nullptr, *d_hi = nullptr, *d_val = nullptr;
     unsigned long long *d_cur = nullptr;
     const u64 cnt = m->size;

@@ -45,6 +45,10 @@ class Context:
         """Wait for everything queued on the context's stream."""
         L.check(L.lib().gk_ctx_sync(self.h), self.h)
 
+    def trim(self):
+        """Give the device buffers parked in the context's pool back to the device (gk_ctx_trim)."""
+        L.check(L.lib().gk_ctx_trim(self.h), self.h)
+
     def host_alloc(self, nbytes: int) -> np.ndarray:
         """Page-locked host buffer as a uint8 array (gk_host_alloc); give it back with host_free(array)."""
         p = L.vp()

@@ -83,6 +83,7 @@ class Context {
     Context(const Context &) = delete;
     Context &operator=(const Context &) = delete;
     gk_ctx *handle() const { return h_; }
+    void trim() { check(gk_ctx_trim(h_), h_); }        // device buffers parked in the context's pool go back to the device
 
   private:
     gk_ctx *h_ = nullptr;

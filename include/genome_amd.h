@@ -61,6 +61,11 @@ void gk_ctx_destroy(gk_ctx *ctx);
 const char *gk_last_error(const gk_ctx *ctx);    /* ctx may be NULL: last error of the calling thread */
 int gk_ctx_device(const gk_ctx *ctx);
 int gk_ctx_sync(gk_ctx *ctx);                    /* hipStreamSynchronize on the context stream */
+/* Device buffers of 1 MiB and more that the library frees (tables, key scratch, graph arrays, gk_dev_free) are parked in the
+ * context — up to a third of the device's memory — and handed out again by size: hipMalloc / hipFree of multi-GB blocks cost
+ * milliseconds to seconds, and freshly freed memory is scrubbed on the copy engines while the next upload wants them.
+ * gk_ctx_trim gives everything parked back to the device (gk_map_trim does so too); gk_ctx_destroy always does. */
+int gk_ctx_trim(gk_ctx *ctx);
 /* Test / A-B switches (never needed in production).  Their defaults are read from the environment ONCE, in
  * gk_ctx_create (GK_TEST_NO_RESERVE, GK_HOST_RAGGED, GK_PART_EXACT, GK_GRAPH_UNITIGS=walk|pj); no entry point
  * consults the environment afterwards.  Names: "test_no_reserve", "host_ragged", "part_exact" (0/1),

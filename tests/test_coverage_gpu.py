@@ -232,3 +232,28 @@ def test_host_stream_that_only_looks_uniform(ctx, k):
         assert_same_table(m.sorted_items(), (lo, hi, cnt * 2))
         m.close()
 
+
+
+def test_block_pool_reuse_and_trim(ctx):
+    """Freed device buffers are parked in the context and handed out again (gk_ctx_trim gives them back): a map built, destroyed
+    and built again over recycled blocks — with stale contents in them — must still be the oracle's table, twice, and so must
+    one built right after a trim; user buffers (gk_dev_alloc / gk_dev_free) go the same way."""
+    k, n, L_ = 31, 40000, 150
+    rec = synth.reads_mode_g(n, L_, 300000, 0.01, config_id=77)
+    ref = O.PMap(k, 1)
+    occ = ref.count_reads(rec.tobytes(), n)
+    want = ref.export_sorted()
+    for cycle in range(3):
+        d = ctx.alloc(rec.size + 64)             # >= 1 MiB: pooled
+        ctx.upload(d, rec)
+        m = HipDNAMap(ctx, k, occ)
+        m.set_insert_path("partitioned")
+        assert m.count_reads_dev(d, n, L_) == occ
+        assert_same_table(m.sorted_items(), want)
+        assert m.verify()[1] == 0
+        m.deleteAll_lt(2)                        # compaction: another table comes out of the pool, the old one goes back
+        g = buildGraph(k, m)
+        assert g.counts()[0] > 0
+        g.close(); m.close(); ctx.free(d)
+        if cycle == 1:
+            ctx.trim()
