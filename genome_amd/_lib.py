@@ -42,6 +42,7 @@ u64p = C.POINTER(C.c_uint64)
 i64p = C.POINTER(C.c_int64)
 i32p = C.POINTER(C.c_int32)
 u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
 vp = C.c_void_p
 
 # every symbol include/genome_amd.h declares: (restype, argtypes)
@@ -117,6 +118,14 @@ SIGNATURES = {
     "gk_graph_edges_by_id": (C.c_int, [vp, C.POINTER(C.c_uint32), C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), u64p, u8p, u8p]),
     "gk_graph_add_node": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]),
     "gk_graph_replace_start": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
+    "gk_graph_id_bounds": (C.c_int, [vp, u64p, u64p]),
+    "gk_graph_remove_edges_by_id": (C.c_int, [vp, u32p, C.c_uint64, u64p]),
+    "gk_support_create": (C.c_int, [vp, C.POINTER(vp)]),
+    "gk_support_destroy": (None, [vp]),
+    "gk_support_size": (C.c_int, [vp, u64p, u64p, u64p]),
+    "gk_support_export": (C.c_int, [vp, u32p, u32p, u32p, C.c_uint64, u64p]),
+    "gk_graph_walk_pairs": (C.c_int, [vp, vp, vp, u8p, C.c_size_t, C.c_uint64, C.c_int, C.c_int]),
+    "gk_graph_split_by_support": (C.c_int, [vp, vp, C.c_int, u64p, u64p]),
     "gk_graph_replace_end": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
     "gk_graph_build": (C.c_int, [vp, C.POINTER(vp)]),
     "gk_graph_destroy": (None, [vp]),

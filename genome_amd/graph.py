@@ -137,6 +137,30 @@ class HipGraph:
     def replaceEnd(self, edge_id: int, node_id: int):      # :204-209
         L.check(L.lib().gk_graph_replace_end(self.h, edge_id, node_id), self.ctx.h)
 
+    # ---- paired-end walking (S/scripts/GraphSimplifier.scala:188-318)
+    def idBounds(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        L.check(L.lib().gk_graph_id_bounds(self.h, C.byref(a), C.byref(b)), self.ctx.h)
+        return a.value, b.value
+
+    def removeEdgesById(self, edge_ids) -> int:             # toRemove.foreach(id => graph.removeEdge(graph.getEdge(id)))  :316
+        ids = np.ascontiguousarray(edge_ids, np.uint32)
+        rm = C.c_uint64()
+        L.check(L.lib().gk_graph_remove_edges_by_id(self.h, L.ptr(ids, C.c_uint32), len(ids), C.byref(rm)), self.ctx.h)
+        return rm.value
+
+    def walkPairs(self, positions, support: "Support", bin_bytes, npairs: int, range_lo: int = 180, range_hi: int = 250):
+        """:213-247: the pairs' positions through `positions` (getGraphMap of this graph as it is now), annotate, the bounded
+        walks; the supported (edge, edge) pairs are counted in `support`."""
+        buf = np.frombuffer(bin_bytes, np.uint8) if not isinstance(bin_bytes, np.ndarray) else np.ascontiguousarray(bin_bytes, np.uint8).reshape(-1)
+        L.check(L.lib().gk_graph_walk_pairs(self.h, positions.h, support.h, L.ptr(buf, C.c_uint8), buf.size, npairs, range_lo, range_hi), self.ctx.h)
+
+    def splitBySupport(self, support: "Support", cutoff: int):
+        """:272-316 -> (edges removed, nodes added); call simplifyGraph() next (:318)."""
+        rm, nn = C.c_uint64(), C.c_uint64()
+        L.check(L.lib().gk_graph_split_by_support(self.h, support.h, cutoff, C.byref(rm), C.byref(nn)), self.ctx.h)
+        return rm.value, nn.value
+
     def getNodes(self):
         n = self.counts()[0]
         lo, hi = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
@@ -196,3 +220,38 @@ def buildGraph(k: int, kmersFreq) -> HipGraph:
         if own is not None:
             own.close()
     return HipGraph(kmersFreq.ctx, k, h)
+
+
+class Support:
+    """pathsMap + badPairs of GraphSimplifier.scala:209-211: (edge id, edge id) -> read pairs whose walk passes through both."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = L.vp()
+        L.check(L.lib().gk_support_create(ctx.h, C.byref(h)), ctx.h)
+        self.h = h
+
+    def close(self):
+        if self.h:
+            L.lib().gk_support_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sizes(self):
+        """-> (edge pairs, bad pairs, pair orientations walked)"""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        L.check(L.lib().gk_support_size(self.h, C.byref(a), C.byref(b), C.byref(c)), self.ctx.h)
+        return a.value, b.value, c.value
+
+    def items(self):
+        n = self.sizes()[0]
+        e1, e2, cnt = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        got = C.c_uint64()
+        L.check(L.lib().gk_support_export(self.h, L.ptr(e1, C.c_uint32), L.ptr(e2, C.c_uint32), L.ptr(cnt, C.c_uint32), n, C.byref(got)), self.ctx.h)
+        return e1, e2, cnt
+

@@ -255,6 +255,40 @@ inline DNAMap extractFilteredKmers(Context &ctx, const PairedEndData &data, int 
 }
 }  // namespace FreqFilter
 
+// DNAMap[GraphPosition] — the multimap Graph.getGraphMap fills (Graph.scala:90-119); values are GK_POS_* encoded
+class PositionMap {
+  public:
+    PositionMap(Context &ctx, int k, uint64_t capacityHint = 0) : ctx_(ctx) { check(gk_vmap_create(ctx.handle(), k, capacityHint, &h_), ctx.handle()); }
+    ~PositionMap() { gk_vmap_destroy(h_); }
+    PositionMap(PositionMap &&o) noexcept : ctx_(o.ctx_), h_(o.h_) { o.h_ = nullptr; }
+    PositionMap(const PositionMap &) = delete;
+    gk_vmap *handle() const { return h_; }
+    uint64_t size() const { uint64_t n = 0; check(gk_vmap_size(h_, &n), ctx_.handle()); return n; }
+
+  private:
+    Context &ctx_;
+    gk_vmap *h_ = nullptr;
+};
+
+// pathsMap + badPairs of GraphSimplifier.scala:209-211
+class Support {
+  public:
+    explicit Support(Context &ctx) : ctx_(ctx) { check(gk_support_create(ctx.handle(), &h_), ctx.handle()); }
+    ~Support() { gk_support_destroy(h_); }
+    Support(const Support &) = delete;
+    gk_support *handle() const { return h_; }
+    // -> (supported edge pairs, bad pairs, pair orientations walked)
+    std::tuple<uint64_t, uint64_t, uint64_t> sizes() const {
+        uint64_t a = 0, b = 0, c = 0;
+        check(gk_support_size(h_, &a, &b, &c), ctx_.handle());
+        return {a, b, c};
+    }
+
+  private:
+    Context &ctx_;
+    gk_support *h_ = nullptr;
+};
+
 struct Edge {                 // S/data/graph/Edge.scala:11 (ids are not part of the observable result)
     DNASeq start, end;
     std::string seq;
@@ -300,6 +334,25 @@ class Graph {
         std::map<uint64_t, uint64_t> h1, h2;
         for (uint64_t i = 0; i < n; i++) { h1[nodes[i]]++; h2[len[i]]++; }
         return {h1, h2};
+    }
+    // Graph.getGraphMap :90-119
+    PositionMap getGraphMap() {
+        auto [n, e, l] = counts();
+        PositionMap pm(ctx_, k_, l + n);
+        uint64_t entries = 0;
+        check(gk_graph_position_map(h_, pm.handle(), &entries), ctx_.handle());
+        return pm;
+    }
+    // GraphSimplifier.scala:213-247: the pairs' positions, annotate, the bounded walks -> support counts
+    void walkPairs(PositionMap &positions, Support &support, const PairedEndData &data, uint64_t takeFirst, int rangeLo = 180, int rangeHi = 250) {
+        check(gk_graph_walk_pairs(h_, positions.handle(), support.handle(), data.bin.data(), data.bin.size(), std::min<uint64_t>(data.count, takeFirst),
+                                  rangeLo, rangeHi), ctx_.handle());
+    }
+    // :272-316 -> (edges removed, nodes added); simplifyGraph() is the next call (:318)
+    std::pair<uint64_t, uint64_t> splitBySupport(const Support &support, int cutoff) {
+        uint64_t rm = 0, nn = 0;
+        check(gk_graph_split_by_support(h_, support.handle(), cutoff, &rm, &nn), ctx_.handle());
+        return {rm, nn};
     }
     std::tuple<uint64_t, uint64_t, uint64_t> counts() const {
         uint64_t n = 0, e = 0, l = 0;

@@ -300,6 +300,33 @@ int gk_graph_add_node(gk_graph *g, uint64_t lo, uint64_t hi, uint32_t *node_id);
 /* MapGraph.replaceStart / replaceEnd (:197-209): re-attach one end of an edge to another node */
 int gk_graph_replace_start(gk_graph *g, uint32_t edge_id, uint32_t new_start_node);
 int gk_graph_replace_end(gk_graph *g, uint32_t edge_id, uint32_t new_end_node);
+/* ids run from 0 to these bounds (dead nodes / edges keep theirs) */
+int gk_graph_id_bounds(gk_graph *g, uint64_t *node_ids, uint64_t *edge_ids);
+/* MapGraph.removeEdge (:191-195) by edge id (each id once, as the reference's `toRemove` Set, GraphSimplifier.scala:270,316) */
+int gk_graph_remove_edges_by_id(gk_graph *g, const uint32_t *edge_ids, uint64_t n, uint64_t *removed);
+
+/* ---- paired-end walking: GraphSimplifier.startup (S/scripts/GraphSimplifier.scala:188-318) ------------------------------
+ * gk_support = the reference's pathsMap (:209: (edge id, edge id) -> number of read pairs whose walk passes through the two
+ * edges one after the other) and badPairs (:211).  It accumulates over calls of gk_graph_walk_pairs. */
+typedef struct gk_support gk_support;
+int gk_support_create(gk_ctx *ctx, gk_support **out);
+void gk_support_destroy(gk_support *s);
+int gk_support_size(const gk_support *s, uint64_t *pairs, uint64_t *bad_pairs, uint64_t *walked_orientations);
+int gk_support_export(const gk_support *s, uint32_t *e1, uint32_t *e2, uint32_t *count, uint64_t cap, uint64_t *n);   /* unordered */
+/* :213-247 for the first `npairs` pairs of a `.bin` stream (two records per pair; pairs with a mate shorter than k are
+ * skipped, :213).  `positions` = gk_graph_position_map of THIS graph in its current state (GK_E_STATE otherwise).  For each
+ * pair the four getAll (:214-217) run as one batch on the device; `annotate` (:192-206) drops an orientation whose mates lie
+ * on one edge at a distance inside [range_lo, range_hi]; every (pos1, pos2) is walked as WalkingActor does (:78-125:
+ * reachable set bounded by range_hi, paths whose length puts the mates range_lo..range_hi apart) on host threads, over a
+ * snapshot of the graph's edge arrays; the edge pairs on successful paths are counted once per pair orientation.  The
+ * reference's range is 180 to 250 (:146). */
+int gk_graph_walk_pairs(gk_graph *g, gk_vmap *positions, gk_support *sup, const uint8_t *bin, size_t nbytes, uint64_t npairs, int range_lo,
+                        int range_hi);
+/* :272-316: for every node with in- and out-edges the matrix support[in][out]; its connected groups at `cutoff` (genome.cutoff);
+ * a group without an out-edge has its in-edge removed, every other group moves to a copy of the node (addNode, replaceEnd,
+ * replaceStart); out-edges that no group reached are removed.  Follow with gk_graph_simplify (:318).  Node ids: copies are
+ * appended; nodes that existed when the call started are the ones visited (the reference iterates a live map: unspecified). */
+int gk_graph_split_by_support(gk_graph *g, const gk_support *sup, int cutoff, uint64_t *removed_edges, uint64_t *new_nodes);
 /* live nodes, unspecified order */
 int gk_graph_export_nodes(gk_graph *g, uint64_t *lo, uint64_t *hi, uint64_t cap, uint64_t *n);
 /* live edges, unspecified order: start/end k-mer, length in bases, and the edge sequence as 2-bit

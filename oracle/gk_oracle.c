@@ -965,3 +965,266 @@ int gko_graph_edge_info(const gko_graph *g, int64_t id, int64_t *start, int64_t 
     return e->alive;
 }
 
+
+/* ================= Paired-end walking (S/scripts/GraphSimplifier.scala) ======================================
+ * A LITERAL restatement: reachable() is the priority-queue search of :43-72 (without its cache, which only saves time),
+ * dfs() the memoised recursion of :90-112, annotate :192-206, the per-pair loop :213-247, the support matrix and the
+ * node split :272-313, removeEdge + simplifyGraph :316-318.  Test infrastructure only. */
+typedef struct { int is_edge; int64_t id; int32_t dist; } gpos;
+
+/* getGraphMap as a multimap on the host: open addressing over the putNew calls */
+typedef struct { gko_kmer key; gpos pos; int used; } gm_ent;
+typedef struct { gm_ent *t; size_t cap; } gmap;
+static uint64_t gm_hash(gko_kmer x) { uint64_t h = x.lo * 0x9E3779B97F4A7C15ull ^ (x.hi + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full; return h ^ (h >> 29); }
+static gmap gmap_build(const gko_graph *g) {
+    size_t n = gko_graph_get_graph_map(g, NULL, NULL, NULL, NULL, NULL, 0);
+    uint64_t *lo = (uint64_t *)malloc((n + 1) * 8), *hi = (uint64_t *)malloc((n + 1) * 8);
+    uint8_t *ie = (uint8_t *)malloc(n + 1);
+    int64_t *id = (int64_t *)malloc((n + 1) * 8);
+    int32_t *ds = (int32_t *)malloc((n + 1) * 4);
+    gko_graph_get_graph_map(g, lo, hi, ie, id, ds, n);
+    gmap m;
+    m.cap = 16;
+    while (m.cap < 2 * n + 16) m.cap *= 2;
+    m.t = (gm_ent *)calloc(m.cap, sizeof(gm_ent));
+    for (size_t i = 0; i < n; i++) {
+        gko_kmer key = {lo[i], hi[i]};
+        size_t p = gm_hash(key) & (m.cap - 1);
+        while (m.t[p].used) p = (p + 1) & (m.cap - 1);           /* putNew: no duplicate check */
+        m.t[p].used = 1; m.t[p].key = key;
+        m.t[p].pos.is_edge = ie[i]; m.t[p].pos.id = id[i]; m.t[p].pos.dist = ds[i];
+    }
+    free(lo); free(hi); free(ie); free(id); free(ds);
+    return m;
+}
+static int gmap_get_all(const gmap *m, gko_kmer key, gpos *out, int cap) {
+    int n = 0;
+    for (size_t p = gm_hash(key) & (m->cap - 1); m->t[p].used; p = (p + 1) & (m->cap - 1))
+        if (kmer_eq(m->t[p].key, key)) { if (n < cap) out[n] = m->t[p].pos; n++; }
+    return n;
+}
+
+/* a small set / map of 128-bit keys (two int64) -> int32 */
+typedef struct { int64_t a, b; int32_t v; int used; } pm_ent;
+typedef struct { pm_ent *t; size_t cap, n; } pmap2;
+static void pm2_init(pmap2 *m, size_t cap) { m->cap = 16; while (m->cap < cap) m->cap *= 2; m->t = (pm_ent *)calloc(m->cap, sizeof(pm_ent)); m->n = 0; }
+static void pm2_free(pmap2 *m) { free(m->t); m->t = NULL; }
+static pm_ent *pm2_slot(pmap2 *m, int64_t a, int64_t b, int create);
+static void pm2_grow(pmap2 *m) {
+    pmap2 n2; pm2_init(&n2, m->cap * 2);
+    for (size_t i = 0; i < m->cap; i++) if (m->t[i].used) { pm_ent *e = pm2_slot(&n2, m->t[i].a, m->t[i].b, 1); e->v = m->t[i].v; }
+    free(m->t); *m = n2;
+}
+static pm_ent *pm2_slot(pmap2 *m, int64_t a, int64_t b, int create) {
+    if (create && (m->n + 1) * 2 > m->cap) pm2_grow(m);
+    uint64_t h = (uint64_t)a * 0x9E3779B97F4A7C15ull ^ ((uint64_t)b + 0x632BE59BD9B4E019ull) * 0xC2B2AE3D27D4EB4Full;
+    size_t p = (h ^ (h >> 31)) & (m->cap - 1);
+    while (m->t[p].used) {
+        if (m->t[p].a == a && m->t[p].b == b) return &m->t[p];
+        p = (p + 1) & (m->cap - 1);
+    }
+    if (!create) return NULL;
+    m->t[p].used = 1; m->t[p].a = a; m->t[p].b = b; m->t[p].v = 0; m->n++;
+    return &m->t[p];
+}
+
+/* reachable(node) :43-72 — distances back along inEdges, bounded by range.last; a binary heap of (dist, node) */
+typedef struct { int32_t d; int64_t u; } hq_ent;
+static void reachable(const gko_graph *g, int64_t node, int range_hi, pmap2 *set) {
+    size_t hn = 0, hcap = 64;
+    hq_ent *hq = (hq_ent *)malloc(hcap * sizeof(hq_ent));
+    hq[hn++] = (hq_ent){0, node};
+    while (hn) {
+        hq_ent top = hq[0];                                   /* dequeue the smallest dist (ordering y._1 - x._1 :49) */
+        hq[0] = hq[--hn];
+        for (size_t i = 0;;) {
+            size_t l = 2 * i + 1, r = l + 1, s = i;
+            if (l < hn && hq[l].d < hq[s].d) s = l;
+            if (r < hn && hq[r].d < hq[s].d) s = r;
+            if (s == i) break;
+            hq_ent t = hq[i]; hq[i] = hq[s]; hq[s] = t; i = s;
+        }
+        if (pm2_slot(set, top.u, 0, 0)) continue;             /* if (!set.contains(u)) */
+        pm2_slot(set, top.u, 0, 1)->v = top.d;                /* set += u -> dist */
+        const gnode *u = &g->nodes[top.u];
+        for (int i = 0; i < u->nin; i++) {
+            const gedge *e = &g->edges[u->in[i]];
+            const int64_t d2 = (int64_t)top.d + e->len;
+            if (d2 <= range_hi) {
+                if (hn == hcap) { hcap *= 2; hq = (hq_ent *)realloc(hq, hcap * sizeof(hq_ent)); }
+                size_t c = hn++;
+                hq[c] = (hq_ent){(int32_t)d2, e->start};
+                while (c && hq[(c - 1) / 2].d > hq[c].d) { hq_ent t = hq[c]; hq[c] = hq[(c - 1) / 2]; hq[(c - 1) / 2] = t; c = (c - 1) / 2; }
+            }
+        }
+    }
+    free(hq);
+}
+
+typedef struct {
+    const gko_graph *g;
+    int range_lo, range_hi;
+    int64_t node2; int32_t dist2; int64_t end_edge;      /* 0 = null */
+    pmap2 reach, memo, *path_edges;
+} walk_ctx;
+/* dfs(node1, dist1, prevEdge) :90-112 */
+static int walk_dfs(walk_ctx *w, int64_t node1, int32_t dist1, int64_t prev_edge) {
+    pm_ent *m = pm2_slot(&w->memo, prev_edge, dist1, 0);
+    if (m) return m->v;
+    pm_ent *r = pm2_slot(&w->reach, node1, 0, 0);
+    const int64_t rd = r ? r->v : (int64_t)w->range_hi + 1;
+    if ((int64_t)dist1 + w->dist2 + rd > w->range_hi) return 0;
+    int cur = 0;
+    if (node1 == w->node2 && dist1 + w->dist2 >= w->range_lo && dist1 + w->dist2 <= w->range_hi) {
+        if (prev_edge && w->end_edge) pm2_slot(w->path_edges, prev_edge, w->end_edge, 1)->v = 1;
+        cur = 1;
+    }
+    const gnode *n = &w->g->nodes[node1];
+    for (int i = 0; i < n->nout; i++) {
+        const int64_t e = n->out_edge[i];
+        const int res = walk_dfs(w, w->g->edges[e].end, (int32_t)(dist1 + w->g->edges[e].len), e);
+        if (res && prev_edge) pm2_slot(w->path_edges, prev_edge, e, 1)->v = 1;
+        cur |= res;
+    }
+    pm2_slot(&w->memo, prev_edge, dist1, 1)->v = cur;
+    return cur;
+}
+/* WalkingActor.receive :78-125 for one (pos1, pos2): adds to path_edges, returns `good` */
+static int walk_one(const gko_graph *g, gpos pos1, gpos pos2, int range_lo, int range_hi, pmap2 *path_edges) {
+    walk_ctx w;
+    w.g = g; w.range_lo = range_lo; w.range_hi = range_hi; w.path_edges = path_edges;
+    w.node2 = pos2.is_edge ? g->edges[pos2.id].start : pos2.id;
+    w.dist2 = pos2.is_edge ? pos2.dist : 0;
+    w.end_edge = pos2.is_edge ? pos2.id : 0;
+    const int64_t start_edge = pos1.is_edge ? pos1.id : 0;
+    pm2_init(&w.reach, 64); pm2_init(&w.memo, 64);
+    reachable(g, w.node2, range_hi, &w.reach);
+    const int64_t node0 = pos1.is_edge ? g->edges[pos1.id].end : pos1.id;
+    const int32_t dist0 = pos1.is_edge ? (int32_t)(g->edges[pos1.id].len - pos1.dist) : 0;
+    const int good = walk_dfs(&w, node0, dist0, start_edge);
+    pm2_free(&w.reach); pm2_free(&w.memo);
+    return good;
+}
+
+struct gko_support { pmap2 paths; long bad_pairs; };
+gko_support *gko_support_new(void) { gko_support *s = (gko_support *)calloc(1, sizeof(*s)); pm2_init(&s->paths, 1024); return s; }
+void gko_support_free(gko_support *s) { if (s) { pm2_free(&s->paths); free(s); } }
+long gko_support_bad_pairs(const gko_support *s) { return s->bad_pairs; }
+size_t gko_support_export(const gko_support *s, int64_t *e1, int64_t *e2, int32_t *cnt, size_t cap) {
+    size_t n = 0;
+    for (size_t i = 0; i < s->paths.cap; i++) if (s->paths.t[i].used) {
+        if (n < cap) { e1[n] = s->paths.t[i].a; e2[n] = s->paths.t[i].b; cnt[n] = s->paths.t[i].v; }
+        n++;
+    }
+    return n;
+}
+
+/* the body of GraphSimplifier.startup :188-247 over the first `npairs` pairs of a `.bin` stream (two records per pair) */
+long gko_graph_walk_pairs(const gko_graph *g, gko_support *sup, const uint8_t *bin, size_t nbytes, uint64_t npairs, int range_lo, int range_hi) {
+    const int k = g->k;
+    gmap gm = gmap_build(g);
+    size_t pos = 0;
+    long walked = 0;
+    gpos *f[4];
+    int fcap[4] = {64, 64, 64, 64};
+    for (int i = 0; i < 4; i++) f[i] = (gpos *)malloc((size_t)fcap[i] * sizeof(gpos));
+    for (uint64_t p = 0; p < npairs && pos < nbytes; p++) {
+        const uint8_t *r1 = bin + pos; const int l1 = r1[0]; pos += 1 + (size_t)(l1 + 3) / 4;
+        if (pos >= nbytes) break;
+        const uint8_t *r2 = bin + pos; const int l2 = r2[0]; pos += 1 + (size_t)(l2 + 3) / 4;
+        if (l1 < k || l2 < k) continue;                                           /* :213 */
+        const gko_kmer a = gko_kmer_from_packed(r1 + 1, 0, k), b = gko_kmer_from_packed(r2 + 1, 0, k);
+        int n[4];
+        const gko_kmer keys[4] = {a,                      /* f1 = getAll(p1.take(k))               :214 */
+                                  gko_revcomp(b, k),      /* f2 = getAll(p2.take(k).revComplement) :215 */
+                                  b,                      /* f3 = getAll(p2.take(k))               :216 */
+                                  gko_revcomp(a, k)};     /* f4 = getAll(p1.take(k).revComplement) :217 */
+        for (int i = 0; i < 4; i++) {
+            n[i] = gmap_get_all(&gm, keys[i], f[i], fcap[i]);
+            if (n[i] > fcap[i]) {
+                fcap[i] = n[i] * 2;
+                f[i] = (gpos *)realloc(f[i], (size_t)fcap[i] * sizeof(gpos));
+                n[i] = gmap_get_all(&gm, keys[i], f[i], fcap[i]);
+            }
+        }
+        for (int o = 0; o < 2; o++) {                                               /* List((s1, s2), (s3, s4)) :219 */
+            const gpos *p1 = f[2 * o], *p2 = f[2 * o + 1];
+            const int n1 = n[2 * o], n2 = n[2 * o + 1];
+            int same_edge = 0;                                                      /* annotate :192-206 */
+            for (int i = 0; i < n1 && !same_edge; i++) if (p1[i].is_edge)
+                for (int j = 0; j < n2; j++) if (p2[j].is_edge && p1[i].id == p2[j].id) {
+                    const int d = (p2[j].dist - p1[i].dist) + k;
+                    if (d >= range_lo && d <= range_hi) { same_edge = 1; break; }
+                }
+            if (same_edge) continue;
+            if (n1 == 0 || n2 == 0) continue;                                       /* `if !list.isEmpty` :231 */
+            pmap2 path_edges; pm2_init(&path_edges, 64);
+            int good = 0;
+            for (int i = 0; i < n1; i++) for (int j = 0; j < n2; j++) good |= walk_one(g, p1[i], p2[j], range_lo, range_hi, &path_edges);
+            for (size_t i = 0; i < path_edges.cap; i++) if (path_edges.t[i].used)
+                pm2_slot(&sup->paths, path_edges.t[i].a, path_edges.t[i].b, 1)->v++;   /* counter.incrementAndGet() :240 */
+            if (!good) sup->bad_pairs++;
+            pm2_free(&path_edges);
+            walked++;
+        }
+    }
+    for (int i = 0; i < 4; i++) free(f[i]);
+    free(gm.t);
+    return walked;
+}
+
+/* :272-318: support matrix per node, connected groups at `cutoff`, node split, removeEdge(toRemove), simplifyGraph.
+ * Nodes in ascending id, only those that existed before the loop (the reference iterates a live map while it adds to it:
+ * whether a copy is visited is unspecified, and a visited copy only produces another copy with the same edges). */
+static void split_dfs_left(int i, int nin, int nout, const int32_t *mx, int cutoff, int *col_l, int *col_r, int *l, int *nl, int *r, int *nr);
+static void split_dfs_right(int j, int nin, int nout, const int32_t *mx, int cutoff, int *col_l, int *col_r, int *l, int *nl, int *r, int *nr) {
+    col_r[j] = 1; r[(*nr)++] = j;
+    for (int i = 0; i < nin; i++) if (!col_l[i] && mx[i * nout + j] >= cutoff) split_dfs_left(i, nin, nout, mx, cutoff, col_l, col_r, l, nl, r, nr);
+}
+static void split_dfs_left(int i, int nin, int nout, const int32_t *mx, int cutoff, int *col_l, int *col_r, int *l, int *nl, int *r, int *nr) {
+    col_l[i] = 1; l[(*nl)++] = i;
+    for (int j = 0; j < nout; j++) if (!col_r[j] && mx[i * nout + j] >= cutoff) split_dfs_right(j, nin, nout, mx, cutoff, col_l, col_r, l, nl, r, nr);
+}
+void gko_graph_split_by_support(gko_graph *g, const gko_support *sup, int cutoff, long *removed_edges, long *new_nodes) {
+    const int64_t n0 = g->nnodes;
+    int64_t *to_remove = NULL; size_t nrm = 0, rmcap = 0;
+    long added = 0;
+#define PUSH_RM(id) do { if (nrm == rmcap) { rmcap = rmcap ? rmcap * 2 : 64; to_remove = (int64_t *)realloc(to_remove, rmcap * 8); } to_remove[nrm++] = (id); } while (0)
+    for (int64_t v = 1; v <= n0; v++) {
+        if (!g->nodes[v].alive) continue;
+        const int nin = g->nodes[v].nin, nout = g->nodes[v].nout;
+        if (nin == 0 || nout == 0) continue;                                         /* :273 */
+        int64_t *in = (int64_t *)malloc((size_t)nin * 8), out[4];
+        memcpy(in, g->nodes[v].in, (size_t)nin * 8);
+        for (int j = 0; j < nout; j++) out[j] = g->nodes[v].out_edge[j];
+        int32_t *mx = (int32_t *)calloc((size_t)nin * nout, 4);
+        for (int i = 0; i < nin; i++) for (int j = 0; j < nout; j++) {
+            pm_ent *e = pm2_slot((pmap2 *)&sup->paths, in[i], out[j], 0);
+            mx[i * nout + j] = e ? e->v : 0;
+        }
+        int *col_l = (int *)calloc((size_t)nin, sizeof(int)), col_r[4] = {0, 0, 0, 0};
+        int *l = (int *)malloc((size_t)nin * sizeof(int)), r[4];
+        const gko_kmer seq = g->nodes[v].seq;
+        for (int i = 0; i < nin; i++) {
+            if (col_l[i]) continue;
+            int nl = 0, nr = 0;
+            split_dfs_left(i, nin, nout, mx, cutoff, col_l, col_r, l, &nl, r, &nr);
+            if (nr == 0) PUSH_RM(in[i]);                                             /* toRemove += in(i) :304 */
+            else {
+                const int64_t nn = gko_graph_add_node(g, seq);                       /* :306 */
+                added++;
+                for (int q = 0; q < nl; q++) gko_graph_replace_end(g, in[l[q]], nn);    /* :307 */
+                for (int q = 0; q < nr; q++) gko_graph_replace_start(g, out[r[q]], nn); /* :308 */
+            }
+        }
+        for (int j = 0; j < nout; j++) if (!col_r[j]) PUSH_RM(out[j]);                /* :311 */
+        free(in); free(mx); free(col_l); free(l);
+    }
+    long removed = 0;
+    for (size_t i = 0; i < nrm; i++) if (g->edges[to_remove[i]].alive) { graph_remove_edge(g, to_remove[i]); removed++; }   /* :316 (a Set: once each) */
+    free(to_remove);
+    gko_graph_simplify(g);                                                            /* :318 */
+    if (removed_edges) *removed_edges = removed;
+    if (new_nodes) *new_nodes = added;
+#undef PUSH_RM
+}

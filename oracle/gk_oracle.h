@@ -132,6 +132,19 @@ size_t gko_graph_get_graph_map(const gko_graph *g, uint64_t *lo, uint64_t *hi, u
 gko_kmer gko_graph_node_seq(const gko_graph *g, int64_t id);
 int gko_graph_edge_info(const gko_graph *g, int64_t id, int64_t *start, int64_t *end, int64_t *len, int *first);
 
+
+/* ---- paired-end walking (S/scripts/GraphSimplifier.scala): literal restatement, test infrastructure */
+typedef struct gko_support gko_support;             /* pathsMap :209 — (edge id, edge id) -> count — and badPairs :211 */
+gko_support *gko_support_new(void);
+void gko_support_free(gko_support *s);
+long gko_support_bad_pairs(const gko_support *s);
+size_t gko_support_export(const gko_support *s, int64_t *e1, int64_t *e2, int32_t *cnt, size_t cap);
+/* :188-247 over the first npairs pairs of a `.bin` stream; range = range_lo to range_hi inclusive (:146); returns the
+ * number of pair orientations walked */
+long gko_graph_walk_pairs(const gko_graph *g, gko_support *sup, const uint8_t *bin, size_t nbytes, uint64_t npairs, int range_lo, int range_hi);
+/* :272-318: support matrix per node, groups at `cutoff`, node split, removeEdge(toRemove), simplifyGraph */
+void gko_graph_split_by_support(gko_graph *g, const gko_support *sup, int cutoff, long *removed_edges, long *new_nodes);
+
 #ifdef __cplusplus
 }
 #endif

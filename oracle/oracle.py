@@ -94,6 +94,12 @@ def lib():
         "gko_graph_get_graph_map": (C.c_size_t, [vp, u64p, u64p, u8p, i64p, i32p, C.c_size_t]),
         "gko_graph_node_seq": (Kmer, [vp, C.c_int64]),
         "gko_graph_edge_info": (C.c_int, [vp, C.c_int64, i64p, i64p, i64p, C.POINTER(C.c_int)]),
+        "gko_support_new": (vp, []),
+        "gko_support_free": (None, [vp]),
+        "gko_support_bad_pairs": (C.c_long, [vp]),
+        "gko_support_export": (C.c_size_t, [vp, i64p, i64p, i32p, C.c_size_t]),
+        "gko_graph_walk_pairs": (C.c_long, [vp, vp, u8p, C.c_size_t, C.c_uint64, C.c_int, C.c_int]),
+        "gko_graph_split_by_support": (None, [vp, vp, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -288,6 +294,16 @@ class Graph:
         alive = lib().gko_graph_edge_info(self.h, edge, C.byref(s), C.byref(e), C.byref(ln), C.byref(f))
         return {"start": s.value, "end": e.value, "len": ln.value, "first": f.value, "alive": bool(alive)}
 
+    # ---- paired-end walking (GraphSimplifier.scala)
+    def walk_pairs(self, sup: "Support", bin_bytes: bytes, npairs: int, range_lo: int = 180, range_hi: int = 250) -> int:
+        buf = (C.c_uint8 * len(bin_bytes)).from_buffer_copy(bin_bytes)
+        return lib().gko_graph_walk_pairs(self.h, sup.h, buf, len(bin_bytes), npairs, range_lo, range_hi)
+
+    def split_by_support(self, sup: "Support", cutoff: int):
+        rm, nn = C.c_long(0), C.c_long(0)
+        lib().gko_graph_split_by_support(self.h, sup.h, cutoff, C.byref(rm), C.byref(nn))
+        return rm.value, nn.value
+
     def graph_map_calls(self):
         """Graph.getGraphMap as its putNew sequence: arrays (lo, hi, is_edge, id, dist)."""
         n = lib().gko_graph_get_graph_map(self.h, None, None, None, None, None, 0)
@@ -301,3 +317,28 @@ class Graph:
         if lib().gko_graph_degree(self.h, km(lo, hi), C.byref(i), C.byref(o)) < 0:
             return None
         return i.value, o.value
+
+
+class Support:
+    """pathsMap + badPairs of GraphSimplifier.scala:209-211 (edge ids are the ORACLE graph's)."""
+
+    def __init__(self):
+        self.h = lib().gko_support_new()
+
+    def close(self):
+        if self.h:
+            lib().gko_support_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def bad_pairs(self) -> int:
+        return lib().gko_support_bad_pairs(self.h)
+
+    def items(self):
+        n = lib().gko_support_export(self.h, None, None, None, 0)
+        e1, e2, c = np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n, np.int32)
+        lib().gko_support_export(self.h, _p(e1, C.c_int64), _p(e2, C.c_int64), _p(c, C.c_int32), n)
+        return e1, e2, c
+

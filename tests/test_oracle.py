@@ -428,3 +428,42 @@ def test_long_hash_formula_is_one_visible_choice():
         assert O.hash_code(v["rc_lo"], 0, k) == want["h_rc"] == R.hash_code(v["rc"])
         lo, _ = O.canon(v["x_lo"], 0, k)
         assert R.canon(v["x"]) == want["canonical"] and lo == R.pack(want["canonical"])[0]
+
+
+def test_oracle_paired_end_walking_resolves_a_repeated_kmer():
+    """GraphSimplifier.scala:188-318 in the oracle: a k-mer that occurs twice in different contexts gives a node with two in-
+    and two out-edges; read pairs that span it support exactly the two true (in, out) combinations; the split + simplify
+    leaves longer edges and the same total sequence."""
+    import random
+    from oracle import oracle as O
+    from oracle import pyref as R
+    from genome_amd import dna
+    k, glen = 21, 1600
+    rnd = random.Random(5)
+    g = [rnd.choice("AGCT") for _ in range(glen)]
+    g[1100:1100 + k] = g[400:400 + k]
+    g = "".join(g)
+    reads = []
+    for _ in range(3000):
+        ins = rnd.randint(80, 100)
+        s = rnd.randrange(0, glen - ins)
+        frag = g[s:s + ins]
+        if rnd.random() < 0.5:
+            frag = R.rev_comp(frag)
+        reads += [frag[:40], R.rev_comp(frag)[:40]]
+    binb = dna.reads_to_bin(reads)
+    ref = O.PMap(k, 1)
+    ref.count_reads(binb, len(reads)); ref.delete_lt(2)
+    og = O.Graph(ref)
+    e0 = og.edges()
+    sup = O.Support()
+    walked = og.walk_pairs(sup, binb, len(reads) // 2, 60, 95)
+    e1, e2, cnt = sup.items()
+    assert walked > 0 and len(e1) > 0
+    # every supported pair is a pair of CONSECUTIVE edges: e1 ends where e2 starts
+    for a, b in zip(e1, e2):
+        assert og.edge_info(int(a))["end"] == og.edge_info(int(b))["start"]
+    removed, added = og.split_by_support(sup, 3)
+    assert added >= 2                                  # the repeated k-mer's node and its reverse complement are split
+    e = og.edges()
+    assert max(e["len"]) > max(e0["len"])              # contigs grew through the resolved repeat
