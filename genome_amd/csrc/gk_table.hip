@@ -257,8 +257,11 @@ template <int W> static Table<W> table_of(const gk_map *m) {
     return Table<W>{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u};
 }
 
-static int alloc_table(gk_ctx *ctx, int W, uint64_t cap, void **out) {
-    GK_HIP(ctx, hipMalloc(out, cap * slot_bytes(W)));
+// mem_kind: 0 = ordinary device memory (pooled); 1 = hipDeviceMallocUncached, 2 = hipDeviceMallocFinegrained (A/B of the
+// table the graph phase reads: every read request of ordinary memory is a 128-byte line, whatever the lane asked for)
+static int alloc_table(gk_ctx *ctx, int W, uint64_t cap, void **out, int mem_kind = 0) {
+    if (mem_kind == 0) GK_HIP(ctx, hipMalloc(out, cap * slot_bytes(W)));
+    else GK_HIP(ctx, hipExtMallocWithFlags(out, cap * slot_bytes(W), mem_kind == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained));
     int grid = grid_for(ctx, cap, BLOCK * 4);
     if (W == 1) hipLaunchKernelGGL(k_clear<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (Slot<1> *)*out, cap);
     else hipLaunchKernelGGL(k_clear<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (Slot<2> *)*out, cap);
@@ -536,6 +539,7 @@ int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value) {
     else if (n == "p45_stripes") ctx->hook_p45_stripes = (int)value;
     else if (n == "p4_grid") ctx->hook_p4_grid = (int)value;
     else if (n == "graph_walk_queue") ctx->hook_walk_queue = (int)value;
+    else if (n == "graph_mem") ctx->hook_graph_mem = (int)value;
     else if (n == "graph_load_pct") ctx->hook_graph_load_pct = (int)value;
     else if (n == "fine_exact") ctx->hook_fine_exact = value < 0 ? -1 : value != 0;
     else return fail(ctx, GK_E_INVALID, "gk_ctx_set_option: unknown option '" + n + "'");
@@ -742,7 +746,7 @@ struct PathCost {
     double direct_ps = 45.0;        // k_count_reads, one global CAS/add per window: 5.45 ms / 1.2e8 windows (C2-U); 40 ps at C3's ~1000x repeats
     double p2_ps = 5.0;             // k_op_scatter1_reads: 0.60 ms / 1.2e8 (x W for 16-byte keys: 0.97 ms / 9.6e7 at k = 55)
     double p3_ps = 2.3;             // k_part_hist2r + scans (exact fine level only): one more read of the keys
-    double p4_ps = 4.6;             // k_part_scatter2 at few fine buckets ...
+    double p4_ps = 3.9;             // k_part_scatter2 at few fine buckets (0.55 ms / 1.2e8 at nb2 = 370 with the next chunk's keys prefetched) ...
     double p4_ps_per_nb2 = 0.0018;  // ... + what each fine bucket per L1 bucket adds (0.57 / 0.65 / 0.80 / 1.2 ms per 1.2e8 at nb2 = 93 / 370 / 1479 / 2958)
     double p5_ps = 1.7;             // k_seg_insert: its key stream and LDS inserts (its table traffic is priced below)
     double stream_tbps = 4.6;       // k_seg_insert writes / reads the table at 4.6 TB/s; k_clear reaches 4.95
@@ -1212,7 +1216,7 @@ static int map_compact(gk_map *m) {
     plan_segments(m->W, (uint64_t)((double)m->size / graph_load) + 1, &nnb2, &nlnb1, &ncap);
     if (ncap > m->capacity) { nnb2 = m->nb2; nlnb1 = m->lnb1; ncap = m->capacity; }
     void *nslots = nullptr;
-    if (alloc_table(ctx, m->W, ncap, &nslots) != GK_OK) { if (nslots) (void)hipFree(nslots); return GK_OK; }   // keep tombstones if memory is short
+    if (alloc_table(ctx, m->W, ncap, &nslots, ctx->hook_graph_mem > 0 ? ctx->hook_graph_mem : 0) != GK_OK) { if (nslots) (void)hipFree(nslots); return GK_OK; }   // keep tombstones if memory is short
     int g2 = grid_for(ctx, m->capacity, BLOCK);
     if (m->W == 1)
         hipLaunchKernelGGL(k_rehash<1>, dim3(g2), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, m->capacity,
