@@ -222,6 +222,9 @@ template <int W> struct Table {
     u32 tagged;        // 1 for k = 64: slot index mod 4 carries the key's last base
     u32 both;          // 1: the table may hold ANY orientation of a k-mer (keys inserted verbatim through the ABI), not only
                        // the hash-rule one: strand-agnostic lookups (table_find_either) must probe both, always
+    u32 aligned;       // 1: a key's probe starts at the FIRST slot of its 128-byte line (home_pos): every read request of this
+                       // chip is a whole line, so a lookup in a sparse table then costs exactly one (the table the graph phase
+                       // reads; never with `tagged`)
     GK_HD u64 nseg() const { return (u64)nb2 << lnb1; }
     GK_HD u64 capacity() const { return nseg() << SegBits<W>::value; }
 };
@@ -229,6 +232,11 @@ template <int W> GK_HD u32 seg_l1(const Table<W> &t, u64 h) { return t.lnb1 ? (u
 template <int W> GK_HD u32 seg_fine(const Table<W> &t, u64 h) { return (u32)((((h >> 24) & 0xffffffffULL) * (u64)t.nb2) >> 32); }
 template <int W> GK_HD u32 seg_of(const Table<W> &t, u64 h) { return seg_l1(t, h) * t.nb2 + seg_fine(t, h); }
 template <int W> GK_HD u32 seg_pos(u64 h) { return (u32)h & ((1u << SegBits<W>::value) - 1u); }
+// where a key's probe starts in its segment
+template <int W> GK_HD u32 home_pos(const Table<W> &t, u64 h) {
+    constexpr u32 line_slots = 128u / (u32)sizeof(Slot<W>);
+    return t.aligned ? (seg_pos<W>(h) & ~(line_slots - 1u)) : seg_pos<W>(h);
+}
 
 struct Counters {      // device-resident, one per map
     unsigned long long size;        // live keys
@@ -339,7 +347,7 @@ struct GlobalAdd { GK_D void operator()(u32 *p, u32 v) const { add32_noret(p, v)
 template <int W> GK_D int table_add(const Table<W> &t, Kmer<W> key, u32 add, u32 *err) {
     const u64 h = slot_hash(key);
     Slot<W> *seg = t.slots + ((u64)seg_of(t, h) << SegBits<W>::value);
-    int r = seg_add(seg, seg_pos<W>(h), key, add, GlobalCas(), GlobalAdd(), t.tagged);
+    int r = seg_add(seg, home_pos(t, h), key, add, GlobalCas(), GlobalAdd(), t.tagged);
     if (r < 0) { *err = 1; return 0; }
     return r;
 }
@@ -372,7 +380,7 @@ GK_D i64 seg_find(const Slot<2> *seg, u32 pos, Kmer<2> key, u32 tagged = 0u) {
 template <int W> GK_D i64 table_find(const Table<W> &t, Kmer<W> key) {
     const u64 h = slot_hash(key);
     const u64 base = (u64)seg_of(t, h) << SegBits<W>::value;
-    i64 r = seg_find(t.slots + base, seg_pos<W>(h), key, t.tagged);
+    i64 r = seg_find(t.slots + base, home_pos(t, h), key, t.tagged);
     return r < 0 ? -1 : (i64)base + r;
 }
 template <int W> GK_D bool slot_live(const Slot<W> *s) { return s->w0 != KEY_EMPTY && s->w0 != KEY_TOMB; }

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(BLOCK) void k_classify(Table<W> t, int k, unsigned 
             q[j] = hx < hr ? x : rc;
             const u64 h = slot_hash(q[j]);
             qseg[j] = t.slots + ((u64)seg_of(t, h) << SegBits<W>::value);
-            qpos[j] = t.tagged ? ((seg_pos<W>(h) & ~3u) | key_tag(q[j])) : seg_pos<W>(h);
+            qpos[j] = t.tagged ? ((seg_pos<W>(h) & ~3u) | key_tag(q[j])) : home_pos(t, h);
             w0v[j] = qseg[j][qpos[j]].w0;
         }
 #pragma unroll
@@ -1406,7 +1406,7 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
     gk_ctx *ctx = m->ctx;
     // (m->dirty: keys were inserted verbatim and at least one was not its k-mer's hash-rule orientation — the reference's
     //  `contains` probes both strands unconditionally, Graph.scala:270; so does every lookup below then)
-    Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u, m->dirty ? 1u : 0u};
+    Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u, m->dirty ? 1u : 0u, m->aligned ? 1u : 0u};
     const int k = m->k;
     unsigned long long *d_cnt = nullptr;     // [0] terminals [1] cursor [2] edges [3] ecursor [4] pool cursor
     u32 *d_err = nullptr, *slot_node = nullptr;

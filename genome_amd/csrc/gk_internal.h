@@ -31,6 +31,7 @@ struct gk_ctx {
     int hook_p2_sorted = -1;         // over-provisioned L1 scatter: 1 = bucket-ordered write-out (A/B)
     int hook_p45_stripes = -1;       // over-provisioned fine level: stripes of L1 buckets whose P5 overlaps the next stripe's P4 (-1/1: none)
     int hook_graph_load_pct = -1;    // load factor (percent) of the table map_compact builds for the graph phase (-1: 40, 30 at k = 64)
+    int hook_graph_aligned = -1;     // compacted table: 1 = probes start at the first slot of a 128-byte line (A/B; loses), else anywhere
     int hook_graph_mem = -1;         // memory kind of the compacted table the graph phase reads: 0 ordinary, 1 uncached, 2 fine-grained (A/B)
     int hook_walk_queue = -1;        // unitig walk: 0 = one edge per lane (k_walk pass 0), else lanes fed from a queue (k_walk_q)
     int hook_p4_grid = -1;           // over-provisioned fine level: P4 workgroups per CU (-1: 4, or 2 of the 1024-thread form)
@@ -97,6 +98,8 @@ struct gk_map {
     uint64_t total_occurrences = 0;
     uint64_t grows = 0;
     bool skewed = false;         // a batch overflowed the pipeline's L1 regions and spill list (pathological skew): auto mode stays on the direct path
+    bool aligned = false;        // this table's probes start at the first slot of a 128-byte line (Table::aligned; set by map_compact,
+                                 // dropped when the contents are cleared)
     bool dirty = false;          // the table may hold keys that are not the hash-rule orientation of their k-mer (verbatim inserts):
                                  // Graph.buildGraph's `contains` then probes both strands, as the reference does (Graph.scala:270)
     bool sample_dirty = false;   // the distinct-key sample holds keys: gk_map_clear must reset it

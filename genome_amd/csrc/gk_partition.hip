@@ -958,7 +958,7 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W> t, const u64 
 #pragma unroll
                 for (int j = 0; j < KPT; j++) {
                     if (threadIdx.x + j * SBLOCK >= nk) continue;
-                    const u32 pos = seg_pos<W>(slot_hash(kk[j]));
+                    const u32 pos = home_pos(t, slot_hash(kk[j]));
                     if (mode == 0) { claims += lds_add_unbounded(seg, pos, kk[j]); continue; }
                     const int r = mode == 1 ? lds_add_look(seg, pos, kk[j]) : seg_add(seg, pos, kk[j], 1u, LdsCas(), LdsAdd(), t.tagged);
                     if (r < 0) overflow = true; else claims += (u32)r;
@@ -1153,7 +1153,7 @@ template <int W>
 static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d_keys, u64 nkeys_in, u64 nkeys_bound, bool from_empty,
                     const PartPlan &plan) {
     gk_ctx *ctx = m->ctx;
-    Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u};
+    Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u, 0u, m->aligned ? 1u : 0u};
     PartArrays a;
     const uint8_t *d_rec = src.rec;
     const u32 *d_off = src.off;
@@ -1338,7 +1338,7 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
                 const u64 ahead = (u64)((double)est_new * (1.0 + 0.6 * (std::max(plan.grow_ahead, 1.0) - 1.0)));
                 if (int rc = map_make_room(m, est_new, ahead, from_empty)) return rc;     // may replace the table (same lnb1)
             }
-            t = Table<W>{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u};
+            t = Table<W>{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u, 0u, m->aligned ? 1u : 0u};
             // many repeats: segment sizes are far from binomial -> exact fine level
             fine_exact = !op1 || plan.fine_exact || (double)est_new < 0.5 * (double)nkeys_bound;
         }

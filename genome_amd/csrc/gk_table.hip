@@ -129,7 +129,7 @@ __global__ __launch_bounds__(BLOCK) void k_rehash(const Slot<W> *__restrict__ ol
         // every key of the old table is unique: one CAS claims its new slot, the count goes in with a plain store
         const u64 h = slot_hash(key);
         Slot<W> *seg = t.slots + ((u64)seg_of(t, h) << SegBits<W>::value);
-        const i64 at = seg_claim_unique(seg, seg_pos<W>(h), key, t.tagged);
+        const i64 at = seg_claim_unique(seg, home_pos(t, h), key, t.tagged);
         if (at < 0) { err = 1; continue; }
         seg[at].extra = old[i].extra;
     }
@@ -254,7 +254,7 @@ static inline int grid_for(const gk_ctx *ctx, u64 work_items, int per_block) {
 }
 
 template <int W> static Table<W> table_of(const gk_map *m) {
-    return Table<W>{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u};
+    return Table<W>{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u, 0u, m->aligned ? 1u : 0u};
 }
 
 // mem_kind: 0 = ordinary device memory (pooled); 1 = hipDeviceMallocUncached, 2 = hipDeviceMallocFinegrained (A/B of the
@@ -373,10 +373,10 @@ static int map_grow_to(gk_map *m, uint64_t want_slots, bool rehash) {
         int grid = grid_for(ctx, m->capacity, BLOCK);
         if (m->W == 1)
             hipLaunchKernelGGL(k_rehash<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, m->capacity,
-                               Table<1>{(Slot<1> *)nslots, nnb2, nlnb1, 0u}, m->d_ctr);
+                               Table<1>{(Slot<1> *)nslots, nnb2, nlnb1, 0u, 0u, m->aligned ? 1u : 0u}, m->d_ctr);
         else
             hipLaunchKernelGGL(k_rehash<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots, m->capacity,
-                               Table<2>{(Slot<2> *)nslots, nnb2, nlnb1, m->k == 64 ? 1u : 0u}, m->d_ctr);
+                               Table<2>{(Slot<2> *)nslots, nnb2, nlnb1, m->k == 64 ? 1u : 0u, 0u, m->aligned ? 1u : 0u}, m->d_ctr);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { (void)hipFree(nslots); return hip_fail(ctx, e, "table rehash"); }
@@ -540,6 +540,7 @@ int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value) {
     else if (n == "p4_grid") ctx->hook_p4_grid = (int)value;
     else if (n == "graph_walk_queue") ctx->hook_walk_queue = (int)value;
     else if (n == "graph_mem") ctx->hook_graph_mem = (int)value;
+    else if (n == "graph_aligned") ctx->hook_graph_aligned = (int)value;
     else if (n == "graph_load_pct") ctx->hook_graph_load_pct = (int)value;
     else if (n == "fine_exact") ctx->hook_fine_exact = value < 0 ? -1 : value != 0;
     else return fail(ctx, GK_E_INVALID, "gk_ctx_set_option: unknown option '" + n + "'");
@@ -684,6 +685,7 @@ int gk_map_clear(gk_map *m) {
     m->tombstones = 0;
     m->total_occurrences = 0;
     m->dirty = false;
+    m->aligned = false;          // (the contents are void: the next build uses the count table's rule again)
     return GK_OK;
 }
 
@@ -1217,13 +1219,18 @@ static int map_compact(gk_map *m) {
     if (ncap > m->capacity) { nnb2 = m->nb2; nlnb1 = m->lnb1; ncap = m->capacity; }
     void *nslots = nullptr;
     if (alloc_table(ctx, m->W, ncap, &nslots, ctx->hook_graph_mem > 0 ? ctx->hook_graph_mem : 0) != GK_OK) { if (nslots) (void)hipFree(nslots); return GK_OK; }   // keep tombstones if memory is short
+    // A/B option "graph_aligned" = 1: probes of the compacted table start at the first slot of a 128-byte line (Table::aligned),
+    // so that a lookup — hit or miss — stays inside one line.  Measured at C3 it LOSES (classify 35.3 -> 41.4 ms, walk 12.9 ->
+    // 13.9): the key is then rarely in the first slot probed, and classify's second look at a line comes after the line has
+    // left the caches (16 waves x 64 lanes x 8 lookups in flight per CU), i.e. it is fetched from HBM again.  Off by default.
+    const bool aligned = m->k != 64 && ctx->hook_graph_aligned > 0;
     int g2 = grid_for(ctx, m->capacity, BLOCK);
     if (m->W == 1)
         hipLaunchKernelGGL(k_rehash<1>, dim3(g2), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, m->capacity,
-                           Table<1>{(Slot<1> *)nslots, nnb2, nlnb1, 0u}, m->d_ctr);
+                           Table<1>{(Slot<1> *)nslots, nnb2, nlnb1, 0u, 0u, aligned ? 1u : 0u}, m->d_ctr);
     else
         hipLaunchKernelGGL(k_rehash<2>, dim3(g2), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots, m->capacity,
-                           Table<2>{(Slot<2> *)nslots, nnb2, nlnb1, m->k == 64 ? 1u : 0u}, m->d_ctr);
+                           Table<2>{(Slot<2> *)nslots, nnb2, nlnb1, m->k == 64 ? 1u : 0u, 0u, aligned ? 1u : 0u}, m->d_ctr);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { (void)hipFree(nslots); return hip_fail(ctx, e, "table compaction"); }
@@ -1234,6 +1241,7 @@ static int map_compact(gk_map *m) {
     m->nb2 = nnb2;
     m->lnb1 = nlnb1;
     m->tombstones = 0;
+    m->aligned = aligned;
     return GK_OK;
 }
 
