@@ -747,16 +747,44 @@ __global__ __launch_bounds__(BLOCK) void k_node_class(GraphView g, const u32 *in
 // every interior node to the first non-interior end.  Sequential simplifyGraph produces exactly
 // one merged edge per chain (e1.seq ++ e2.seq, repeatedly) whatever the node order; chains of
 // interior nodes only (perfect cycles) vanish.  pass 0 counts, pass 1 writes.
+// A piece of LONG_PIECE bases and more is not copied base by base by the chain's lane (a contig graph has edges of hundreds of
+// kilobases: 4 Mbp of merges took 109 ms that way) but listed for k_copy_long, which copies it 16 bases per thread and ORs it
+// into the zeroed output; the lane ORs the bytes it shares with such a piece instead of storing them.
+static constexpr u64 LONG_PIECE = 1024;
+struct LongPiece { u64 src_off, dst_off, dst_base, len; };     // source byte offset, chain's byte offset, base position inside the chain, bases
+__device__ __forceinline__ void pool_or(uint8_t *pool, u64 byte, u32 val) {
+    atomicOr(reinterpret_cast<u32 *>(pool + (byte & ~3ull)), val << (8u * (u32)(byte & 3ull)));
+}
+__global__ __launch_bounds__(BLOCK) void k_copy_long(GraphView g, const LongPiece *pieces) {
+    const LongPiece p = pieces[blockIdx.x];
+    for (u64 c = threadIdx.x; c * 16 < p.len; c += BLOCK) {
+        const u64 first = c * 16;
+        const u32 n = (u32)min((u64)16, p.len - first);
+        // 16 bases = 32 bits of the source starting at base `first` (any 2-bit alignment): five bytes cover them
+        const u64 sb = p.src_off + (first >> 2);
+        u64 five = 0;
+        for (u32 q = 0; q < 5 && (first >> 2) + q < (p.len + 3) / 4; q++) five |= (u64)g.pool[sb + q] << (8 * q);
+        u32 bits = (u32)(five >> ((first & 3) * 2));
+        if (n < 16) bits &= (1u << (2 * n)) - 1u;
+        const u64 bitpos = p.dst_off * 8 + (p.dst_base + first) * 2;            // in the pool
+        u32 *w = reinterpret_cast<u32 *>(g.pool) + (bitpos >> 5);
+        const u32 sh = (u32)(bitpos & 31);
+        atomicOr(w, bits << sh);
+        if (sh && (bits >> (32 - sh))) atomicOr(w + 1, bits >> (32 - sh));
+    }
+}
 __global__ __launch_bounds__(BLOCK) void k_chain(GraphView g, const uint8_t *cls, int pass, u64 old_edges, u64 old_pool,
-                                                 unsigned long long *counters /* [0]=chains [1]=bytes */, u32 *merged_key) {
+                                                 unsigned long long *counters /* [0]=chains [1]=bytes [2]=long pieces */, u32 *merged_key,
+                                                 LongPiece *long_pieces) {
     for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < old_edges; e += (u64)gridDim.x * BLOCK) {
         if (!g.e_alive[e]) continue;
         const u32 s = g.e_start[e];
         if (cls[s] != 0 || cls[g.e_end[e]] != 1) continue;
         u64 total = 0;
-        u32 cur = (u32)e, maxn = NONE;
+        u32 cur = (u32)e, maxn = NONE, nlong = 0;
         for (u64 guard = 0; guard <= old_edges; guard++) {
             total += g.e_len[cur];
+            if (g.e_len[cur] >= LONG_PIECE) nlong++;
             const u32 v = g.e_end[cur];
             if (cls[v] != 1) break;
             if (maxn == NONE || node_less(g, maxn, v)) maxn = v;
@@ -766,6 +794,7 @@ __global__ __launch_bounds__(BLOCK) void k_chain(GraphView g, const uint8_t *cls
         if (pass == 0) {
             atomicAdd(&counters[0], 1ull);
             atomicAdd(&counters[1], (unsigned long long)bytes);
+            if (nlong) atomicAdd(&counters[2], (unsigned long long)nlong);
             continue;
         }
         const u64 id = old_edges + atomicAdd(&counters[0], 1ull);
@@ -773,20 +802,31 @@ __global__ __launch_bounds__(BLOCK) void k_chain(GraphView g, const uint8_t *cls
         // e1.seq ++ e2.seq ++ ...  (Graph.scala:225)
         u64 w = 0;
         u32 acc = 0;
+        bool shared = false;                           // the byte being assembled also holds bases of a long piece
         cur = (u32)e;
         for (u64 guard = 0; guard <= old_edges; guard++) {
             const u64 so = g.e_off[cur], sl = g.e_len[cur];
-            for (u64 i = 0; i < sl; i++) {
-                acc |= (u32)pool_get(g.pool, so, i) << ((w & 3) * 2);
-                if ((w & 3) == 3) { g.pool[off + (w >> 2)] = (uint8_t)acc; acc = 0; }
-                w++;
+            if (sl >= LONG_PIECE) {
+                if (w & 3) { pool_or(g.pool, off + (w >> 2), acc); acc = 0; }      // the piece starts inside this byte
+                long_pieces[atomicAdd(&counters[2], 1ull)] = LongPiece{so, off, w, sl};
+                w += sl;
+                shared = (w & 3) != 0;                                              // ... and ends inside that one
+            } else {
+                for (u64 i = 0; i < sl; i++) {
+                    acc |= (u32)pool_get(g.pool, so, i) << ((w & 3) * 2);
+                    if ((w & 3) == 3) {
+                        if (shared) pool_or(g.pool, off + (w >> 2), acc); else g.pool[off + (w >> 2)] = (uint8_t)acc;
+                        acc = 0; shared = false;
+                    }
+                    w++;
+                }
             }
             g.e_alive[cur] = 0;                        // removeEdge(e1); removeEdge(e2)  :223-224
             const u32 v = g.e_end[cur];
             if (cls[v] != 1) break;
             cur = g.out_edge[(u64)v * 4 + order_base(g.out_order[v], 0)];
         }
-        if (w & 3) g.pool[off + (w >> 2)] = (uint8_t)acc;
+        if (w & 3) { if (shared) pool_or(g.pool, off + (w >> 2), acc); else g.pool[off + (w >> 2)] = (uint8_t)acc; }
         g.e_start[id] = s;                             // addEdge(e1.start, e2.end, ...)   :225
         g.e_end[id] = g.e_end[cur];
         g.e_len[id] = total;
@@ -1625,42 +1665,49 @@ int gk_graph_simplify(gk_graph *g) {
     if (v.n_nodes == 0) return GK_OK;
     u32 *in_single = nullptr, *merged_key = nullptr;
     uint8_t *cls = nullptr;
-    unsigned long long *d_cnt = nullptr, h_cnt[2] = {0, 0};
+    unsigned long long *d_cnt = nullptr, h_cnt[3] = {0, 0, 0};
+    LongPiece *long_pieces = nullptr;
     auto done = [&](int code) {
         if (in_single) (void)hipFree(in_single);
         if (merged_key) (void)hipFree(merged_key);
         if (cls) (void)hipFree(cls);
         if (d_cnt) (void)hipFree(d_cnt);
+        if (long_pieces) (void)hipFree(long_pieces);
         return code;
     };
     hipError_t e = hipMalloc((void **)&in_single, v.n_nodes * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&merged_key, v.n_nodes * 16);
     if (e == hipSuccess) e = hipMalloc((void **)&cls, v.n_nodes);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_cnt, 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_cnt, 24);
     if (e == hipSuccess) e = hipMemsetAsync(in_single, 0xff, v.n_nodes * 4, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(merged_key, 0xff, v.n_nodes * 16, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, 16, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, 24, ctx->stream);
     if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_simplify: alloc"));
     const int gn = ggrid(ctx, v.n_nodes), ge = ggrid(ctx, std::max<u64>(v.n_edges, 1));
     hipLaunchKernelGGL(k_in_single, dim3(ge), dim3(BLOCK), 0, ctx->stream, v, in_single);
     hipLaunchKernelGGL(k_node_class, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, in_single, cls);
     const u64 old_edges = v.n_edges, old_pool = g->pool_used;
-    hipLaunchKernelGGL(k_chain, dim3(ge), dim3(BLOCK), 0, ctx->stream, v, cls, 0, old_edges, old_pool, d_cnt, merged_key);
+    hipLaunchKernelGGL(k_chain, dim3(ge), dim3(BLOCK), 0, ctx->stream, v, cls, 0, old_edges, old_pool, d_cnt, merged_key, (LongPiece *)nullptr);
     e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 16, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 24, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_simplify: count"));
     if (h_cnt[0]) {
         if (old_edges + h_cnt[0] >= (u64)NONE) return done(fail(ctx, GK_E_CAPACITY, "more than 2^32 graph edges"));
         if (int rc = graph_grow_edges(g, old_edges + h_cnt[0])) return done(rc);
-        if (old_pool + h_cnt[1] > g->pool_cap) {
-            e = dev_grow(ctx, &v.pool, old_pool, old_pool + h_cnt[1], ctx->stream);
+        if (old_pool + h_cnt[1] + 8 > g->pool_cap) {             // (+8: k_copy_long ORs whole 32-bit words, the last one may reach past the last byte)
+            e = dev_grow(ctx, &v.pool, old_pool, old_pool + h_cnt[1] + 8, ctx->stream);
             if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_simplify: pool"));
-            g->pool_cap = old_pool + h_cnt[1];
+            g->pool_cap = old_pool + h_cnt[1] + 8;
         }
-        e = hipMemsetAsync(d_cnt, 0, 16, ctx->stream);
+        e = hipMemsetAsync(d_cnt, 0, 24, ctx->stream);
+        if (e == hipSuccess && h_cnt[2]) {                       // long pieces are ORed into their place: it starts as zeroes
+            e = hipMalloc((void **)&long_pieces, h_cnt[2] * sizeof(LongPiece));
+            if (e == hipSuccess) e = hipMemsetAsync(v.pool + old_pool, 0, h_cnt[1], ctx->stream);
+        }
         if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_simplify"));
-        hipLaunchKernelGGL(k_chain, dim3(ge), dim3(BLOCK), 0, ctx->stream, v, cls, 1, old_edges, old_pool, d_cnt, merged_key);
+        hipLaunchKernelGGL(k_chain, dim3(ge), dim3(BLOCK), 0, ctx->stream, v, cls, 1, old_edges, old_pool, d_cnt, merged_key, long_pieces);
+        if (h_cnt[2]) hipLaunchKernelGGL(k_copy_long, dim3((unsigned)h_cnt[2]), dim3(BLOCK), 0, ctx->stream, v, long_pieces);
         v.n_edges = old_edges + h_cnt[0];
         g->pool_used = old_pool + h_cnt[1];
     }

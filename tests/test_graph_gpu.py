@@ -337,3 +337,39 @@ def test_graphbuilder_flow_through_the_mirror_api(ctx):
         assert comps == og2.num_components() and kept == og2.retain_largest()
         assert g.canonical() == oracle_canonical(og2)
         g.close(); kmers.close()
+
+
+@pytest.mark.parametrize("k,seed", [(21, 3), (31, 4), (41, 5)])
+def test_simplify_merges_long_edges_like_the_oracle(ctx, k, seed):
+    """A contig-like graph: a 24 kbp genome with a handful of SNPs between two haplotypes — edges of thousands of bases.
+    removeBubbles + simplifyGraph then concatenates LONG pieces (k_copy_long: 16 bases per thread, ORed into place, next to
+    short pieces copied by the chain's own lane at every 2-bit alignment) — the result must be the oracle's, base for base."""
+    rnd = random.Random(seed)
+    glen = 24000
+    g0 = [rnd.choice("AGCT") for _ in range(glen)]
+    h1 = list(g0)
+    # SNP sites at irregular distances: long stretches (> 1024 bases) and short ones (a few dozen bases) between them
+    sites = [700, 760, 3100, 3133, 5200, 9050, 9051 + k + 3, 14000, 14007 + 2 * k, 20500, 23000]
+    for p in sites:
+        h1[p] = rnd.choice([c for c in "AGCT" if c != h1[p]])
+    haps = ["".join(g0), "".join(h1)]
+    reads = []
+    for _ in range(9000):
+        h = rnd.choice(haps)
+        ln = rnd.randint(k + 20, 150)
+        st = rnd.randrange(0, glen - ln + 1)
+        r = h[st:st + ln]
+        reads.append(R.rev_comp(r) if rnd.random() < 0.5 else r)
+    binb = dna.reads_to_bin(reads)
+    m, ref = HipDNAMap(ctx, k), O.PMap(k, 1)
+    m.count_reads(binb, len(reads)); ref.count_reads(binb, len(reads))
+    m.deleteAll_lt(2); ref.delete_lt(2)
+    g, og = buildGraph(k, m), O.Graph(ref)
+    assert g.canonical() == oracle_canonical(og)
+    assert max(len(e[2]) for e in g.canonical()[1]) > 1024
+    g.removeBubbles(); og.remove_bubbles()
+    g.simplifyGraph(); og.simplify()
+    nodes, edges = g.canonical()
+    assert (nodes, edges) == oracle_canonical(og)
+    assert max(len(e[2]) for e in edges) > 4000           # long pieces were concatenated
+    g.close(); m.close()
