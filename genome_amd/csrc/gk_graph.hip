@@ -977,6 +977,9 @@ __global__ __launch_bounds__(BLOCK) void k_cc_sizes(GraphView g, const u32 *pare
     __syncthreads();
     const int lane = threadIdx.x & 63;
     u32 nroots = 0;
+    // (and the wave carries the last root's count from group to group: with a giant component nearly every group of 64 nodes
+    //  has that one root, so the wave adds it ONCE at the end instead of once per group — 4.4e5 atomics on one address at C3)
+    u32 c_root = 0xffffffffu, c_cnt = 0;                // wave-uniform
     for (u64 n0 = (u64)blockIdx.x * BLOCK + (threadIdx.x & ~63u); n0 < g.n_nodes; n0 += (u64)gridDim.x * BLOCK) {   // wave-uniform trip count
         const u64 n = n0 + lane;
         const bool active = n < g.n_nodes && g.node_alive[n];
@@ -986,11 +989,17 @@ __global__ __launch_bounds__(BLOCK) void k_cc_sizes(GraphView g, const u32 *pare
             const int leader = __ffsll((long long)todo) - 1;
             const u32 lr = __shfl(root, leader);
             const unsigned long long same = __ballot(active && root == lr);
-            if (lane == leader) atomicAdd(&size[lr], (u32)__popcll(same));
+            const u32 cnt = (u32)__popcll(same);
+            if (lr == c_root) c_cnt += cnt;
+            else if (cnt >= 8) {                        // a root that fills an eighth of the wave is worth carrying; the rest go straight out
+                if (lane == 0 && c_cnt) atomicAdd(&size[c_root], c_cnt);
+                c_root = lr; c_cnt = cnt;
+            } else if (lane == leader) atomicAdd(&size[lr], cnt);
             todo &= ~same;
         }
         nroots += (u32)__popcll(__ballot(active && root == (u32)n));
     }
+    if (lane == 0 && c_cnt) atomicAdd(&size[c_root], c_cnt);
     if (lane == 0 && nroots) atomicAdd(&s_roots, nroots);
     __syncthreads();
     if (threadIdx.x == 0 && s_roots) atomicAdd(ncomp, (unsigned long long)s_roots);
@@ -999,6 +1008,9 @@ __global__ __launch_bounds__(BLOCK) void k_cc_sizes(GraphView g, const u32 *pare
 // live edge adds its length to the root of its start node; lanes of a wave that share a root are combined first
 __global__ __launch_bounds__(BLOCK) void k_cc_edge_len(GraphView g, const u32 *parent, unsigned long long *len) {
     const int lane = threadIdx.x & 63;
+    u32 c_root = 0xffffffffu;                           // wave-uniform: the last root's sum travels from group to group (see k_cc_sizes)
+    unsigned long long c_len = 0;
+    bool c_any = false;
     for (u64 e0 = (u64)blockIdx.x * BLOCK + (threadIdx.x & ~63u); e0 < g.n_edges; e0 += (u64)gridDim.x * BLOCK) {
         const u64 e = e0 + lane;
         const bool active = e < g.n_edges && g.e_alive[e];
@@ -1013,10 +1025,15 @@ __global__ __launch_bounds__(BLOCK) void k_cc_edge_len(GraphView g, const u32 *p
             unsigned long long part = mine ? mylen : 0ull;
             for (int d = 32; d; d >>= 1) part += __shfl_down(part, d);
             part = __shfl(part, 0);
-            if (lane == leader) atomicAdd(&len[lr], part);
+            if (c_any && lr == c_root) c_len += part;
+            else if (__popcll(same) >= 8) {
+                if (lane == 0 && c_any) atomicAdd(&len[c_root], c_len);
+                c_root = lr; c_len = part; c_any = true;
+            } else if (lane == leader) atomicAdd(&len[lr], part);
             todo &= ~same;
         }
     }
+    if (lane == 0 && c_any) atomicAdd(&len[c_root], c_len);
 }
 // one (node count, summed out-edge length) pair per component, in root order
 __global__ __launch_bounds__(BLOCK) void k_cc_collect(GraphView g, const u32 *parent, const u32 *size, const unsigned long long *len,
