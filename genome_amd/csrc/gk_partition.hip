@@ -498,13 +498,28 @@ __global__ __launch_bounds__(NT, GK_OP_MIN_WAVES) void k_op_scatter1_reads(const
             }
             __syncthreads();
             const u32 ntot = rank[255];
-            for (u32 pos = threadIdx.x; pos < ntot; pos += NT) {
-                const u32 i = perm[pos], b = fbin[i];
-                const u32 j = pos - (b ? rank[b - 1] : 0u);
-                const Kmer<W> x = load_key<W>(flat, i);
-                if (j < lim[b]) store_key<W>(out, l1_slot(a, b, gb[b] + j), x);
-                else if constexpr (W == 1) spill_key<1>(a, x.lo, 0);
-                else spill_key<2>(a, x.lo, x.hi);
+            // four positions per thread and round: the chain perm -> (bin, key) -> (run start, limit, destination) is three LDS
+            // round trips deep, one at a time it is all latency
+            constexpr int U = 4;
+            for (u32 p0 = threadIdx.x; p0 < ntot; p0 += U * NT) {
+                u32 idx[U], bb[U], jj[U];
+                Kmer<W> xx[U];
+#pragma unroll
+                for (int q = 0; q < U; q++) { const u32 pos = p0 + q * NT; idx[q] = pos < ntot ? (u32)perm[pos] : 0xffffffffu; }
+#pragma unroll
+                for (int q = 0; q < U; q++) {
+                    bb[q] = idx[q] != 0xffffffffu ? (u32)fbin[idx[q]] : 0u;
+                    if (idx[q] != 0xffffffffu) xx[q] = load_key<W>(flat, idx[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < U; q++) jj[q] = (p0 + q * NT) - (bb[q] ? rank[bb[q] - 1] : 0u);
+#pragma unroll
+                for (int q = 0; q < U; q++) {
+                    if (idx[q] == 0xffffffffu) continue;
+                    if (jj[q] < lim[bb[q]]) store_key<W>(out, l1_slot(a, bb[q], gb[bb[q]] + jj[q]), xx[q]);
+                    else if constexpr (W == 1) spill_key<1>(a, xx[q].lo, 0);
+                    else spill_key<2>(a, xx[q].lo, xx[q].hi);
+                }
             }
         } else {
             // four keys per thread and round: each key is a chain LDS read -> LDS atomic -> LDS reads -> store, and with
@@ -1196,7 +1211,9 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         const u64 ntiles = (src.nreads + rs - 1) / rs;
         const int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)ctx->cu_count * GK_OP_WGS_PER_CU);
         const bool p2_wide = ctx->hook_p2_wide > 0;        // 1024 threads per tile: A/B option (gk_ctx_set_option "p2_wide")
-        const bool p2_sorted = ctx->hook_p2_sorted > 0;    // bucket-ordered write-out: A/B option ("p2_sorted")
+        // bucket-ordered write-out ("p2_sorted"): the same 0.60 ms as the window-ordered form for 8-byte keys (the LDS passes cost
+        // what the 64-lines-per-instruction stores cost), 6 % faster for 16-byte keys (0.97 -> 0.91 ms at k = 55): default there
+        const bool p2_sorted = ctx->hook_p2_sorted >= 0 ? ctx->hook_p2_sorted > 0 : W == 2;
         const int vu = src.verify_uniform ? 1 : 0;
         auto launch_p2 = [&](int g, const uint8_t *recs, u64 nr) {
 #define GK_P2(NT, SORTED)                                                                                                                 \
