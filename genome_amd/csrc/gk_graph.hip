@@ -22,6 +22,7 @@
 // simplifyGraph), this file reproduces "ascending k-mer order", the oracle's deterministic choice.
 #include <algorithm>
 #include <chrono>
+#include <memory>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -74,6 +75,10 @@ struct gk_graph {
     float build_ms[6] = {0, 0, 0, 0, 0, 0};
     u64 walked_bases = 0;        // bases emitted by the unitig construction (= total edge length at build time)
     int used_pj = 0;
+    // host snapshot of the edge arrays for the paired-end walks, valid while `epoch` (bumped by every edit) has not moved:
+    // a stream of gk_graph_walk_pairs batches downloads the graph once
+    u64 epoch = 0, snap_epoch = ~0ull;
+    std::shared_ptr<void> snap;
 };
 
 __device__ __forceinline__ int order_count(u32 o) { return (int)(o & 7u); }
@@ -1427,6 +1432,7 @@ static int graph_grow_edges(gk_graph *g, u64 new_n) {
 
 static int graph_refresh_counts(gk_graph *g) {
     gk_ctx *ctx = g->ctx;
+    g->epoch++;                  // (every edit of the graph ends here or in a point edit)
     unsigned long long *d = nullptr, h[3] = {0, 0, 0};
     GK_HIP(ctx, hipMalloc((void **)&d, 24));
     hipError_t e = hipMemsetAsync(d, 0, 24, ctx->stream);
@@ -2128,6 +2134,7 @@ int gk_graph_add_node(gk_graph *g, uint64_t lo, uint64_t hi, uint32_t *node_id) 
     if (v.n_nodes + 1 >= (u64)NONE) return fail(ctx, GK_E_CAPACITY, "more than 2^32 graph nodes");
     if (v.n_nodes + 1 > g->node_cap) { if (int rc = graph_grow_nodes(g, std::max<u64>(g->node_cap * 2, 16))) return rc; }
     const u32 n = (u32)v.n_nodes;
+    g->epoch++;
     hipLaunchKernelGGL(k_add_node, dim3(1), dim3(1), 0, ctx->stream, v, n, lo, hi);
     v.n_nodes++;
     g->live_nodes++;
@@ -2146,6 +2153,7 @@ int gk_graph_add_node(gk_graph *g, uint64_t lo, uint64_t hi, uint32_t *node_id) 
 static int graph_point_edit(gk_graph *g, bool start, uint32_t edge_id, uint32_t node_id) {
     if (int rc = check_graph(g)) return rc;
     gk_ctx *ctx = g->ctx;
+    g->epoch++;
     int *d = nullptr, h = 1;
     GK_HIP(ctx, hipMalloc((void **)&d, 4));
     if (start) hipLaunchKernelGGL(k_replace_start, dim3(1), dim3(1), 0, ctx->stream, g->v, edge_id, node_id, d);
@@ -2275,6 +2283,17 @@ int graph_snapshot(gk_graph *g, HostGraph &H) {
     H.in_list.resize(H.in_off[H.n_nodes]);
     std::vector<u32> cur(H.in_off.begin(), H.in_off.end() - 1);
     for (u64 e = 0; e < H.n_edges; e++) if (H.e_alive[e]) H.in_list[cur[H.e_end[e]]++] = (u32)e;
+    return GK_OK;
+}
+
+int graph_snapshot_cached(gk_graph *g, const HostGraph **out) {
+    if (!g->snap || g->snap_epoch != g->epoch) {
+        auto h = std::make_shared<HostGraph>();
+        if (int rc = graph_snapshot(g, *h)) return rc;
+        g->snap = h;
+        g->snap_epoch = g->epoch;
+    }
+    *out = static_cast<const HostGraph *>(g->snap.get());
     return GK_OK;
 }
 
@@ -2457,8 +2476,9 @@ int gk_graph_walk_pairs(gk_graph *g, gk_vmap *positions, gk_support *sup, const 
     int rc = gk_vmap_get_all_batch(positions, klo.data(), khi.data(), nq, off.data(), vals.data(), vals.size(), &total);
     if (rc == GK_E_CAPACITY) { vals.resize(total); rc = gk_vmap_get_all_batch(positions, klo.data(), khi.data(), nq, off.data(), vals.data(), vals.size(), &total); }
     if (rc) return rc;
-    HostGraph H;
-    if (int rc2 = graph_snapshot(g, H)) return rc2;
+    const HostGraph *Hp = nullptr;
+    if (int rc2 = graph_snapshot_cached(g, &Hp)) return rc2;
+    const HostGraph &H = *Hp;
     for (u64 i = 0; i < total; i++) {                       // a position must name something of THIS graph
         const Pos p = decode_pos(vals[i]);
         if (p.is_edge ? (p.id >= H.n_edges || !H.e_alive[p.id] || p.dist >= H.e_len[p.id]) : (p.id >= H.n_nodes || !H.node_alive[p.id]))
@@ -2598,8 +2618,9 @@ int gk_graph_split_by_support(gk_graph *g, const gk_support *sup, int cutoff, ui
     if (removed_edges) *removed_edges = 0;
     if (new_nodes) *new_nodes = 0;
     if (!sup) return fail(ctx, GK_E_INVALID, "gk_graph_split_by_support: null support handle");
-    HostGraph H;
-    if (int rc = graph_snapshot(g, H)) return rc;
+    const HostGraph *Hp = nullptr;
+    if (int rc = graph_snapshot_cached(g, &Hp)) return rc;
+    const HostGraph &H = *Hp;
     std::vector<u32> to_remove, new_src, end_edge, end_node, start_edge, start_node;
     const u32 first_new = (u32)H.n_nodes;
     for (u64 v = 0; v < H.n_nodes; v++) {
