@@ -196,6 +196,15 @@ def c3_object(ctx):
                             "unitig_walk": roof(9.25 * bs["walked_bases"], walk_ms),
                             "bytes_per_unit": "SURVEY.md §8d: 16.3 B/occurrence (+8 B/distinct key) count; 20 B/slot filter (12 B scan + 8 B tombstone; the wall "
                                               "time also holds the rebuild into a table sized for the survivors); 80 B/live key classify; 9.25 B/walked base"}}
+    # what the memory system carried for the graph kernels, from the committed PMC passes over this same flow (every read request is
+    # a 128-byte line, also for a 16-byte random probe: the algorithmic fractions above understate how busy HBM is)
+    pmc = os.path.join(ROOT, "profiles", "r02", "pmc_c3_v11.json")
+    if res is not None and os.path.exists(pmc):
+        k_ = json.load(open(pmc))["kernels"]
+        res["roofline"]["moved_by_pmc"] = {name: {"fetch_bytes": k_[name]["fetch_bytes"], "write_bytes": k_[name]["write_bytes"], "ms": k_[name]["total_ms"],
+                                                   "frac_of_hbm_peak": k_[name]["moved_frac_of_hbm_peak"]}
+                                            for name in ("k_classify<1>", "k_walk_q<1>", "k_filter_lt<1>", "k_rehash<1>") if name in k_}
+        res["roofline"]["moved_by_pmc"]["source"] = os.path.relpath(pmc, ROOT)
     m.close(); ctx.free(d)
     return res
 
