@@ -183,3 +183,51 @@ def test_graph_builder_cli_walk_pairs_stage(ctx, tmp_path):
     nodes, edges = oracle_canonical(og)
     assert sorted(open(str(out) + ".nodes.txt").read().split()) == nodes
     assert sorted(tuple(line.split()) for line in open(str(out) + ".edges.txt").read().splitlines()) == edges
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_walk_pairs_fuzz_small_cyclic_graphs(ctx, seed):
+    """Small genomes with tandem and inverted repeats (cycles, self-loops, palindromic neighbourhoods in the graph), small k,
+    short inserts: the walk's state space folds back on itself here, which is where a state-by-distance formulation and the
+    reference's memoised recursion could part ways.  Support, bad pairs and the split graph must still be the oracle's."""
+    rnd = random.Random(1000 + seed)
+    k = rnd.choice([11, 13, 15])
+    unit = "".join(rnd.choice("AGCT") for _ in range(rnd.randint(k + 2, 3 * k)))
+    parts = []
+    for _ in range(rnd.randint(4, 7)):
+        t = rnd.random()
+        if t < 0.35:
+            parts.append(unit * rnd.randint(1, 3))                                   # tandem copies: cycles
+        elif t < 0.5:
+            parts.append(R.rev_comp(unit))                                           # inverted copy
+        else:
+            parts.append("".join(rnd.choice("AGCT") for _ in range(rnd.randint(30, 120))))
+    g = "".join(parts)
+    L, reads = 30, []
+    for _ in range(2500):
+        ins = rnd.randint(45, 80)
+        if ins > len(g):
+            continue
+        s = rnd.randrange(0, len(g) - ins + 1)
+        frag = g[s:s + ins]
+        if rnd.random() < 0.5:
+            frag = R.rev_comp(frag)
+        reads += [frag[:L], R.rev_comp(frag)[:L]]
+    binb = dna.reads_to_bin(reads)
+    m, ref = HipDNAMap(ctx, k), O.PMap(k, 1)
+    m.count_reads(binb, len(reads)); ref.count_reads(binb, len(reads))
+    m.deleteAll_lt(2); ref.delete_lt(2)
+    g_, og = buildGraph(k, m), O.Graph(ref)
+    assert gpu_canonical(g_) == oracle_canonical(og)
+    lo, hi = rnd.choice([(20, 60), (30, 70), (10, 45)])
+    vm = g_.getGraphMap()
+    sup, osup = Support(ctx), O.Support()
+    g_.walkPairs(vm, sup, binb, len(reads) // 2, lo, hi)
+    walked = og.walk_pairs(osup, binb, len(reads) // 2, lo, hi)
+    assert sup.sizes()[1:] == (osup.bad_pairs(), walked)
+    assert gpu_support_by_content(g_, k, sup) == oracle_support_by_content(og, k, osup)
+    cutoff = rnd.choice([1, 2, 5])
+    assert g_.splitBySupport(sup, cutoff) == og.split_by_support(osup, cutoff)
+    g_.simplifyGraph()
+    assert gpu_canonical(g_) == oracle_canonical(og)
+    vm.close(); g_.close(); m.close()
