@@ -69,8 +69,11 @@ int gk_ctx_trim(gk_ctx *ctx);
 /* Test / A-B switches (never needed in production).  Their defaults are read from the environment ONCE, in
  * gk_ctx_create (GK_TEST_NO_RESERVE, GK_HOST_RAGGED, GK_PART_EXACT, GK_GRAPH_UNITIGS=walk|pj); no entry point
  * consults the environment afterwards.  Names: "test_no_reserve", "host_ragged", "part_exact" (0/1),
- * "graph_unitigs" (0 auto, 1 one lane per edge, 2 pointer jumping), "p4_direct" / "fine_exact" / "p4_wide" / "p2_wide" /
- * "p2_sorted" (-1 auto, 0, 1: A/B of the partitioned insert's kernels, gk_partition.hip). */
+ * "graph_unitigs" (0 auto, 1 walk, 2 pointer jumping), "graph_walk_queue" (0: one edge per lane), "graph_load_pct" (load factor
+ * of the compacted table, percent), "graph_mem" (1 uncached / 2 fine-grained memory for it), "graph_aligned" (1: probes start at
+ * the first slot of a 128-byte line), "p4_direct" / "fine_exact" / "p4_wide" / "p2_wide" / "p2_sorted" (-1 auto, 0, 1),
+ * "p45_stripes" (P5 of one stripe of L1 buckets beside P4 of the next), "p4_grid" (P4 workgroups per CU): A/B switches of
+ * the kernels in gk_partition.hip / gk_graph.hip; what each measured is in DESIGN.md and profiles/r02. */
 int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value);
 /* Pinned host memory: gk_map_count_reads / gk_prefilter_add_reads read the caller's `.bin` buffer with asynchronous copies
  * that overlap the insert kernels only if the buffer is page-locked — allocate it here, or register an existing one (a JNI
