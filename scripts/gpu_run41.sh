@@ -1,0 +1,15 @@
+set -o pipefail
+mkdir -p gpurun_out
+one() {  # label, lib, args
+  label=$1; lib=$2; shift 2
+  GK_LIB_PATH=$lib timeout -k 10 100 python bench.py --steps 20 --warmup 3 --no-extras --no-cpu-baseline "$@" > gpurun_out/r3k_b.json 2>> gpurun_out/r3k.err || return 1
+  python - "$label" <<'PY'
+import json,sys
+d=json.load(open('gpurun_out/r3k_b.json')); r=d["roofline"]
+print(sys.argv[1], "ms/step %.3f" % d["ms_per_step"], "kernel %.3f" % r["kernel_ms"], {k:round(v,3) for k,v in (r["phases_ms"] or {}).items()})
+PY
+}
+one "U base" "" --mode U || exit 1
+for v in wavep2_64 wavep2_8; do
+  one "U $v (P2 TIMING ONLY)" $PWD/genome_amd/variants/$v.so --mode U || exit 1
+done
