@@ -31,6 +31,7 @@ struct gk_ctx {
     int hook_p2_sorted = -1;         // over-provisioned L1 scatter: 1 = bucket-ordered write-out (A/B)
     int hook_p45_stripes = -1;       // over-provisioned fine level: stripes of L1 buckets whose P5 overlaps the next stripe's P4 (-1/1: none)
     int hook_graph_load_pct = -1;    // load factor (percent) of the table map_compact builds for the graph phase (-1: 40, 30 at k = 64)
+    int hook_filter_classic = -1;    // deleteAll: 1 = tombstones + k_rehash (the older path), else the one-pass segment-wise filter + compaction
     int hook_graph_aligned = -1;     // compacted table: 1 = probes start at the first slot of a 128-byte line (A/B; loses), else anywhere
     int hook_graph_mem = -1;         // memory kind of the compacted table the graph phase reads: 0 ordinary, 1 uncached, 2 fine-grained (A/B)
     int hook_walk_queue = -1;        // unitig walk: 0 = one edge per lane (k_walk pass 0), else lanes fed from a queue (k_walk_q)

@@ -154,6 +154,93 @@ __global__ __launch_bounds__(BLOCK) void k_filter_lt(Slot<W> *slots, u64 ncap, i
     if (threadIdx.x == 0 && s_rm) atomicAdd(removed, (unsigned long long)s_rm);
 }
 
+// deleteAll((k, v) => v < rounds) (ArrayDNAMap.scala:164-173) and the rescale that follows it (:214), as ONE streaming pass:
+// the new table keeps the L1 bucket of every key and its fine bucket is a monotone rescaling of the same 32 hash bits
+// (seg_fine), so the keys of new segment (b1, fn) all live in a short run of OLD segments of the same L1 bucket.  One
+// workgroup per new segment reads that run (coalesced), keeps the survivors that are its own, builds the segment in LDS and
+// writes it out whole: no tombstone writes, no clear of the new table, no random access to HBM.
+static constexpr int CBLOCK = 512;
+// live slots with count >= rounds in every `every`-th segment (sizes the new table; exact sizes come from k_compact_seg)
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_count_ge_sample(const Slot<W> *slots, u64 nseg, u32 every, i32 rounds, unsigned long long *out) {
+    __shared__ u32 s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    constexpr u32 S = 1u << SegBits<W>::value;
+    u32 n = 0;
+    for (u64 s = (u64)blockIdx.x * every; s < nseg; s += (u64)gridDim.x * every)
+        for (u32 i = threadIdx.x; i < S; i += BLOCK) {
+            const Slot<W> *p = &slots[(s << SegBits<W>::value) + i];
+            if (slot_live(p) && (i32)slot_count(p) >= rounds) n++;
+        }
+    if (n) atomicAdd(&s_n, n);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) atomicAdd(out, (unsigned long long)s_n);
+}
+template <int W>
+__global__ __launch_bounds__(CBLOCK) void k_compact_seg(Table<W> old, Table<W> nw, i32 rounds, Counters *ctr, unsigned long long *kept_total) {
+    extern __shared__ uint4 cseg_raw[];
+    constexpr u32 S = 1u << SegBits<W>::value;
+    constexpr u32 NVEC = S * sizeof(Slot<W>) / 16;
+    constexpr u32 smask = S - 1u;
+    Slot<W> *seg = reinterpret_cast<Slot<W> *>(cseg_raw);
+    __shared__ u32 s_kept, s_err;
+    u32 wg_kept = 0;
+    const u64 nseg_new = nw.nseg();
+    for (u64 sn = blockIdx.x; sn < nseg_new; sn += gridDim.x) {
+        const u32 b1 = (u32)(sn / nw.nb2), fn = (u32)(sn % nw.nb2);
+        __syncthreads();
+        if (threadIdx.x == 0) { s_kept = 0; s_err = 0; }
+        for (u32 i = threadIdx.x; i < NVEC; i += CBLOCK) {
+            if constexpr (W == 1) cseg_raw[i] = make_uint4(~0u, ~0u, 0u, 0u);
+            else cseg_raw[i] = (i & 1) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
+        }
+        // the 32 hash bits x with seg_fine(nw, .) == fn: [xlo, xhi); the old fine buckets they fall into: f0 .. f1
+        const u64 xlo = (((u64)fn << 32) + nw.nb2 - 1) / nw.nb2, xhi = ((((u64)fn + 1) << 32) + nw.nb2 - 1) / nw.nb2;
+        const u32 f0 = (u32)((xlo * old.nb2) >> 32), f1 = (u32)(((xhi - 1) * old.nb2) >> 32);
+        __syncthreads();
+        u32 kept = 0;
+        bool err = false;
+        for (u32 f = f0; f <= f1; f++) {
+            const Slot<W> *src = old.slots + (((u64)b1 * old.nb2 + f) << SegBits<W>::value);
+            for (u32 i = threadIdx.x; i < S; i += CBLOCK) {
+                const Slot<W> sl = src[i];
+                if (sl.w0 == KEY_EMPTY || sl.w0 == KEY_TOMB || (i32)(sl.extra + 1u) < rounds) continue;
+                const Kmer<W> key = slot_key(src, i, 0u);
+                const u64 h = slot_hash(key);
+                if (seg_fine(nw, h) != fn) continue;
+                u32 p = home_pos(nw, h);
+                bool placed = false;
+                for (u32 n = 0; n <= smask && !placed; n++, p = (p + 1) & smask) {
+                    if constexpr (W == 1) {
+                        if (atomicCAS(reinterpret_cast<unsigned long long *>(&seg[p].w0), (unsigned long long)KEY_EMPTY, (unsigned long long)sl.w0) == KEY_EMPTY) {
+                            seg[p].extra = sl.extra;
+                            placed = true;
+                        }
+                    } else {
+                        // (keys are unique: a slot whose w0 we claim — or that holds an equal w0 — is ours only if its w1 is free)
+                        unsigned long long c0 = atomicCAS(reinterpret_cast<unsigned long long *>(&seg[p].w0), (unsigned long long)KEY_EMPTY, (unsigned long long)sl.w0);
+                        if (c0 == KEY_EMPTY || c0 == sl.w0) {
+                            if (atomicCAS(reinterpret_cast<unsigned long long *>(&seg[p].w1), (unsigned long long)KEY_EMPTY, (unsigned long long)sl.w1) == KEY_EMPTY) {
+                                seg[p].extra = sl.extra;
+                                placed = true;
+                            }
+                        }
+                    }
+                }
+                if (placed) kept++; else err = true;
+            }
+        }
+        if (kept) atomicAdd(&s_kept, kept);
+        if (err) s_err = 1;
+        __syncthreads();
+        uint4 *dst = reinterpret_cast<uint4 *>(nw.slots + (sn << SegBits<W>::value));
+        for (u32 i = threadIdx.x; i < NVEC; i += CBLOCK) dst[i] = cseg_raw[i];
+        if (threadIdx.x == 0) { wg_kept += s_kept; if (s_err) ctr->error = 1; }
+    }
+    if (threadIdx.x == 0 && wg_kept) atomicAdd(kept_total, (unsigned long long)wg_kept);
+}
+
 // Container.apply (ArrayDNAMap.scala:90-101) for a batch of keys.
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_get(const u64 *__restrict__ lo, const u64 *__restrict__ hi, u64 n,
@@ -541,6 +628,7 @@ int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value) {
     else if (n == "graph_walk_queue") ctx->hook_walk_queue = (int)value;
     else if (n == "graph_mem") ctx->hook_graph_mem = (int)value;
     else if (n == "graph_aligned") ctx->hook_graph_aligned = (int)value;
+    else if (n == "filter_classic") ctx->hook_filter_classic = (int)value;
     else if (n == "graph_load_pct") ctx->hook_graph_load_pct = (int)value;
     else if (n == "fine_exact") ctx->hook_fine_exact = value < 0 ? -1 : value != 0;
     else return fail(ctx, GK_E_INVALID, "gk_ctx_set_option: unknown option '" + n + "'");
@@ -1245,9 +1333,85 @@ static int map_compact(gk_map *m) {
     return GK_OK;
 }
 
+// filter + compaction as one streaming pass (k_compact_seg).  GK_OK with *done = true when it replaced the table; *done = false
+// when the geometry does not allow it (k = 64's tagged slots, another L1 fan-out, no memory for the new table) — the caller
+// then takes the tombstone + rehash path.
+static int filter_compact_streaming(gk_map *m, int32_t rounds, bool *done) {
+    gk_ctx *ctx = m->ctx;
+    *done = false;
+    if (m->k == 64 || ctx->hook_filter_classic > 0 || m->aligned || ctx->hook_graph_aligned > 0 || ctx->hook_graph_mem > 0) return GK_OK;
+    const u64 nseg = (u64)m->nb2 << m->lnb1;
+    unsigned long long *d2 = (unsigned long long *)map_scratch(m, 256);
+    if (!d2) return GK_E_CAPACITY;
+    unsigned long long h2[2] = {0, 0};
+    GK_HIP(ctx, hipMemsetAsync(d2, 0, 16, ctx->stream));
+    // 1. survivors, estimated from every 16th segment (the hash spreads keys evenly: +-1 % at any size that matters)
+    const u32 every = nseg >= 4096 ? 16u : 1u;
+    const int gs = (int)std::min<u64>((nseg + every - 1) / every, (u64)ctx->cu_count * 8);
+    if (m->W == 1) hipLaunchKernelGGL(k_count_ge_sample<1>, dim3(gs), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, nseg, every, rounds, d2);
+    else hipLaunchKernelGGL(k_count_ge_sample<2>, dim3(gs), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots, nseg, every, rounds, d2);
+    GK_HIP(ctx, hipGetLastError());
+    GK_HIP(ctx, hipMemcpyAsync(h2, d2, 8, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const u64 est = (u64)((double)h2[0] * every * 1.03) + 1024;
+    // 2. the new table's geometry (same rule as map_compact)
+    double graph_load = ctx->hook_graph_load_pct > 0 ? ctx->hook_graph_load_pct / 100.0 : 0.25;
+    if (ctx->hook_graph_load_pct <= 0) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+        free_b += ctx->pool_held;
+        if ((double)est / graph_load * (double)slot_bytes(m->W) > (double)free_b / 3.0) graph_load = 0.4;
+    }
+    uint32_t nnb2, nlnb1;
+    uint64_t ncap;
+    plan_segments(m->W, (uint64_t)((double)est / graph_load) + 1, &nnb2, &nlnb1, &ncap);
+    if (ncap > m->capacity) { nnb2 = m->nb2; nlnb1 = m->lnb1; ncap = m->capacity; }
+    if (nlnb1 != m->lnb1) return GK_OK;                    // the L1 bucket of a key would change: not a segment-local move
+    void *nslots = nullptr;
+    if (hipMalloc(&nslots, ncap * slot_bytes(m->W)) != hipSuccess) { (void)hipGetLastError(); return GK_OK; }    // (every slot is written below: no clear)
+    // 3. one workgroup per new segment
+    const size_t lds = (size_t)slot_bytes(m->W) << seg_bits_for(m->W);
+    const int gc = (int)std::min<u64>((u64)nnb2 << nlnb1, (u64)ctx->cu_count * 16);
+    hipError_t e = hipSuccess;
+    if (m->W == 1) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_compact_seg<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) hipLaunchKernelGGL(k_compact_seg<1>, dim3(gc), dim3(CBLOCK), lds, ctx->stream, table_of<1>(m), Table<1>{(Slot<1> *)nslots, nnb2, nlnb1, 0u}, rounds, m->d_ctr, d2 + 1);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_compact_seg<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) hipLaunchKernelGGL(k_compact_seg<2>, dim3(gc), dim3(CBLOCK), lds, ctx->stream, table_of<2>(m), Table<2>{(Slot<2> *)nslots, nnb2, nlnb1, 0u}, rounds, m->d_ctr, d2 + 1);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h2, d2, 16, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(nslots); return hip_fail(ctx, e, "filter + compaction"); }
+    const u64 kept = h2[1];
+    if (int rc = map_sync_counters(m)) {                   // a segment of the new table filled up (cannot at these loads): the old table stays
+        (void)hipFree(nslots);
+        return rc;
+    }
+    unsigned long long sz = kept;
+    GK_HIP(ctx, hipMemcpyAsync(&m->d_ctr->size, &sz, sizeof(sz), hipMemcpyHostToDevice, ctx->stream));
+    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));         // (`sz` is a stack variable)
+    GK_HIP(ctx, hipFree(m->slots));
+    m->slots = nslots;
+    m->capacity = ncap;
+    m->nb2 = nnb2;
+    m->lnb1 = nlnb1;
+    m->tombstones = 0;
+    m->size = kept;
+    m->aligned = false;
+    *done = true;
+    return GK_OK;
+}
+
 int gk_map_filter_lt(gk_map *m, int32_t rounds) {
     if (int rc = check_map(m)) return rc;
     gk_ctx *ctx = m->ctx;
+    {
+        bool done = false;
+        if (int rc = filter_compact_streaming(m, rounds, &done)) return rc;
+        if (done) return GK_OK;
+    }
     unsigned long long *d_removed = (unsigned long long *)map_scratch(m, 256);
     if (!d_removed) return GK_E_CAPACITY;
     GK_HIP(ctx, hipMemsetAsync(d_removed, 0, sizeof(unsigned long long), ctx->stream));
