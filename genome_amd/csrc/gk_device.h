@@ -246,6 +246,8 @@ struct Counters {      // device-resident, one per map
     unsigned long long sample_claims;   // keys the distinct-key sample has admitted since the last clear
     u32 noncanon;                   // 1 = a key inserted VERBATIM was not the hash-rule orientation of its k-mer (sticky until clear)
     u32 pad;
+    unsigned long long rebuild_kept;    // k_compact_seg: keys moved into the new table
+    unsigned long long rebuild_sample;  // k_count_ge_sample: survivors seen in the sampled segments
 };
 
 GK_D u64 cas64(u64 *p, u64 expect, u64 val) {

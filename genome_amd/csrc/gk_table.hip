@@ -346,6 +346,7 @@ template <int W> static Table<W> table_of(const gk_map *m) {
 
 // mem_kind: 0 = ordinary device memory (pooled); 1 = hipDeviceMallocUncached, 2 = hipDeviceMallocFinegrained (A/B of the
 // table the graph phase reads: every read request of ordinary memory is a 128-byte line, whatever the lane asked for)
+static int streaming_rebuild(gk_map *m, uint32_t nnb2, uint32_t nlnb1, uint64_t ncap, int32_t rounds, bool *done);     // (defined next to its kernel's host code)
 static int alloc_table(gk_ctx *ctx, int W, uint64_t cap, void **out, int mem_kind = 0) {
     if (mem_kind == 0) GK_HIP(ctx, hipMalloc(out, cap * slot_bytes(W)));
     else GK_HIP(ctx, hipExtMallocWithFlags(out, cap * slot_bytes(W), mem_kind == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained));
@@ -450,6 +451,12 @@ static int map_grow_to(gk_map *m, uint64_t want_slots, bool rehash) {
     uint32_t nnb2, nlnb1;
     uint64_t ncap;
     plan_segments(m->W, want_slots, &nnb2, &nlnb1, &ncap);
+    if (rehash && m->k != 64 && nlnb1 == m->lnb1 && ctx->hook_filter_classic <= 0) {
+        // same L1 fan-out: the keys move between neighbouring segments only — one streaming pass instead of a CAS per key
+        bool done = false;
+        if (int rc = ::streaming_rebuild(m, nnb2, nlnb1, ncap, INT32_MIN, &done)) return rc;
+        if (done) { m->grows++; return GK_OK; }
+    }
     void *nslots = nullptr;
     if (!rehash) {
         hipError_t e = hipMalloc(&nslots, ncap * slot_bytes(m->W));
@@ -1333,6 +1340,50 @@ static int map_compact(gk_map *m) {
     return GK_OK;
 }
 
+// Move the live keys with count >= rounds into a new table of geometry (nnb2, nlnb1 == m->lnb1) with k_compact_seg and install
+// it; the old table stays (and *done stays false) if the new one cannot be allocated.  Not for k = 64.
+static int streaming_rebuild(gk_map *m, uint32_t nnb2, uint32_t nlnb1, uint64_t ncap, int32_t rounds, bool *done) {
+    gk_ctx *ctx = m->ctx;
+    // (the counter lives in the map's Counters block, not in the pooled scratch: a caller further up — gk_map_add_counts through
+    //  map_reserve — may be holding its keys there)
+    unsigned long long h_kept = 0;
+    GK_HIP(ctx, hipMemsetAsync(&m->d_ctr->rebuild_kept, 0, 8, ctx->stream));
+    void *nslots = nullptr;
+    if (hipMalloc(&nslots, ncap * slot_bytes(m->W)) != hipSuccess) { (void)hipGetLastError(); return GK_OK; }    // (every slot is written below: no clear)
+    const size_t lds = (size_t)slot_bytes(m->W) << seg_bits_for(m->W);
+    const int gc = (int)std::min<u64>((u64)nnb2 << nlnb1, (u64)ctx->cu_count * 16);
+    hipError_t e = hipSuccess;
+    if (m->W == 1) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_compact_seg<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) hipLaunchKernelGGL(k_compact_seg<1>, dim3(gc), dim3(CBLOCK), lds, ctx->stream, table_of<1>(m), Table<1>{(Slot<1> *)nslots, nnb2, nlnb1, 0u}, rounds, m->d_ctr, &m->d_ctr->rebuild_kept);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_compact_seg<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) hipLaunchKernelGGL(k_compact_seg<2>, dim3(gc), dim3(CBLOCK), lds, ctx->stream, table_of<2>(m), Table<2>{(Slot<2> *)nslots, nnb2, nlnb1, 0u}, rounds, m->d_ctr, &m->d_ctr->rebuild_kept);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_kept, &m->d_ctr->rebuild_kept, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(nslots); return hip_fail(ctx, e, "streaming table rebuild"); }
+    const u64 kept = h_kept;
+    if (int rc = map_sync_counters(m)) {                   // a segment of the new table filled up (a sizing error): the old table stays
+        (void)hipFree(nslots);
+        return rc;
+    }
+    unsigned long long sz = kept;
+    GK_HIP(ctx, hipMemcpyAsync(&m->d_ctr->size, &sz, sizeof(sz), hipMemcpyHostToDevice, ctx->stream));
+    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));         // (`sz` is a stack variable)
+    GK_HIP(ctx, hipFree(m->slots));
+    m->slots = nslots;
+    m->capacity = ncap;
+    m->nb2 = nnb2;
+    m->lnb1 = nlnb1;
+    m->tombstones = 0;
+    m->size = kept;
+    m->aligned = false;
+    *done = true;
+    return GK_OK;
+}
+
 // filter + compaction as one streaming pass (k_compact_seg).  GK_OK with *done = true when it replaced the table; *done = false
 // when the geometry does not allow it (k = 64's tagged slots, another L1 fan-out, no memory for the new table) — the caller
 // then takes the tombstone + rehash path.
@@ -1341,10 +1392,9 @@ static int filter_compact_streaming(gk_map *m, int32_t rounds, bool *done) {
     *done = false;
     if (m->k == 64 || ctx->hook_filter_classic > 0 || m->aligned || ctx->hook_graph_aligned > 0 || ctx->hook_graph_mem > 0) return GK_OK;
     const u64 nseg = (u64)m->nb2 << m->lnb1;
-    unsigned long long *d2 = (unsigned long long *)map_scratch(m, 256);
-    if (!d2) return GK_E_CAPACITY;
-    unsigned long long h2[2] = {0, 0};
-    GK_HIP(ctx, hipMemsetAsync(d2, 0, 16, ctx->stream));
+    unsigned long long *d2 = &m->d_ctr->rebuild_sample;
+    unsigned long long h2[1] = {0};
+    GK_HIP(ctx, hipMemsetAsync(d2, 0, 8, ctx->stream));
     // 1. survivors, estimated from every 16th segment (the hash spreads keys evenly: +-1 % at any size that matters)
     const u32 every = nseg >= 4096 ? 16u : 1u;
     const int gs = (int)std::min<u64>((nseg + every - 1) / every, (u64)ctx->cu_count * 8);
@@ -1367,41 +1417,7 @@ static int filter_compact_streaming(gk_map *m, int32_t rounds, bool *done) {
     plan_segments(m->W, (uint64_t)((double)est / graph_load) + 1, &nnb2, &nlnb1, &ncap);
     if (ncap > m->capacity) { nnb2 = m->nb2; nlnb1 = m->lnb1; ncap = m->capacity; }
     if (nlnb1 != m->lnb1) return GK_OK;                    // the L1 bucket of a key would change: not a segment-local move
-    void *nslots = nullptr;
-    if (hipMalloc(&nslots, ncap * slot_bytes(m->W)) != hipSuccess) { (void)hipGetLastError(); return GK_OK; }    // (every slot is written below: no clear)
-    // 3. one workgroup per new segment
-    const size_t lds = (size_t)slot_bytes(m->W) << seg_bits_for(m->W);
-    const int gc = (int)std::min<u64>((u64)nnb2 << nlnb1, (u64)ctx->cu_count * 16);
-    hipError_t e = hipSuccess;
-    if (m->W == 1) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_compact_seg<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) hipLaunchKernelGGL(k_compact_seg<1>, dim3(gc), dim3(CBLOCK), lds, ctx->stream, table_of<1>(m), Table<1>{(Slot<1> *)nslots, nnb2, nlnb1, 0u}, rounds, m->d_ctr, d2 + 1);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_compact_seg<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) hipLaunchKernelGGL(k_compact_seg<2>, dim3(gc), dim3(CBLOCK), lds, ctx->stream, table_of<2>(m), Table<2>{(Slot<2> *)nslots, nnb2, nlnb1, 0u}, rounds, m->d_ctr, d2 + 1);
-    }
-    if (e == hipSuccess) e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(h2, d2, 16, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) { (void)hipFree(nslots); return hip_fail(ctx, e, "filter + compaction"); }
-    const u64 kept = h2[1];
-    if (int rc = map_sync_counters(m)) {                   // a segment of the new table filled up (cannot at these loads): the old table stays
-        (void)hipFree(nslots);
-        return rc;
-    }
-    unsigned long long sz = kept;
-    GK_HIP(ctx, hipMemcpyAsync(&m->d_ctr->size, &sz, sizeof(sz), hipMemcpyHostToDevice, ctx->stream));
-    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));         // (`sz` is a stack variable)
-    GK_HIP(ctx, hipFree(m->slots));
-    m->slots = nslots;
-    m->capacity = ncap;
-    m->nb2 = nnb2;
-    m->lnb1 = nlnb1;
-    m->tombstones = 0;
-    m->size = kept;
-    m->aligned = false;
-    *done = true;
-    return GK_OK;
+    return streaming_rebuild(m, nnb2, nlnb1, ncap, rounds, done);
 }
 
 int gk_map_filter_lt(gk_map *m, int32_t rounds) {
