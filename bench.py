@@ -231,6 +231,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="gk_ctx_set_option name=value (A/B switches of the insert pipeline)")
     ap.add_argument("--no-extras", action="store_true", help="skip the objects measured next to the headline at N=1: mode_G, pcie_inclusive, c3")
+    ap.add_argument("--no-c3", action="store_true", help="skip only the c3 object (A/B runs of the C2 pipeline)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -411,7 +412,8 @@ def main():
             out["pcie_inclusive"]["workload"] = ("SURVEY.md §8(d) reading of the metric: the headline's reads as a `.bin` stream in PINNED HOST memory -> complete "
                                                  "table in HBM (gk_map_count_reads; host framing walk + PCIe upload in sub-chunks overlapped with the L1 scatter)")
             ctx.host_free(hb)
-            out["c3"] = c3_object(ctx)
+            if not args.no_c3:
+                out["c3"] = c3_object(ctx)
         if not args.no_cpu_baseline and world == 1 and not sharded:
             sample_reads = min(n, 400_000)
             host = ctx.download(rec, sample_reads * stride).reshape(sample_reads, stride)

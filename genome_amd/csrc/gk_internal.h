@@ -18,7 +18,8 @@ struct gk_ctx {
     hipEvent_t gev2 = nullptr;                    // joins the second stream back into the first (striped P4/P5)
     hipEvent_t gev = nullptr;                     // "the host is back": the fine level's first launch (the GPU idles from pev[2] to here)
     hipStream_t copy_stream = nullptr;            // host -> device copies that overlap kernels on `stream` (host-fed inserts)
-    hipEvent_t cev[16] = {};                      // "sub-chunk j has landed" (round robin)
+    hipEvent_t cev[16] = {};                      // "sub-chunk j has landed" (round robin; 8..15: "piece j is scattered")
+    hipStream_t aux_stream = nullptr;             // P4 of the pieces of a pipelined batch, beside the next piece's scatter on `stream`
     int cu_count = 256;
     void *skm_counts = nullptr;      // device scratch of gk_shard_superkmers_dev (cursors, counts, overflow flag)
     uint32_t *d_flags = nullptr;     // [0] = a device record's length byte exceeded the declared read length (kernels without a map)
@@ -29,6 +30,7 @@ struct gk_ctx {
     int hook_p4_direct = -1;         // exact fine level: -1 auto (by nb2), 0 chunk sorted in LDS, 1 straight scatter with per-range cursors
     int hook_p2_wide = -1;           // over-provisioned L1 scatter: 1 = 1024 threads per tile (A/B)
     int hook_p2_sorted = -1;         // over-provisioned L1 scatter: 1 = bucket-ordered write-out (A/B)
+    int hook_p24_pieces = -1;        // pipelined batch (both levels over-provisioned): pieces whose P4 overlaps the next piece's scatter (-1: default, 0/1: off)
     int hook_p45_stripes = -1;       // over-provisioned fine level: stripes of L1 buckets whose P5 overlaps the next stripe's P4 (-1/1: none)
     int hook_graph_load_pct = -1;    // load factor (percent) of the table map_compact builds for the graph phase (-1: 40, 30 at k = 64)
     int hook_filter_classic = -1;    // deleteAll: 1 = tombstones + k_rehash (the older path), else the one-pass segment-wise filter + compaction

@@ -112,6 +112,9 @@ struct PartArrays {
     u32 *overflow;                  // spill list itself overflowed: abandon the pipeline (scratch only so far)
     u32 *noncanon;                  // key-array source taken verbatim from the caller: flag keys that are not canonical (nullptr: trusted)
     int k;
+    // P4 over a SLICE of every L1 region (pipelined pieces, see part_run): keys [l1_from[b], l1_to[b]) of bucket b, with the
+    // chunk table in cbase counting the slice's chunks only.  nullptr: the whole region.
+    const unsigned long long *l1_from, *l1_to;
 };
 __device__ __forceinline__ u64 l1_begin(const PartArrays &a, u32 b) { return a.op1 ? 0ull : a.l1_base[b]; }
 // Over-provisioned L1: where key number `pos` of L1 region `b` lives in bufA.  From 1.5 GB up (part_prepare sets
@@ -579,6 +582,32 @@ __global__ __launch_bounds__(256) void k_part_prefix1(PartArrays a, u32 nb1) {
     }
 }
 
+// The same for ONE PIECE of a pipelined batch (over-provisioned L1 level): the slice of every L1 region that the scatters
+// launched so far have filled beyond the previous piece's end — [prev_to[b], min(cursor1[b], cap1)) — and its chunk table.
+// Runs on the scattering stream between two pieces' scatters, so the cursors it reads are quiescent.
+__global__ __launch_bounds__(256) void k_part_prefix1_piece(PartArrays a, u32 nb1, const unsigned long long *prev_to, unsigned long long *from_out,
+                                                            unsigned long long *to_out, unsigned long long *cbase_out) {
+    __shared__ unsigned long long c[4];
+    const u32 i = threadIdx.x;
+    const unsigned long long to = i < nb1 ? min(a.cursor1[i], a.cap1) : 0ull;
+    const unsigned long long from = (i < nb1 && prev_to) ? min(prev_to[i], to) : 0ull;
+    const unsigned long long cv = (to - from + a.chunk_keys - 1) / a.chunk_keys;
+    unsigned long long icv = cv;
+    const int lane = i & 63, wave = i >> 6;
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long t1 = __shfl_up(icv, d);
+        if (lane >= d) icv += t1;
+    }
+    if (lane == 63) c[wave] = icv;
+    __syncthreads();
+    unsigned long long p1 = 0;
+    for (int w = 0; w < wave; w++) p1 += c[w];
+    from_out[i] = from;
+    to_out[i] = to;
+    cbase_out[i] = p1 + icv - cv;
+    if (i == 255) cbase_out[256] = p1 + icv;
+}
+
 // which L1 bucket does chunk / range `c` belong to (binary search over a 257-entry prefix)
 __device__ __forceinline__ u32 chunk_bucket(const unsigned long long *cbase, u64 c) {
     u32 lo = 0, hi = 256;
@@ -695,10 +724,13 @@ __global__ __launch_bounds__(NT) void k_part_scatter2(const u64 *__restrict__ bu
     constexpr u32 TILE = NT * KEYS_PER_THREAD;          // keys this workgroup sorts at a time (ranges and the chunk table stay in TILE2 units)
     // chunk / range table and L1 bucket extents: LDS copies (the binary search below was eight dependent global
     // loads per chunk: 16 % of the kernel by the phase timers)
-    __shared__ unsigned long long s_ubase[257], s_l1n[256], s_l1b[256];
+    __shared__ unsigned long long s_ubase[257], s_l1n[256], s_l1b[256], s_l1f[256];
     for (u32 b = threadIdx.x; b < 257u; b += NT) s_ubase[b] = RANGED ? a.rbase[b] : a.cbase[b];
     for (u32 b = threadIdx.x; b < 256u; b += NT) {
-        s_l1n[b] = b < (1u << t.lnb1) ? l1_count(a, b) : 0ull;
+        const bool live = b < (1u << t.lnb1);
+        const bool slice = !RANGED && a.l1_to != nullptr;              // (a slice of every region: pipelined pieces)
+        s_l1f[b] = live && slice ? a.l1_from[b] : 0ull;
+        s_l1n[b] = !live ? 0ull : slice ? a.l1_to[b] - a.l1_from[b] : l1_count(a, b);
         s_l1b[b] = l1_begin(a, b);
     }
     __syncthreads();
@@ -734,8 +766,9 @@ __global__ __launch_bounds__(NT) void k_part_scatter2(const u64 *__restrict__ bu
             Pos p{c, 0u, 0ull, 0u};
             if (c < total) {
                 p.b1 = chunk_bucket(s_ubase, c);
-                p.begin = (c - s_ubase[p.b1]) * TILE;
-                p.cnt = (u32)min((u64)TILE, s_l1n[p.b1] - p.begin);
+                const u64 rel = (c - s_ubase[p.b1]) * TILE;
+                p.begin = s_l1f[p.b1] + rel;
+                p.cnt = (u32)min((u64)TILE, s_l1n[p.b1] - rel);
             }
             return p;
         };
@@ -1044,7 +1077,13 @@ struct PartScratch {
     u64 bufA_keys = 0, bufB_keys = 0, spill_keys = 0;     // capacities in keys
     int W = 1;
     bool lds_attr_set = false;
+    unsigned long long *piece_tables = nullptr;      // inside blob: per piece [from 256][to 256][cbase 257] (pipelined batches)
 };
+static constexpr int MAX_PIECES = 8;
+#ifndef GK_P24_PIECES_DEFAULT
+#define GK_P24_PIECES_DEFAULT 1          // pieces of a pipelined batch ("p24_pieces"; 0/1 = one piece: the default, see part_run)
+#endif
+static constexpr size_t PIECE_WORDS = 256 + 256 + 257 + 7;
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -1077,8 +1116,9 @@ static int part_prepare_l1(gk_map *m, PartScratch *ps, u64 nkeys, bool op1, Part
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     // (nspill, overflow, n_failed are read back together at the end of a batch: contiguous, one copy)
     const size_t o_hist1 = take(256 * 8), o_l1 = take(257 * 8), o_cur1 = take(256 * 8), o_cb = take(257 * 8), o_rb = take(257 * 8),
-                 o_nsp = take(16), o_ovf = o_nsp + 8, o_nf = o_nsp + 12;
+                 o_nsp = take(16), o_ovf = o_nsp + 8, o_nf = o_nsp + 12, o_pieces = take((size_t)MAX_PIECES * PIECE_WORDS * 8);
     if (int rc = grow_raw(ctx, &ps->blob, &ps->blob_bytes, off)) return rc;
+    ps->piece_tables = (unsigned long long *)((char *)ps->blob + o_pieces);
     GK_HIP(ctx, hipMemsetAsync(ps->blob, 0, off, ctx->stream));
     char *b = (char *)ps->blob;
     arr->hist1 = (unsigned long long *)(b + o_hist1); arr->l1_base = (unsigned long long *)(b + o_l1);
@@ -1096,6 +1136,7 @@ static int part_prepare_l1(gk_map *m, PartScratch *ps, u64 nkeys, bool op1, Part
     arr->noncanon = nullptr;
     arr->k = m->k;
     arr->cap1 = arr->cap2 = 0; arr->spill_cap = 0; arr->stripe_nb1 = 0;
+    arr->l1_from = arr->l1_to = nullptr;
     // a range = up to MAX_RANGE_CHUNKS chunks, fewer when the batch is small (enough ranges to fill the chip)
     const u64 nchunks = nkeys / TILE2 + 1;
     arr->range_chunks = (u32)std::min<u64>(MAX_RANGE_CHUNKS, std::max<u64>(1, nchunks / ((u64)ctx->cu_count * 6)));
@@ -1201,6 +1242,59 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
     // (the sample keeps learning whenever it exists, also in batches whose estimate nobody waits for: a key it has not
     //  seen counts as new later — an overestimate, the safe side)
     const Sampler sp = m->d_sample ? Sampler{m->d_sample, m->sample_mask, &m->d_ctr->sample_claims} : Sampler{nullptr, 0, nullptr};
+    // Over-provisioned fine level with 8-byte keys: 8192-key chunks on 1024 threads when asked for (gk_ctx_set_option "p4_wide")
+    // (measured at C2, nb2 = 370: P4 0.66 -> 0.62 ms in mode U, 0.64 -> 0.62 in mode G: half the per-bin bookkeeping per key)
+    auto op_wide_now = [&]() { return W == 1 && (ctx->hook_p4_wide >= 0 ? ctx->hook_p4_wide != 0 : m->nb2 >= 256); };
+    // Over-provisioned segment regions are only safe to try on a table that is being rebuilt from empty (if they and
+    // the spill list overflow, the table is simply cleared again); a table that holds data gets the exact fine level
+    // unless the sample says the batch is near-distinct.
+    bool fine_exact = !op1 || plan.fine_exact || !from_empty;
+    const bool sync_between = plan.estimate || (op1 && !from_empty) || (src.verify_uniform && !from_empty);
+    // PIPELINED PIECES (option "p24_pieces", off by default).  When nothing has to come back to the host between the levels
+    // (table geometry final, both levels over-provisioned), the batch can be cut into pieces: both levels' regions are
+    // append-only, so P4 can take the slice of every L1 region that piece j's scatter filled while piece j+1 is being
+    // scattered (second stream).  Measured at C2 (profiles/r02/ab_p24_pieces.txt): device-resident input 2.05 ms in one piece,
+    // 2.12 / 2.19 / 2.21 / 2.34 in 2 / 3 / 4 / 8 — the two kernels' workgroups do not fit a CU's LDS together, so they take
+    // turns on the CUs and pay the extra launches; host-fed input gains only where the upload is slow enough to leave the
+    // GPU idle (28 GB/s: 2.99 -> 2.71 ms; 56 GB/s: 2.45 -> 2.47-2.55, the scatter alone keeps pace with the link).
+    const int want_pieces = ctx->hook_p24_pieces >= 0 ? ctx->hook_p24_pieces : GK_P24_PIECES_DEFAULT;
+    const bool pipelined = d_rec && op1 && !fine_exact && !sync_between && want_pieces > 1 && ctx->hook_p45_stripes <= 1 && m->nb2 <= MAX_NB2;
+    const u64 max_chunks = nkeys_bound / TILE2 + 257;
+    if (pipelined) {
+        if (int rc = part_prepare_fine(m, ps, nkeys_bound, true, &a)) return rc;
+        if (op_wide_now()) a.chunk_keys = 2 * TILE2;
+    }
+    // P4 of the over-provisioned fine level over L1 buckets [b_lo, b_hi) of `aa` (the whole batch, a stripe, or a piece's slices)
+    auto launch_p4_op = [&](const PartArrays &aa, hipStream_t st, u32 b_lo, u32 b_hi, u64 share) {
+        const int per_cu = ctx->hook_p4_grid > 0 ? ctx->hook_p4_grid : 4;           // ("p4_grid": workgroups per CU, A/B)
+        const int gchunks = (int)std::min<u64>(max_chunks / share + 1, (u64)ctx->cu_count * per_cu);
+        if (aa.chunk_keys == 2 * TILE2) {
+            if constexpr (W == 1) {
+                const size_t wide_lds = ScatterLds<1, 1024>::bytes(m->nb2);
+                hipLaunchKernelGGL((k_part_scatter2<1, false, 1024>), dim3(std::min(gchunks, ctx->cu_count * std::min(per_cu, 2))), dim3(1024), wide_lds, st, ps->bufA, t, aa,
+                                   max_chunks, ps->bufB, b_lo, b_hi);
+            }
+        } else
+            hipLaunchKernelGGL((k_part_scatter2<W, false, PBLOCK>), dim3(gchunks), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2), st, ps->bufA, t, aa, max_chunks,
+                               ps->bufB, b_lo, b_hi);
+    };
+    PartArrays a_last = a;          // pipelined: the last piece's view (its P4 runs on the main stream, after the join)
+    bool have_last = false;
+    // after piece j's scatter: its slice tables; every piece but the last goes to the second stream at once
+    auto piece_done = [&](int j, int npieces) -> int {
+        unsigned long long *tab = ps->piece_tables + (size_t)j * PIECE_WORDS;
+        const unsigned long long *prev = j ? ps->piece_tables + (size_t)(j - 1) * PIECE_WORDS + 256 : nullptr;
+        hipLaunchKernelGGL(k_part_prefix1_piece, dim3(1), dim3(256), 0, ctx->stream, a, nb1, prev, tab, tab + 256, tab + 512);
+        PartArrays aj = a;
+        aj.l1_from = tab; aj.l1_to = tab + 256; aj.cbase = tab + 512;
+        if (j == npieces - 1) { a_last = aj; have_last = true; return GK_OK; }
+        hipEvent_t ev = ctx->cev[8 + j % 8];
+        GK_HIP(ctx, hipEventRecord(ev, ctx->stream));
+        GK_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ev, 0));
+        launch_p4_op(aj, ctx->aux_stream, 0u, nb1, (u64)npieces);
+        GK_HIP(ctx, hipGetLastError());
+        return GK_OK;
+    };
     // ---- stage A: P1 + prefix + P2 (the L1 level) -----------------------------------------------------------
     GK_HIP(ctx, hipEventRecord(ctx->pev[0], ctx->stream));
     if (d_rec && op1) {
@@ -1225,8 +1319,22 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
             else GK_P2(PBLOCK, false);
 #undef GK_P2
         };
-        if (!src.host) {
+        if (!src.host && !pipelined) {
             launch_p2(grid, d_rec, src.nreads);
+        } else if (!src.host) {
+            // equal pieces of whole tiles, each big enough to fill the chip a few times over
+            // (an explicit "p24_pieces" also cuts small batches: tests)
+            const u64 min_piece = (u64)rs * (ctx->hook_p24_pieces > 1 ? 64ull : (u64)ctx->cu_count * GK_OP_WGS_PER_CU * 2);
+            const u64 np = std::max<u64>(1, std::min<u64>({(u64)want_pieces, (u64)MAX_PIECES, src.nreads / std::max<u64>(min_piece, 1)}));
+            const u64 sub_reads = ((src.nreads + np - 1) / np + rs - 1) / rs * rs;
+            const int npieces = (int)((src.nreads + sub_reads - 1) / sub_reads);
+            u64 r0 = 0;
+            for (int j = 0; j < npieces; j++, r0 += sub_reads) {
+                const u64 nr = std::min<u64>(sub_reads, src.nreads - r0);
+                const u64 nt = (nr + rs - 1) / rs;
+                launch_p2((int)std::min<u64>(std::max<u64>(nt, 1), (u64)ctx->cu_count * GK_OP_WGS_PER_CU), d_rec + (size_t)r0 * src.stride, nr);
+                if (int rc = piece_done(j, npieces)) return rc;
+            }
         } else {
             // Host-fed: upload in sub-chunks on the copy stream, scatter each as soon as it has landed.  The L1 regions are
             // append-only (cursor1), so P2 can run once per sub-chunk; P4 and P5 then see one batch.  With the caller's buffer
@@ -1255,6 +1363,7 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
                 const u64 nt = (nr + rs - 1) / rs;
                 const int gsub = (int)std::min<u64>(std::max<u64>(nt, 1), (u64)ctx->cu_count * GK_OP_WGS_PER_CU);
                 launch_p2(gsub, d_rec + off, nr);
+                if (pipelined) { if (int rc = piece_done(j, npieces)) return rc; }
             }
         }
     } else if (d_rec) {
@@ -1279,11 +1388,10 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         const int g2 = (int)std::min<u64>(std::max<u64>((nkeys_in + TILE2 - 1) / TILE2, 1), (u64)ctx->cu_count * 4);
         hipLaunchKernelGGL(k_part_scatter1_keys<W>, dim3(g2), dim3(PBLOCK), ScatterLds<W>::bytes(256u), ctx->stream, d_keys, nkeys_in, t, a, ps->bufA, sp);
     }
-    // over-provisioned fine level with 8-byte keys: 8192-key chunks on 1024 threads when asked for (gk_ctx_set_option "p4_wide")
-    // (measured at C2, nb2 = 370: P4 0.66 -> 0.62 ms in mode U, 0.64 -> 0.62 in mode G: half the per-bin bookkeeping per key)
-    const bool op_wide = W == 1 && (ctx->hook_p4_wide >= 0 ? ctx->hook_p4_wide != 0 : m->nb2 >= 256);
-    if (op_wide) a.chunk_keys = 2 * TILE2;
-    if (op1) hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(256), 0, ctx->stream, a, nb1);     // chunk / range tables from the cursors
+    if (!pipelined) {
+        if (op_wide_now()) a.chunk_keys = 2 * TILE2;      // (only the over-provisioned fine level's P4 reads it)
+        if (op1) hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(256), 0, ctx->stream, a, nb1);     // chunk / range tables from the cursors
+    }
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipEventRecord(ctx->pev[2], ctx->stream));
 
@@ -1315,14 +1423,9 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         m->retries_direct++;
         return PART_RETRY_DIRECT;
     };
-    // Over-provisioned segment regions are only safe to try on a table that is being rebuilt from empty (if they and
-    // the spill list overflow, the table is simply cleared again); a table that holds data gets the exact fine level
-    // unless the sample says the batch is near-distinct.
-    bool fine_exact = !op1 || plan.fine_exact || !from_empty;
     if (src.verify_uniform && !(d_rec && op1)) return fail(ctx, GK_E_STATE, "unverified host stream reached a path that cannot verify it");
     // (an unverified host stream behind a table that is being rebuilt from empty is checked at the END with everything else:
     //  if a length byte differed, the half-built table is simply void again — one host round trip less per batch)
-    const bool sync_between = plan.estimate || (op1 && !from_empty) || (src.verify_uniform && !from_empty);
     if (sync_between) {
         Counters *hc = reinterpret_cast<Counters *>(m->h_status);
         if (int rc = request_status()) return rc;
@@ -1361,12 +1464,11 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         }
     }
     if (m->nb2 > MAX_NB2) return fail(ctx, GK_E_CAPACITY, "table outgrew the partitioned insert path");   // (callers check part_supported first)
-    if (int rc = part_prepare_fine(m, ps, nkeys_bound, !fine_exact, &a)) return rc;
+    if (!pipelined) { if (int rc = part_prepare_fine(m, ps, nkeys_bound, !fine_exact, &a)) return rc; }
     const u64 nseg = t.nseg();
     GK_HIP(ctx, hipEventRecord(ctx->gev, ctx->stream));
 
     // ---- stage B: P3 + scans + P4 (the fine level) ---------------------------------------------------------
-    const u64 max_chunks = nkeys_bound / TILE2 + 257;
     const u64 max_ranges = max_chunks / a.range_chunks + 257;
     const u64 *fine_keys = ps->bufB;
     if (fine_exact) {
@@ -1393,19 +1495,6 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         } else
             hipLaunchKernelGGL((k_part_scatter2<W, true, PBLOCK>), dim3(gr), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2), ctx->stream, ps->bufA, t, a, max_ranges, ps->bufB, 0u, 256u);
     }
-    auto launch_p4_op = [&](u32 b_lo, u32 b_hi, u64 share) {          // over-provisioned fine level, L1 buckets [b_lo, b_hi)
-        const int per_cu = ctx->hook_p4_grid > 0 ? ctx->hook_p4_grid : 4;           // ("p4_grid": workgroups per CU, A/B)
-        const int gchunks = (int)std::min<u64>(max_chunks / share + 1, (u64)ctx->cu_count * per_cu);
-        if (op_wide && op1) {
-            if constexpr (W == 1) {
-                const size_t wide_lds = ScatterLds<1, 1024>::bytes(m->nb2);
-                hipLaunchKernelGGL((k_part_scatter2<1, false, 1024>), dim3(std::min(gchunks, ctx->cu_count * std::min(per_cu, 2))), dim3(1024), wide_lds, ctx->stream, ps->bufA, t, a,
-                                   max_chunks, ps->bufB, b_lo, b_hi);
-            }
-        } else
-            hipLaunchKernelGGL((k_part_scatter2<W, false, PBLOCK>), dim3(gchunks), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2), ctx->stream, ps->bufA, t, a, max_chunks,
-                               ps->bufB, b_lo, b_hi);
-    };
     auto launch_p5 = [&](hipStream_t st, u64 seg_lo, u64 seg_hi) {
         const int gseg = (int)std::min<u64>(seg_hi - seg_lo, (u64)ctx->cu_count * 24);
         hipLaunchKernelGGL(k_seg_insert<W>, dim3(gseg), dim3(SBLOCK), lds, st, t, fine_keys, a, from_empty ? 1 : 0, m->d_ctr, seg_lo, seg_hi);
@@ -1415,9 +1504,16 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
     // beside P4 of stripe i+1 (option "p45_stripes": 1 = one after the other).
     int stripes = fine_exact ? 1 : std::max(1, std::min<int>({ctx->hook_p45_stripes > 0 ? ctx->hook_p45_stripes : 1, (int)nb1, 16}));
     while (nb1 % (u64)stripes) stripes--;
-    if (!fine_exact && stripes == 1) {
+    if (pipelined && !have_last) return fail(ctx, GK_E_STATE, "partitioned insert: a pipelined batch ended without its last piece");
+    if (pipelined) {
+        // the earlier pieces' P4 (second stream) join here; the last piece's runs on this stream
+        GK_HIP(ctx, hipEventRecord(ctx->gev2, ctx->aux_stream));
+        GK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->gev2, 0));
         GK_HIP(ctx, hipEventRecord(ctx->pev[3], ctx->stream));
-        launch_p4_op(0u, (u32)nb1, 1);
+        launch_p4_op(a_last, ctx->stream, 0u, (u32)nb1, 1);
+    } else if (!fine_exact && stripes == 1) {
+        GK_HIP(ctx, hipEventRecord(ctx->pev[3], ctx->stream));
+        launch_p4_op(a, ctx->stream, 0u, (u32)nb1, 1);
     }
     if (stripes == 1) {
         GK_HIP(ctx, hipGetLastError());
@@ -1431,7 +1527,7 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         GK_HIP(ctx, hipEventRecord(ctx->pev[3], ctx->stream));
         const u32 per = (u32)(nb1 / (u64)stripes);
         for (int s = 0; s < stripes; s++) {
-            launch_p4_op(s * per, (s + 1) * per, (u64)stripes);
+            launch_p4_op(a, ctx->stream, s * per, (s + 1) * per, (u64)stripes);
             GK_HIP(ctx, hipGetLastError());
             hipEvent_t ev = ctx->cev[s % 16];
             GK_HIP(ctx, hipEventRecord(ev, ctx->stream));

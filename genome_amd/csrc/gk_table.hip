@@ -564,6 +564,11 @@ int gk_ctx_create(int device, gk_ctx **out) {
     if (e == hipSuccess) e = hipEventCreate(&ctx->gev);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->gev2, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {      // lowest priority: what runs there (P4 of the pieces that have landed) fills gaps and must not delay the main stream's scatters
+        int least = 0, greatest = 0;
+        e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, least);
+    }
     for (int i = 0; i < 16 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->cev[i], hipEventDisableTiming);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
@@ -602,6 +607,7 @@ void gk_ctx_destroy(gk_ctx *ctx) {
     if (ctx->gev2) (void)hipEventDestroy(ctx->gev2);
     for (int i = 0; i < 16; i++) if (ctx->cev[i]) (void)hipEventDestroy(ctx->cev[i]);
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
     delete ctx;
 }
 
@@ -631,6 +637,7 @@ int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value) {
     else if (n == "p2_sorted") ctx->hook_p2_sorted = value < 0 ? -1 : value != 0;
     else if (n == "p4_wide") ctx->hook_p4_wide = value < 0 ? -1 : value != 0;
     else if (n == "p45_stripes") ctx->hook_p45_stripes = (int)value;
+    else if (n == "p24_pieces") ctx->hook_p24_pieces = (int)value;
     else if (n == "p4_grid") ctx->hook_p4_grid = (int)value;
     else if (n == "graph_walk_queue") ctx->hook_walk_queue = (int)value;
     else if (n == "graph_mem") ctx->hook_graph_mem = (int)value;

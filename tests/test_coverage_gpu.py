@@ -257,3 +257,44 @@ def test_block_pool_reuse_and_trim(ctx):
         g.close(); m.close(); ctx.free(d)
         if cycle == 1:
             ctx.trim()
+
+
+@pytest.mark.parametrize("k,mode", [(31, "U"), (31, "G"), (47, "U")])
+def test_pipelined_pieces_build_the_same_table(ctx, k, mode):
+    """A batch whose table geometry is final up front is cut into pieces: P4 takes the slice of every L1 region that piece j's
+    scatter filled while piece j+1 is being scattered on the other stream ("p24_pieces").  Device-resident and host-fed input,
+    one piece / the default / eight pieces: the same (key, count) set each time (order-independent checksum over the table),
+    every key at its own slot, and — on a sample small enough for the oracle — the oracle's table."""
+    n, L_ = 400000, 100
+    stride = synth.record_stride(L_)
+    d = ctx.alloc(n * stride + 64)
+    ctx.synth_reads(d, n, L_, mode, 40 + k, 0, 200000 if mode == "G" else 0, 0.01 if mode == "G" else 0.0)
+    host = ctx.download(d, n * stride)
+    occ = n * (L_ - k + 1)
+    sums = set()
+    try:
+        for pieces in (0, -1, 8):
+            ctx.set_option("p24_pieces", pieces)
+            for src in ("dev", "host"):
+                m = HipDNAMap(ctx, k, occ)
+                m.set_insert_path("partitioned")
+                got = m.count_reads_dev(d, n, L_) if src == "dev" else m.count_reads(host, n)
+                assert got == occ
+                live, bad, total, chk = m.verify_checksum()
+                assert bad == 0 and total == occ and live == m.size()
+                sums.add((live, chk))
+                m.close()
+        assert len(sums) == 1, sums
+        # the oracle on the first 30 000 reads, pieces forced although the batch is small
+        ns = 30000
+        ref = O.PMap(k, 1)
+        assert ref.count_reads(host[:ns * stride].tobytes(), ns) == ns * (L_ - k + 1)
+        ctx.set_option("p24_pieces", 8)
+        m = HipDNAMap(ctx, k, ns * (L_ - k + 1))
+        m.set_insert_path("partitioned")
+        assert m.count_reads_dev(d, ns, L_) == ns * (L_ - k + 1)
+        assert_same_table(m.sorted_items(), ref.export_sorted())
+        m.close()
+    finally:
+        ctx.set_option("p24_pieces", -1)
+        ctx.free(d)
