@@ -392,6 +392,15 @@ def main():
                          "phases_ms": phase_detail, "dominant": dominant,
                          "traffic_source": (os.path.relpath(pmc_file, ROOT) if traffic else None)},
         }
+        # the same figures against what THIS card streams, measured in this run (after the timed region)
+        sb = ctx.stream_bench(1 << 30, 10)
+        rl = out["roofline"]
+        rl["measured_stream"] = dict(sb, what="gk_dev_stream_bench: 16-byte copy / fill / sum kernels over 1 GiB buffers, GB/s "
+                                             "(copy counts bytes read + written)")
+        rl["frac_of_measured_copy"] = achieved / sb["copy_GBps"] if sb["copy_GBps"] else None
+        if traffic:
+            rl["traffic_GBps"] = traffic / (avg_kernel_ms * 1e-3) / 1e9
+            rl["traffic_over_measured_copy"] = rl["traffic_GBps"] / sb["copy_GBps"] if sb["copy_GBps"] else None
         if sharded and dist_ms:
             out["per_rank_step_ms"] = {k_: float(np.mean([x[k_] for x in dist_ms])) for k_ in dist_ms[0]}
             out["per_rank_step_ms"]["what"] = ("rank 0, wall ms inside gk_dist_count_routed: route_wait = waiting for the routing kernel (reads -> super-k-mer records "

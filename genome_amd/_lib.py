@@ -66,6 +66,7 @@ SIGNATURES = {
     "gk_dev_free": (C.c_int, [vp, vp]),
     "gk_dev_upload": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "gk_dev_download": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "gk_dev_stream_bench": (C.c_int, [vp, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "gk_map_create": (C.c_int, [vp, C.c_int, C.c_uint64, C.POINTER(vp)]),
     "gk_map_destroy": (None, [vp]),
     "gk_map_k": (C.c_int, [vp]),

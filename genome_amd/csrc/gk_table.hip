@@ -714,6 +714,57 @@ int gk_dev_download(gk_ctx *ctx, void *host_dst, const void *dev_src, size_t nby
     return GK_OK;
 }
 
+// ---- what this card streams: the yardstick SURVEY.md §8(d) asks for next to the nominal peak -----------------------------
+// copy (one 16-byte load + one 16-byte store per lane and step), fill (stores only), sum (loads only); grid-stride,
+// 256 threads, 8 workgroups per CU — the shape of the library's own streaming kernels.
+__global__ __launch_bounds__(256) void k_stream_copy(const uint4 *__restrict__ in, uint4 *__restrict__ out, u64 n) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) out[i] = in[i];
+}
+__global__ __launch_bounds__(256) void k_stream_fill(uint4 *__restrict__ out, u64 n, u32 v) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) out[i] = make_uint4(v, v, v, v);
+}
+__global__ __launch_bounds__(256) void k_stream_sum(const uint4 *__restrict__ in, u64 n, u32 *sink) {
+    u32 acc = 0;
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
+        const uint4 v = in[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x9e3779b9u) *sink = acc;       // (keeps the loads alive; practically never taken)
+}
+
+int gk_dev_stream_bench(gk_ctx *ctx, size_t nbytes, int reps, double *gbps3) {
+    if (!ctx || !gbps3) return fail(ctx, GK_E_INVALID, "gk_dev_stream_bench: null argument");
+    if (nbytes < (1u << 20) || reps < 1 || reps > 1000) return fail(ctx, GK_E_INVALID, "gk_dev_stream_bench: nbytes >= 1 MiB, 1 <= reps <= 1000");
+    GK_HIP(ctx, hipSetDevice(ctx->device));
+    const u64 n = nbytes / 16;
+    uint4 *a = nullptr, *b = nullptr;
+    GK_HIP(ctx, hipMalloc((void **)&a, n * 16));
+    if (hipError_t e = hipMalloc((void **)&b, n * 16); e != hipSuccess) { (void)hipFree(a); return hip_fail(ctx, e, "gk_dev_stream_bench"); }
+    const int grid = (int)std::min<u64>((n + 255) / 256, (u64)ctx->cu_count * 8);
+    auto timed = [&](int which, double bytes_per_rep, double *out) -> int {
+        for (int r = -1; r < reps; r++) {          // (one untimed launch first)
+            if (r == 0) GK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+            if (which == 0) hipLaunchKernelGGL(k_stream_copy, dim3(grid), dim3(256), 0, ctx->stream, a, b, n);
+            else if (which == 1) hipLaunchKernelGGL(k_stream_fill, dim3(grid), dim3(256), 0, ctx->stream, b, n, 0xffffffffu);
+            else hipLaunchKernelGGL(k_stream_sum, dim3(grid), dim3(256), 0, ctx->stream, a, n, ctx->d_flags + 8);
+        }
+        GK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        GK_HIP(ctx, hipEventSynchronize(ctx->ev1));
+        float ms = 0;
+        GK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        *out = ms > 0 ? bytes_per_rep * reps / (ms * 1e-3) / 1e9 : 0.0;
+        return GK_OK;
+    };
+    int rc = GK_OK;
+    hipLaunchKernelGGL(k_stream_fill, dim3(grid), dim3(256), 0, ctx->stream, a, n, 0x12345678u);
+    if (!rc) rc = timed(0, 32.0 * (double)n, &gbps3[0]);
+    if (!rc) rc = timed(1, 16.0 * (double)n, &gbps3[1]);
+    if (!rc) rc = timed(2, 16.0 * (double)n, &gbps3[2]);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(a); (void)hipFree(b);
+    return rc;
+}
+
 int gk_map_create(gk_ctx *ctx, int k, uint64_t capacity_hint, gk_map **out) {
     if (!ctx || !out) return fail(ctx, GK_E_INVALID, "gk_map_create: null argument");
     *out = nullptr;

@@ -76,6 +76,12 @@ class Context:
         L.check(L.lib().gk_dev_download(self.h, out.ctypes.data, dptr, nbytes), self.h)
         return out
 
+    def stream_bench(self, nbytes: int = 1 << 30, reps: int = 10) -> dict:
+        """What this card streams (GB/s): copy = bytes read + written, fill = written, sum = read (gk_dev_stream_bench)."""
+        out = (C.c_double * 3)()
+        L.check(L.lib().gk_dev_stream_bench(self.h, nbytes, reps, out), self.h)
+        return {"copy_GBps": out[0], "fill_GBps": out[1], "sum_GBps": out[2], "buffer_bytes": nbytes, "reps": reps}
+
     def synth_reads(self, dptr: int, nreads: int, read_len: int, mode: str = "U", config_id: int = 0,
                     first_read: int = 0, genome_len: int = 0, err: float = 0.0):
         L.check(L.lib().gk_synth_reads_dev(self.h, dptr, nreads, read_len, 0 if mode == "U" else 1, config_id,

@@ -87,6 +87,10 @@ int gk_dev_alloc(gk_ctx *ctx, size_t nbytes, void **dev_ptr);
 int gk_dev_free(gk_ctx *ctx, void *dev_ptr);
 int gk_dev_upload(gk_ctx *ctx, void *dev_dst, const void *host_src, size_t nbytes);
 int gk_dev_download(gk_ctx *ctx, void *host_dst, const void *dev_src, size_t nbytes);
+/* What this card streams, measured: gbps3 = {copy (bytes read + written), fill (written), sum (read)} in GB/s over two
+ * scratch buffers of nbytes each, `reps` launches of each kernel.  The yardstick SURVEY.md §8(d) asks for beside the nominal
+ * HBM peak (bench.py reports the pipeline's traffic rate against it); no reference counterpart. */
+int gk_dev_stream_bench(gk_ctx *ctx, size_t nbytes, int reps, double *gbps3);
 
 /* ---- DNAMap[Int]: trait at S/ds/ArrayDNAMap.scala:49-60 ----------------------------------- */
 /* new ArrayDNAMap[Int](k)  (ArrayDNAMap.scala:62-72).  capacity_hint = expected number of distinct

@@ -495,3 +495,15 @@ def test_superkmer_records(ctx, k, L_, P):
             m.count_superkmers_dev(d_all, int(recs.sum()), int(kmers.sum()) - 1)   # announced count must match
         m.close()
     ctx.free(d_out); ctx.free(d); ctx.free(d_all)
+
+
+def test_stream_bench_reports_plausible_rates(ctx):
+    """gk_dev_stream_bench (the measured yardstick bench.py quotes next to the nominal HBM peak): three positive rates in a
+    plausible band for an HBM part, and the argument checks of the boundary."""
+    r = ctx.stream_bench(256 << 20, 3)
+    for name in ("copy_GBps", "fill_GBps", "sum_GBps"):
+        assert 200.0 < r[name] < 20000.0, r
+    with pytest.raises(L.GkError):
+        ctx.stream_bench(1024, 3)
+    with pytest.raises(L.GkError):
+        ctx.stream_bench(1 << 20, 0)
