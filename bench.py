@@ -288,22 +288,23 @@ def main():
     m.set_insert_path(args.insert_path)
 
     kernel_ms, kernel_units, phase_ms, dist_ms = [], [], [], []
-    pending = [False]
+    begun = [0]
 
-    def step(more=False):
+    def step(i=0, K=1):
         m.clear()
         if not sharded:
             m.count_reads_dev(rec, n, L)
             ms, kocc = m.last_count_kernel()
             kernel_ms.append(ms); kernel_units.append(kocc); phase_ms.append(m.last_phase_ms())
             return
-        # a streaming loop: the routing of the NEXT batch is launched on the second stream before this batch is exchanged and
-        # counted, so the route kernel hides behind the owner pipeline.  Every loop of K steps launches K routes and consumes K.
-        if not pending[0]:
+        # a streaming loop, three batches deep: the routing of batch i+2 is launched on the second stream and the exchange of
+        # batch i+1 posted on the communication stream before batch i is counted, so the route kernel and the wire time hide
+        # behind the owner pipeline.  Every loop of K steps launches K routes and consumes K (its first two are not hidden).
+        if i == 0:
+            begun[0] = 0
+        while begun[0] < min(i + 3, K):
             pm.route_begin(rec, n, L)
-        pending[0] = more
-        if more:
-            pm.route_begin(rec, n, L)
+            begun[0] += 1
         _, owned = pm.count_routed()
         ms, _ = m.last_count_kernel()
         kernel_ms.append(ms); kernel_units.append(owned); phase_ms.append(m.last_phase_ms()); dist_ms.append(hd.last_ms())
@@ -315,12 +316,12 @@ def main():
             ctx.sync()
 
     for i in range(args.warmup):
-        step(i + 1 < args.warmup)
+        step(i, args.warmup)
     kernel_ms.clear(); kernel_units.clear(); phase_ms.clear(); dist_ms.clear()
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i + 1 < args.steps)
+        step(i, args.steps)
     fence()
     dt = time.perf_counter() - t0
 
@@ -404,8 +405,8 @@ def main():
         if sharded and dist_ms:
             out["per_rank_step_ms"] = {k_: float(np.mean([x[k_] for x in dist_ms])) for k_ in dist_ms[0]}
             out["per_rank_step_ms"]["what"] = ("rank 0, wall ms inside gk_dist_count_routed: route_wait = waiting for the routing kernel (reads -> super-k-mer records "
-                                               "grouped by owner) that gk_dist_route_begin launched on the second stream one step earlier; "
-                                               "exchange = counts + records over RCCL (enqueue + the one host sync for the sizes); owner_count = "
+                                               "grouped by owner) that gk_dist_route_begin launched on the second stream two steps earlier; "
+                                               "exchange = counts + records of the NEXT batch over RCCL, posted on the communication stream before this batch is counted (enqueue + the one host sync for the sizes); owner_count = "
                                                "the pipeline over what arrived (stream-ordered behind the receives)")
         default_workload = args.mode == "U" and n == 1_000_000 and L == 150 and k == 31
         if world == 1 and not sharded and not args.no_extras and default_workload:

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "gk_internal.h"
@@ -87,22 +88,36 @@ struct gk_dist {
     gk_ctx *ctx = nullptr;
     int rank = 0, world = 1;
     ncclComm_t comm = nullptr;
-    // exchange scratch, kept between calls.  TWO send buffers: gk_dist_route_begin fills one on the second stream while the
-    // records of the previous batch still leave the other one.
-    uint8_t *d_sendbuf[2] = {nullptr, nullptr}, *d_recv = nullptr;
-    u64 send_cap[2] = {0, 0}, recv_records = 0;      // capacities in record slots (send: world regions of send_cap / world)
-    int cur = 0;                                     // the send buffer the next route goes to
+    // Every RCCL call of this handle goes to ONE stream of its own (operations on a communicator must not run concurrently):
+    // the exchange of batch i+1 can then be in flight while the owner pipeline of batch i runs on the context's stream.
+    hipStream_t comm_stream = nullptr;
+    // exchange scratch, kept between calls.  THREE send buffers (a route being written on the second stream, one whose
+    // records are on the wire, one being counted) and TWO receive buffers (on the wire / being counted).
+    static constexpr int NROUTE = 3;
+    uint8_t *d_sendbuf[NROUTE] = {nullptr, nullptr, nullptr}, *d_recv[2] = {nullptr, nullptr};
+    u64 send_cap[NROUTE] = {0, 0, 0}, recv_records[2] = {0, 0};      // capacities in record slots (send: world regions of send_cap / world)
     int slot = 0;                                    // record slot bytes the buffers were sized for
-    // routes that were begun and not yet consumed: at most two (one per send buffer), consumed first in, first out
-    struct Route { int k = 0, read_len = 0; const void *records = nullptr; u64 nreads = 0; };
-    Route route[2];
-    int npending = 0;                                // route[(cur - npending) & 1] is the oldest
-    unsigned long long *d_route_cnt = nullptr;       // [2][SKM_COUNT_WORDS] counters of the routing kernels on the second stream
+    // routes that were begun and not yet counted: at most three, first in, first out
+    struct Route {
+        int k = 0, read_len = 0; const void *records = nullptr; u64 nreads = 0;
+        bool exchanged = false;                      // counts known, records on the wire (or arrived) in d_recv[rbuf]
+        int rbuf = 0;
+        u64 nrec_in = 0, nkm_in = 0, sent = 0;
+        int error = 0;                               // its exchange, attempted ahead, failed: reported when the batch's turn comes
+        std::string error_text;
+    };
+    Route route[NROUTE];
+    int head = 0, npending = 0;                      // route[head] is the oldest; the next route goes to (head + npending) % NROUTE
+    u64 nexchanged = 0;                              // exchanges posted so far: the next one receives into d_recv[nexchanged & 1]
+    unsigned long long *d_route_cnt = nullptr;       // [NROUTE][SKM_COUNT_WORDS] counters of the routing kernels on the second stream
     unsigned long long *h_route_cnt = nullptr;       // pinned copy
-    hipEvent_t route_done[2] = {nullptr, nullptr};   // recorded behind each route's counter copy
+    hipEvent_t route_done[NROUTE] = {nullptr, nullptr, nullptr};   // recorded behind each route's counter copy
+    hipEvent_t exch_done[NROUTE] = {nullptr, nullptr, nullptr};    // recorded behind each batch's receives
+    hipEvent_t join = nullptr;                       // main stream -> communication stream
     unsigned long long *d_cnt = nullptr;             // [4 * world]: (records, k-mers) per peer to send, then as received
     unsigned long long *h_cnt = nullptr;             // pinned mirror
     float last_ms[4] = {0, 0, 0, 0};                 // route, exchange, owner count, total (wall)
+    float last_helper_ms = 0;                        // host time of the exchange that ran beside the last owner count
 };
 
 #define GK_NCCL(ctx, call)                                                                                        \
@@ -185,9 +200,12 @@ int gk_dist_create(gk_ctx *ctx, int rank, int world, const void *id128, gk_dist 
     }
     hipError_t e = hipMalloc((void **)&d->d_cnt, 4 * 64 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc((void **)&d->h_cnt, 4 * 64 * sizeof(unsigned long long), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMalloc((void **)&d->d_route_cnt, 2 * SKM_COUNT_WORDS * sizeof(unsigned long long));
-    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&d->route_done[i], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&d->h_route_cnt, 2 * SKM_COUNT_WORDS * sizeof(unsigned long long), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void **)&d->d_route_cnt, gk_dist::NROUTE * SKM_COUNT_WORDS * sizeof(unsigned long long));
+    for (int i = 0; i < gk_dist::NROUTE && e == hipSuccess; i++) e = hipEventCreateWithFlags(&d->route_done[i], hipEventDisableTiming);
+    for (int i = 0; i < gk_dist::NROUTE && e == hipSuccess; i++) e = hipEventCreateWithFlags(&d->exch_done[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->join, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&d->h_route_cnt, gk_dist::NROUTE * SKM_COUNT_WORDS * sizeof(unsigned long long), hipHostMallocDefault);
     if (e != hipSuccess) { int c = hip_fail(ctx, e, "gk_dist_create"); r->CommDestroy(d->comm); delete d; return c; }
     *out = d;
     return GK_OK;
@@ -197,11 +215,15 @@ void gk_dist_destroy(gk_dist *d) {
     if (!d) return;
     gk_ctx *ctx = d->ctx;
     if (d->ctx) { (void)hipSetDevice(d->ctx->device); (void)hipStreamSynchronize(d->ctx->stream); }
+    if (d->comm_stream) (void)hipStreamSynchronize(d->comm_stream);
     if (d->comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(d->comm);
     if (d->ctx && d->ctx->copy_stream) (void)hipStreamSynchronize(d->ctx->copy_stream);
-    for (int i = 0; i < 2; i++) if (d->d_sendbuf[i]) (void)hipFree(d->d_sendbuf[i]);
-    if (d->d_recv) (void)hipFree(d->d_recv);
-    for (int i = 0; i < 2; i++) if (d->route_done[i]) (void)hipEventDestroy(d->route_done[i]);
+    for (int i = 0; i < gk_dist::NROUTE; i++) if (d->d_sendbuf[i]) (void)hipFree(d->d_sendbuf[i]);
+    for (int i = 0; i < 2; i++) if (d->d_recv[i]) (void)hipFree(d->d_recv[i]);
+    for (int i = 0; i < gk_dist::NROUTE; i++) if (d->route_done[i]) (void)hipEventDestroy(d->route_done[i]);
+    for (int i = 0; i < gk_dist::NROUTE; i++) if (d->exch_done[i]) (void)hipEventDestroy(d->exch_done[i]);
+    if (d->join) (void)hipEventDestroy(d->join);
+    if (d->comm_stream) (void)hipStreamDestroy(d->comm_stream);
     if (d->d_route_cnt) (void)hipFree(d->d_route_cnt);
     if (d->h_route_cnt) (void)hipHostFree(d->h_route_cnt);
     if (d->d_cnt) (void)hipFree(d->d_cnt);
@@ -212,9 +234,17 @@ void gk_dist_destroy(gk_dist *d) {
 int gk_dist_rank(const gk_dist *d) { return d ? d->rank : -1; }
 int gk_dist_world(const gk_dist *d) { return d ? d->world : 0; }
 
+// The collectives below run on the context's stream; a batch whose exchange was posted ahead (gk_dist_count_routed) may still
+// be on the wire on the communication stream, and two operations of one communicator must not run side by side.
+static int dist_quiesce(gk_dist *d) {
+    GK_HIP(d->ctx, hipStreamSynchronize(d->comm_stream));
+    return GK_OK;
+}
+
 int gk_dist_barrier(gk_dist *d) {
     if (int rc = dist_check(d)) return rc;
     gk_ctx *ctx = d->ctx;
+    if (int rc = dist_quiesce(d)) return rc;
     GK_HIP(ctx, hipMemsetAsync(d->d_cnt, 0, 8, ctx->stream));
     GK_NCCL(ctx, rccl()->AllReduce(d->d_cnt, d->d_cnt, 1, ncclUint64, ncclSum, d->comm, ctx->stream));
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -225,6 +255,7 @@ int gk_dist_allreduce_f64(gk_dist *d, double *values, int n, int op_max) {
     if (int rc = dist_check(d)) return rc;
     gk_ctx *ctx = d->ctx;
     if (!values || n < 1 || n > 32) return fail(ctx, GK_E_INVALID, "gk_dist_allreduce_f64: 1..32 values");
+    if (int rc = dist_quiesce(d)) return rc;
     double *dv = reinterpret_cast<double *>(d->d_cnt);
     GK_HIP(ctx, hipMemcpyAsync(dv, values, n * 8, hipMemcpyHostToDevice, ctx->stream));
     GK_NCCL(ctx, rccl()->AllReduce(dv, dv, (size_t)n, ncclFloat64, op_max ? ncclMax : ncclSum, d->comm, ctx->stream));
@@ -237,6 +268,7 @@ int gk_dist_size(gk_dist *d, gk_map *local, uint64_t *total) {
     if (int rc = dist_check(d)) return rc;
     gk_ctx *ctx = d->ctx;
     if (!local || !total) return fail(ctx, GK_E_INVALID, "gk_dist_size: null argument");
+    if (int rc = dist_quiesce(d)) return rc;
     unsigned long long v = local->size;
     GK_HIP(ctx, hipMemcpyAsync(d->d_cnt, &v, 8, hipMemcpyHostToDevice, ctx->stream));
     GK_NCCL(ctx, rccl()->AllReduce(d->d_cnt, d->d_cnt, 1, ncclUint64, ncclSum, d->comm, ctx->stream));
@@ -263,13 +295,14 @@ static u64 route_want_records(int k, int P, u64 nreads, int read_len) {
     return std::max<u64>((u64)1024 * P, (u64)((double)nreads * per_read) / P * P);
 }
 
-// Route this rank's reads for the NEXT gk_dist_count_routed on the context's second stream and return at once: the routing
+// Route this rank's reads for a later gk_dist_count_routed on the context's second stream and return at once: the routing
 // kernel (0.6 ms per 10^6 reads, issue-bound) then overlaps whatever the main stream is doing — in a streaming loop, the
-// owner pipeline of the previous batch.  The records buffer must stay valid until gk_dist_count_routed returns.
+// owner pipeline of an earlier batch.  The records buffer must stay valid until the batch's gk_dist_count_routed returns.
 int gk_dist_route_begin(gk_dist *d, int k, const void *dev_records, uint64_t nreads, int read_len) {
     if (int rc = dist_check(d)) return rc;
     gk_ctx *ctx = d->ctx;
-    if (d->npending >= 2) return fail(ctx, GK_E_STATE, "gk_dist_route_begin: two routes are already waiting (gk_dist_count_routed consumes one)");
+    constexpr int NR = gk_dist::NROUTE;
+    if (d->npending >= NR) return fail(ctx, GK_E_STATE, "gk_dist_route_begin: three routes are already waiting (gk_dist_count_routed consumes one)");
     if (!dev_records && nreads) return fail(ctx, GK_E_INVALID, "gk_dist_route_begin: null records");
     if (read_len < 0 || read_len > 255) return fail(ctx, GK_E_FORMAT, "read_len must be 0..255 (one length byte per record)");
     if (!k_supported(k)) return fail(ctx, GK_E_UNSUPPORTED_K, "k=" + std::to_string(k) + " unsupported");
@@ -278,45 +311,42 @@ int gk_dist_route_begin(gk_dist *d, int k, const void *dev_records, uint64_t nre
         if (d->npending) return fail(ctx, GK_E_KLEN, "gk_dist_route_begin: a route for another key width is still waiting");
         GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         GK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
-        for (int i = 0; i < 2; i++) { if (d->d_sendbuf[i]) GK_HIP(ctx, hipFree(d->d_sendbuf[i])); d->d_sendbuf[i] = nullptr; d->send_cap[i] = 0; }
-        if (d->d_recv) { GK_HIP(ctx, hipFree(d->d_recv)); d->d_recv = nullptr; }
-        d->recv_records = 0;
+        GK_HIP(ctx, hipStreamSynchronize(d->comm_stream));
+        for (int i = 0; i < NR; i++) { if (d->d_sendbuf[i]) GK_HIP(ctx, hipFree(d->d_sendbuf[i])); d->d_sendbuf[i] = nullptr; d->send_cap[i] = 0; }
+        for (int i = 0; i < 2; i++) { if (d->d_recv[i]) GK_HIP(ctx, hipFree(d->d_recv[i])); d->d_recv[i] = nullptr; d->recv_records[i] = 0; }
         d->slot = slot;
     }
-    const int b = d->cur;
+    const int b = (d->head + d->npending) % NR;
+    // (the buffer's previous batch was counted before this slot could come round again: its records have left)
     if (int rc = dist_grow(ctx, &d->d_sendbuf[b], &d->send_cap[b], std::max(route_want_records(k, P, nreads, read_len), d->send_cap[b]), slot)) return rc;
     if (int rc = skm_route_launch(ctx, ctx->copy_stream, d->d_route_cnt + b * SKM_COUNT_WORDS, d->h_route_cnt + b * SKM_COUNT_WORDS, k, dev_records, nreads,
                                   read_len, P, d->d_sendbuf[b], d->send_cap[b])) return rc;
     GK_HIP(ctx, hipEventRecord(d->route_done[b], ctx->copy_stream));
-    d->route[b].k = k; d->route[b].read_len = read_len; d->route[b].records = dev_records; d->route[b].nreads = nreads;
+    gk_dist::Route &rt = d->route[b];
+    rt = gk_dist::Route();
+    rt.k = k; rt.read_len = read_len; rt.records = dev_records; rt.nreads = nreads;
     d->npending++;
-    d->cur ^= 1;
     return GK_OK;
 }
 
-// The rest of the batch begun by gk_dist_route_begin: wait for its route, exchange counts and records, count what arrived.
-int gk_dist_count_routed(gk_dist *d, gk_map *local, uint64_t *occurrences_sent, uint64_t *occurrences_owned) {
-    if (int rc = dist_check(d)) return rc;
+// Counts and records of route slot b over RCCL, on the communication stream: waits (host) for the route and for the
+// per-peer sizes, then posts the sends and receives and returns — the records are on the wire when this returns, and
+// exch_done[b] fires when they have arrived.  ms2 += {waiting for the route, the exchange's host time}.
+static int dist_exchange(gk_dist *d, int b, float *ms2) {
     gk_ctx *ctx = d->ctx;
-    if (occurrences_sent) *occurrences_sent = 0;
-    if (occurrences_owned) *occurrences_owned = 0;
-    if (!d->npending) return fail(ctx, GK_E_STATE, "gk_dist_count_routed: no route was begun (gk_dist_route_begin)");
-    const int b = (d->cur - d->npending) & 1;
-    const gk_dist::Route rt = d->route[b];
-    if (!local || local->ctx != ctx) return fail(ctx, GK_E_INVALID, "gk_dist_count_routed: the local map must live on the handle's context");
-    if (local->k != rt.k) return fail(ctx, GK_E_KLEN, "gk_dist_count_routed: the route was begun for another k");
-    d->npending--;
+    gk_dist::Route &rt = d->route[b];
     const int k = rt.k, P = d->world, slot = d->slot;
     unsigned long long *d_rc = d->d_route_cnt + b * SKM_COUNT_WORDS, *h_rc = d->h_route_cnt + b * SKM_COUNT_WORDS;
     const double t0 = now_ms();
     // ---- 1. the route's counters (it ran on the second stream, possibly long ago)
     uint64_t recs[64], kmers[64];
-    GK_HIP(ctx, hipEventSynchronize(d->route_done[b]));        // this route only: the next one may already be queued behind it
+    GK_HIP(ctx, hipEventSynchronize(d->route_done[b]));        // this route only: later ones may already be queued behind it
     int rrc = skm_route_finish(ctx, h_rc, rt.nreads && rt.read_len >= k, P, d->send_cap[b], recs, kmers);
     for (int attempt = 0; rrc == GK_E_CAPACITY && attempt < 4; attempt++) {       // a region was too small: route again, in place, bigger
         u64 worst = 0;
         for (int p = 0; p < P; p++) worst = std::max<u64>(worst, recs[p]);
         const u64 want = std::max<u64>(d->send_cap[b] * 2, (worst + worst / 8 + 1024) * P);
+        GK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));                       // (later routes share the stream: let them finish)
         if (int rc = dist_grow(ctx, &d->d_sendbuf[b], &d->send_cap[b], want, slot)) return rc;
         if (int rc = skm_route_launch(ctx, ctx->copy_stream, d_rc, h_rc, k, rt.records, rt.nreads, rt.read_len, P, d->d_sendbuf[b], d->send_cap[b])) return rc;
         GK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
@@ -326,40 +356,100 @@ int gk_dist_count_routed(gk_dist *d, gk_map *local, uint64_t *occurrences_sent, 
     const double t1 = now_ms();
     // ---- 2. counts: (records, k-mers) for every peer, one tiny all-to-all; the sizes then reach the host
     const u64 region = d->send_cap[b] / (u64)P;
+    hipStream_t cs = d->comm_stream;
     u64 sent = 0;
     for (int p = 0; p < P; p++) { d->h_cnt[2 * p] = recs[p]; d->h_cnt[2 * p + 1] = kmers[p]; sent += kmers[p]; }
     unsigned long long *d_in = d->d_cnt, *d_out = d->d_cnt + 2 * 64;
-    GK_HIP(ctx, hipMemcpyAsync(d_in, d->h_cnt, 2 * P * 8, hipMemcpyHostToDevice, ctx->stream));
+    GK_HIP(ctx, hipMemcpyAsync(d_in, d->h_cnt, 2 * P * 8, hipMemcpyHostToDevice, cs));
     Rccl *r = rccl();
     GK_NCCL(ctx, r->GroupStart());
     for (int p = 0; p < P; p++) {
-        GK_NCCL(ctx, r->Send(d_in + 2 * p, 2, ncclUint64, p, d->comm, ctx->stream));
-        GK_NCCL(ctx, r->Recv(d_out + 2 * p, 2, ncclUint64, p, d->comm, ctx->stream));
+        GK_NCCL(ctx, r->Send(d_in + 2 * p, 2, ncclUint64, p, d->comm, cs));
+        GK_NCCL(ctx, r->Recv(d_out + 2 * p, 2, ncclUint64, p, d->comm, cs));
     }
     GK_NCCL(ctx, r->GroupEnd());
     unsigned long long *h_out = d->h_cnt + 2 * 64;
-    GK_HIP(ctx, hipMemcpyAsync(h_out, d_out, 2 * P * 8, hipMemcpyDeviceToHost, ctx->stream));
-    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GK_HIP(ctx, hipMemcpyAsync(h_out, d_out, 2 * P * 8, hipMemcpyDeviceToHost, cs));
+    GK_HIP(ctx, hipStreamSynchronize(cs));                     // (also: the previous batch's records have arrived)
     u64 nrec_in = 0, nkm_in = 0;
     for (int p = 0; p < P; p++) { nrec_in += h_out[2 * p]; nkm_in += h_out[2 * p + 1]; }
-    // ---- 3. payload: region p -> rank p, straight out of the send buffer; arrivals land back to back
-    if (int rc = dist_grow(ctx, &d->d_recv, &d->recv_records, std::max<u64>(nrec_in, d->recv_records), slot)) return rc;
+    // ---- 3. payload: region p -> rank p, straight out of the send buffer; arrivals land back to back in the receive buffer
+    //         that is NOT being counted (the batch counted two exchanges ago has returned)
+    const int rb = (int)(d->nexchanged & 1);
+    if (int rc = dist_grow(ctx, &d->d_recv[rb], &d->recv_records[rb], std::max<u64>(nrec_in, d->recv_records[rb]), slot)) return rc;
     GK_NCCL(ctx, r->GroupStart());
     u64 roff = 0;
     for (int p = 0; p < P; p++) {
-        if (recs[p]) GK_NCCL(ctx, r->Send(d->d_sendbuf[b] + (u64)p * region * slot, (size_t)recs[p] * slot, ncclUint8, p, d->comm, ctx->stream));
-        if (h_out[2 * p]) GK_NCCL(ctx, r->Recv(d->d_recv + roff * slot, (size_t)h_out[2 * p] * slot, ncclUint8, p, d->comm, ctx->stream));
+        if (recs[p]) GK_NCCL(ctx, r->Send(d->d_sendbuf[b] + (u64)p * region * slot, (size_t)recs[p] * slot, ncclUint8, p, d->comm, cs));
+        if (h_out[2 * p]) GK_NCCL(ctx, r->Recv(d->d_recv[rb] + roff * slot, (size_t)h_out[2 * p] * slot, ncclUint8, p, d->comm, cs));
         roff += h_out[2 * p];
     }
     GK_NCCL(ctx, r->GroupEnd());
+    GK_HIP(ctx, hipEventRecord(d->exch_done[b], cs));
+    rt.exchanged = true; rt.rbuf = rb; rt.nrec_in = nrec_in; rt.nkm_in = nkm_in; rt.sent = sent;
+    d->nexchanged++;
     const double t2 = now_ms();
-    // ---- 4. the owner counts what it received: the records ARE short reads (stream-ordered behind the receives)
+    ms2[0] += (float)(t1 - t0); ms2[1] += (float)(t2 - t1);
+    return GK_OK;
+}
+
+// The rest of the oldest batch begun by gk_dist_route_begin: exchange counts and records (unless that was done ahead), count
+// what arrived.  With THREE batches begun, the exchange of the next one is posted first, so that its records travel while
+// this batch is being counted (the rule depends on the number of begun batches only, never on timing: every rank issues
+// the same sequence of RCCL operations).
+int gk_dist_count_routed(gk_dist *d, gk_map *local, uint64_t *occurrences_sent, uint64_t *occurrences_owned) {
+    if (int rc = dist_check(d)) return rc;
+    gk_ctx *ctx = d->ctx;
+    constexpr int NR = gk_dist::NROUTE;
+    if (occurrences_sent) *occurrences_sent = 0;
+    if (occurrences_owned) *occurrences_owned = 0;
+    if (!d->npending) return fail(ctx, GK_E_STATE, "gk_dist_count_routed: no route was begun (gk_dist_route_begin)");
+    const int b = d->head;
+    if (!local || local->ctx != ctx) return fail(ctx, GK_E_INVALID, "gk_dist_count_routed: the local map must live on the handle's context");
+    if (local->k != d->route[b].k) return fail(ctx, GK_E_KLEN, "gk_dist_count_routed: the route was begun for another k");
+    const double t0 = now_ms();
+    float ms2[2] = {0, 0};
+    auto drop_head = [&]() { d->head = (d->head + 1) % NR; d->npending--; };
+    if (d->route[b].error) {                 // found while this batch's exchange was attempted ahead of its turn
+        const int rc = d->route[b].error;
+        const std::string text = d->route[b].error_text;
+        drop_head();
+        return fail(ctx, rc, text);
+    }
+    if (!d->route[b].exchanged) {
+        if (int rc = dist_exchange(d, b, ms2)) { drop_head(); return rc; }       // (a batch that cannot be exchanged is dropped)
+    }
+    // With three batches begun, the NEXT batch's exchange runs on a helper thread beside this batch's owner count: its host
+    // side alone (two RCCL group launches and the round trip for the sizes, 0.4-0.6 ms) would otherwise sit in front of
+    // the owner pipeline's launches.  The helper is the only thread that touches the communicator until it is joined below.
+    std::thread helper;
+    float hms[2] = {0, 0};
+    if (d->npending >= NR) {
+        const int b1 = (b + 1) % NR;
+        if (!d->route[b1].exchanged && !d->route[b1].error) {
+            helper = std::thread([d, b1, &hms]() {
+                (void)hipSetDevice(d->ctx->device);
+                if (int rc = dist_exchange(d, b1, hms)) { d->route[b1].error = rc; d->route[b1].error_text = d->ctx->err; }
+            });
+        }
+    }
+    struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_helper{helper};
+    const gk_dist::Route rt = d->route[b];
+    drop_head();
+    const double t2 = now_ms();
+    // ---- the owner counts what it received: the records ARE short reads (stream-ordered behind the receives)
+    GK_HIP(ctx, hipStreamWaitEvent(ctx->stream, d->exch_done[b], 0));
     uint64_t occ = 0;
-    if (nrec_in) { if (int rc = gk_map_count_superkmers_dev(local, d->d_recv, nrec_in, nkm_in, &occ)) return rc; }
+    if (rt.nrec_in) { if (int rc = gk_map_count_superkmers_dev(local, d->d_recv[rt.rbuf], rt.nrec_in, rt.nkm_in, &occ)) return rc; }
     else GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const double t3 = now_ms();
-    d->last_ms[0] = (float)(t1 - t0); d->last_ms[1] = (float)(t2 - t1); d->last_ms[2] = (float)(t3 - t2); d->last_ms[3] = (float)(t3 - t0);
-    if (occurrences_sent) *occurrences_sent = sent;
+    if (helper.joinable()) helper.join();
+    const double t4 = now_ms();
+    // {waiting for routes, exchanges done in front of the count, owner count, total}; [1] also carries what the helper's
+    // exchange took beyond the owner count (0 when it was hidden completely)
+    d->last_ms[0] = ms2[0]; d->last_ms[1] = ms2[1] + (float)(t4 - t3); d->last_ms[2] = (float)(t3 - t2); d->last_ms[3] = (float)(t4 - t0);
+    d->last_helper_ms = hms[0] + hms[1];
+    if (occurrences_sent) *occurrences_sent = rt.sent;
     if (occurrences_owned) *occurrences_owned = occ;
     return GK_OK;
 }
@@ -385,6 +475,7 @@ int gk_dist_gather_map(gk_dist *d, gk_map *local, gk_map **full) {
     gk_ctx *ctx = d->ctx;
     if (!local || !full || local->ctx != ctx) return fail(ctx, GK_E_INVALID, "gk_dist_gather_map: bad argument");
     *full = nullptr;
+    if (int rc = dist_quiesce(d)) return rc;
     if (int rc = map_materialize(local)) return rc;
     const int P = d->world, W = local->W;
     Rccl *r = rccl();

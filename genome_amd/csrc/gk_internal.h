@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 
@@ -48,6 +49,7 @@ struct gk_ctx {
     std::unordered_map<void *, size_t> pool_sizes;           // every block the pool has handed out or holds
     size_t pool_held = 0, pool_limit = 0;                    // bytes parked; cap (a third of the device's memory)
     uint64_t pool_hits = 0, pool_misses = 0;
+    std::recursive_mutex pool_mu;                            // (gk_dist's helper thread grows its buffers beside the owner pipeline)
     std::string err;
 };
 

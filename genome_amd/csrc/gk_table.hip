@@ -362,6 +362,7 @@ namespace gk {
 static constexpr size_t POOL_MIN_BLOCK = 1u << 20;
 hipError_t pool_malloc(gk_ctx *ctx, void **p, size_t bytes) {
     *p = nullptr;
+    std::lock_guard<std::recursive_mutex> lock(ctx->pool_mu);
     if (bytes < POOL_MIN_BLOCK) return (hipMalloc)(p, bytes ? bytes : 1);
     // best fit, but never a block more than half again as big as asked for (a 12 GB table must not sit in a 50 GB block)
     auto it = ctx->pool_free_blocks.lower_bound(bytes);
@@ -383,6 +384,7 @@ hipError_t pool_malloc(gk_ctx *ctx, void **p, size_t bytes) {
 }
 hipError_t pool_free(gk_ctx *ctx, void *p) {
     if (!p) return hipSuccess;
+    std::lock_guard<std::recursive_mutex> lock(ctx->pool_mu);
     auto it = ctx->pool_sizes.find(p);
     if (it == ctx->pool_sizes.end()) return (hipFree)(p);
     const size_t bytes = it->second;
@@ -399,6 +401,7 @@ hipError_t pool_free(gk_ctx *ctx, void *p) {
     return hipSuccess;
 }
 void pool_release(gk_ctx *ctx) {
+    std::lock_guard<std::recursive_mutex> lock(ctx->pool_mu);
     for (auto &b : ctx->pool_free_blocks) { ctx->pool_sizes.erase(b.second); (void)(hipFree)(b.second); }
     ctx->pool_free_blocks.clear();
     ctx->pool_held = 0;

@@ -75,7 +75,8 @@ class DistDNAMap:
 
     def route_begin(self, d_records: int, nreads: int, read_len: int):
         """First half of count_reads_dev, asynchronous: route the batch on the second stream.  Call it for batch i+1 before
-        count_routed() of batch i and the routing kernel hides behind the owner pipeline."""
+        count_routed() of batch i and the routing kernel hides behind the owner pipeline; with batch i+2 begun as well (three
+        is the limit), count_routed(i) also posts the exchange of batch i+1 beside the count of batch i."""
         L.check(L.lib().gk_dist_route_begin(self.dist.h, self.k, d_records, nreads, read_len), self.ctx.h)
 
     def count_routed(self):

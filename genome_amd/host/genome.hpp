@@ -201,7 +201,8 @@ class PartitionedDNAMap {
         check(gk_dist_count_reads_dev(d_, local_.handle(), devRecords, nreads, readLen, &sent, &owned), ctx_.handle());
         return {sent, owned};
     }
-    // the same in two halves for a streaming loop: routeBegin(batch i+1) before countRouted() of batch i
+    // the same in two halves for a streaming loop: routeBegin(batch i+1), and routeBegin(batch i+2) for the exchange to run
+    // ahead as well, before countRouted() of batch i (at most three begun)
     void routeBegin(const void *devRecords, uint64_t nreads, int readLen) {
         check(gk_dist_route_begin(d_, local_.k(), devRecords, nreads, readLen), ctx_.handle());
     }

@@ -248,11 +248,15 @@ int gk_dist_count_reads_dev(gk_dist *d, gk_map *local, const void *dev_records, 
                             uint64_t *occurrences_sent, uint64_t *occurrences_owned);
 /* The same in two halves, for a streaming loop: gk_dist_route_begin launches the routing of a batch on the context's second
  * stream and returns at once; gk_dist_count_routed waits for it, exchanges and counts.  Calling route_begin for batch i+1
- * BEFORE count_routed for batch i overlaps the routing kernel with the owner pipeline (send buffers are double-buffered).
- * The records of a begun batch must stay valid until its count_routed returns.  At most two batches may be begun and not
+ * BEFORE count_routed for batch i overlaps the routing kernel with the owner pipeline; with route_begin for batch i+2 before
+ * it as well, count_routed(i) first posts the exchange of batch i+1 on the handle's own communication stream, so that those
+ * records travel over xGMI while batch i is counted (three send buffers, two receive buffers; the rule depends only on the
+ * number of begun batches, so every rank issues the same sequence of RCCL operations — all ranks must run the same loop).
+ * The records of a begun batch must stay valid until its count_routed returns.  At most three batches may be begun and not
  * yet counted (GK_E_STATE otherwise; count_routed with none begun is GK_E_STATE too); they are counted first in, first out:
- * begin(0), [begin(i+1), count_routed(i)]*, count_routed(last).  A malformed record in a begun batch (GK_E_FORMAT) may be
- * reported by whichever count call on the context checks the flags next. */
+ * begin(0), begin(1), [begin(i+2), count_routed(i)]*, count_routed(last-1), count_routed(last).  A batch whose exchange
+ * fails is dropped and the error returned by the count_routed whose turn it is.  A malformed record in a begun batch
+ * (GK_E_FORMAT) may be reported by whichever count call on the context checks the flags next. */
 int gk_dist_route_begin(gk_dist *d, int k, const void *dev_records, uint64_t nreads, int read_len);
 int gk_dist_count_routed(gk_dist *d, gk_map *local, uint64_t *occurrences_sent, uint64_t *occurrences_owned);
 /* wall ms of the last gk_dist_count_routed on this rank: {waiting for the route, exchange, owner count, total} */

@@ -64,12 +64,15 @@ def test_one_rank_communicator_matches_oracle(dist, k, L_):
     g.close(); full.close(); pm.close(); ctx.free(d)
 
 
+@pytest.mark.parametrize("depth", [2, 3])
 @pytest.mark.parametrize("k,L_", [(31, 150), (47, 120)])
-def test_streaming_route_begin_count_routed(dist, k, L_):
-    """The two-halves form of FreqFilter.add over a partitioned map: the route of batch i+1 is launched before batch i is
-    exchanged and counted (two send buffers).  Same table as one count over all the reads."""
+def test_streaming_route_begin_count_routed(dist, k, L_, depth):
+    """The two-halves form of FreqFilter.add over a partitioned map.  depth 2: the route of batch i+1 is launched before batch
+    i is exchanged and counted.  depth 3: with batch i+2 begun as well, count_routed(i) posts the exchange of batch i+1 on the
+    communication stream before it counts batch i (three send buffers, two receive buffers).  Same table as one count over all
+    the reads; a size query in the middle (an RCCL operation on the other stream) must not disturb a posted exchange."""
     ctx = dist.ctx
-    n, nb = 40000, 4
+    n, nb = 40000, 5
     rec = synth.reads_mode_g(n, L_, 60000, 0.01, config_id=500 + k)
     d = ctx.alloc(rec.size + 64)
     ctx.upload(d, rec)
@@ -81,38 +84,23 @@ def test_streaming_route_begin_count_routed(dist, k, L_):
     with pytest.raises(L.GkError) as e:
         pm.count_routed()                            # nothing begun
     assert e.value.code == L.GK_E_STATE
-    pm.route_begin(at(0), per, L_)
+    begun = 0
     tot_s = tot_o = 0
     for i in range(nb):
-        if i + 1 < nb:
-            pm.route_begin(at(i + 1), per, L_)
-            if i == 0:
-                with pytest.raises(L.GkError) as e:
-                    pm.route_begin(at(2), per, L_)   # a third one: both send buffers are taken
-                assert e.value.code == L.GK_E_STATE
+        while begun < min(i + depth, nb):
+            pm.route_begin(at(begun), per, L_)
+            begun += 1
+        if i == 0 and depth == 3:
+            with pytest.raises(L.GkError) as e:
+                pm.route_begin(at(3), per, L_)       # a fourth one: all three send buffers are taken
+            assert e.value.code == L.GK_E_STATE
         s_, o_ = pm.count_routed()
         tot_s += s_; tot_o += o_
+        if i == 2:
+            assert pm.size() <= ref.size()           # all-reduce while (depth 3) the next batch's records may be on the wire
     assert tot_s == tot_o == occ
     assert pm.size() == ref.size()
     for a, b in zip(pm.local.sorted_items(), ref.export_sorted()):
         assert np.array_equal(a, b)
     assert pm.local.verify()[1] == 0
     pm.close(); ctx.free(d)
-
-
-def test_collectives_and_errors(dist):
-    assert np.array_equal(dist.allreduce([1.5, 2.5, -3.0]), [1.5, 2.5, -3.0])
-    assert np.array_equal(dist.allreduce([4.0], "max"), [4.0])
-    dist.barrier()
-    with pytest.raises(L.GkError) as e:
-        HipDist(dist.ctx, 3, 2, unique_id())               # rank outside the world: refused before any RCCL call
-    assert e.value.code == L.GK_E_INVALID
-    pm = DistDNAMap(dist, 31)
-    assert pm.count_reads_dev(0, 0, 150) == (0, 0)
-    with pytest.raises(L.GkError) as e:
-        pm.count_reads_dev(0, 5, 150)
-    assert e.value.code == L.GK_E_INVALID
-    with pytest.raises(L.GkError) as e:
-        pm.count_reads_dev(1, 5, 300)
-    assert e.value.code == L.GK_E_FORMAT
-    pm.close()
