@@ -124,6 +124,7 @@ SIGNATURES = {
     "gk_support_create": (C.c_int, [vp, C.POINTER(vp)]),
     "gk_support_destroy": (None, [vp]),
     "gk_support_size": (C.c_int, [vp, u64p, u64p, u64p]),
+    "gk_support_last_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
     "gk_support_export": (C.c_int, [vp, u32p, u32p, u32p, C.c_uint64, u64p]),
     "gk_graph_walk_pairs": (C.c_int, [vp, vp, vp, u8p, C.c_size_t, C.c_uint64, C.c_int, C.c_int]),
     "gk_graph_split_by_support": (C.c_int, [vp, vp, C.c_int, u64p, u64p]),

@@ -2248,6 +2248,7 @@ struct gk_support {
     gk_ctx *ctx = nullptr;
     std::unordered_map<u64, u32> paths;        // (e1 << 32 | e2) -> count          pathsMap :209
     u64 bad_pairs = 0, walked = 0;             // badPairs :211; pair orientations that reached the walk
+    float last_ms[5] = {0, 0, 0, 0, 0};        // last gk_graph_walk_pairs: keys from the stream, getAll batch, snapshot + checks, walks, merge
 };
 
 namespace {
@@ -2311,6 +2312,7 @@ struct Walker {
     std::vector<State> states;                              // in order of d
     std::unordered_map<u64, u32> index;                     // (pe, d) -> position in `states`
     std::vector<std::vector<u32>> sq;                       // states by distance
+    std::vector<u32> rq_touched, sq_touched;                // the distances whose buckets the last walk filled
     Walker(const HostGraph &g, int lo_, int hi_) : G(g), lo(lo_), hi(hi_), rq(hi_ + 1), sq(hi_ + 1) {}
 
     bool walk(Pos p1, Pos p2, std::vector<u64> &pairs) {
@@ -2320,10 +2322,13 @@ struct Walker {
         const u32 start_edge = p1.is_edge ? p1.id : NONE;
         const u32 node0 = p1.is_edge ? G.e_end[p1.id] : p1.id;
         const u64 dist0 = p1.is_edge ? G.e_len[p1.id] - p1.dist : 0;
+        if (dist0 > (u64)hi) return false;                  // (the reference finds this out after `reachable`; nothing is recorded either way)
         // ---- reachable(node2) :43-72: shortest distance back along in-edges, <= hi (edge lengths >= 1: buckets by distance)
         reach.clear();
-        for (auto &b : rq) b.clear();
+        for (u32 d : rq_touched) rq[d].clear();
+        rq_touched.clear();
         rq[0].push_back(node2);
+        rq_touched.push_back(0);
         for (int d = 0; d <= hi; d++)
             for (size_t i = 0; i < rq[d].size(); i++) {
                 const u32 u = rq[d][i];
@@ -2331,18 +2336,19 @@ struct Walker {
                 for (u32 j = G.in_off[u]; j < G.in_off[u + 1]; j++) {
                     const u32 e = G.in_list[j];
                     const u64 d2 = (u64)d + G.e_len[e];
-                    if (d2 <= (u64)hi) rq[d2].push_back(G.e_start[e]);
+                    if (d2 <= (u64)hi) { if (rq[d2].empty()) rq_touched.push_back((u32)d2); rq[d2].push_back(G.e_start[e]); }
                 }
             }
-        if (dist0 > (u64)hi) return false;
         // ---- forward: states (previous edge, distance) in order of distance
         states.clear(); index.clear();
-        for (auto &b : sq) b.clear();
+        for (u32 d : sq_touched) sq[d].clear();
+        sq_touched.clear();
         auto node_of = [&](u32 pe) { return pe == NONE ? node0 : G.e_end[pe]; };
         auto add_state = [&](u32 pe, u32 d) {
             const u64 key = ((u64)pe << 32) | d;
             if (index.count(key)) return;
             index.emplace(key, 0u);
+            if (sq[d].empty()) sq_touched.push_back(d);
             sq[d].push_back(pe);
         };
         add_state(start_edge, (u32)dist0);
@@ -2388,22 +2394,27 @@ struct Walker {
     }
 };
 
-// the first k bases of a `.bin` record as (lo, hi) and its reverse complement
-inline void first_kmer(const uint8_t *payload, int k, u64 &lo, u64 &hi) {
-    lo = hi = 0;
-    for (int i = 0; i < k; i++) {
-        const u64 b = (payload[i >> 2] >> ((i & 3) * 2)) & 3u;
-        if (i < 32) lo |= b << (2 * i); else hi |= b << (2 * (i - 32));
-    }
+// the first k bases of a `.bin` record as (lo, hi) — the first 2k bits of its payload, LSB first (DNASeq.scala:285-303) —
+// and its reverse complement.  `avail` = payload bytes that may be read (>= ceil(k / 4)).
+inline void first_kmer(const uint8_t *payload, size_t avail, int k, u64 &lo, u64 &hi) {
+    u64 w[2] = {0, 0};
+    memcpy(w, payload, std::min<size_t>(16, avail));
+    if (k <= 32) { lo = k == 32 ? w[0] : w[0] & ((1ull << (2 * k)) - 1ull); hi = 0; }
+    else { lo = w[0]; hi = k == 64 ? w[1] : w[1] & ((1ull << (2 * (k - 32))) - 1ull); }
 }
+// the 32 two-bit groups of a word in reverse order
+inline u64 reverse_groups(u64 x) {
+    x = __builtin_bswap64(x);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    return ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+}
+// complement (A<->T, G<->C = b ^ 3, Base.scala:6-23), then reverse; the complemented padding ends up below bit 0 and is shifted out
 inline void revcomp_host(u64 lo, u64 hi, int k, u64 &rlo, u64 &rhi) {
-    rlo = rhi = 0;
-    for (int i = 0; i < k; i++) {
-        const u64 b = (i < 32 ? (lo >> (2 * i)) : (hi >> (2 * (i - 32)))) & 3u;
-        const int j = k - 1 - i;
-        const u64 c = b ^ 3u;                               // A<->T, G<->C  (Base.scala:6-23)
-        if (j < 32) rlo |= c << (2 * j); else rhi |= c << (2 * (j - 32));
-    }
+    if (k <= 32) { rlo = reverse_groups(~lo) >> (64 - 2 * k); rhi = 0; return; }
+    const u64 nhi = reverse_groups(~lo), nlo = reverse_groups(~hi);       // the 128-bit value reversed: words swapped
+    const int s = 128 - 2 * k;                                             // 0 <= s < 64
+    rlo = s ? (nlo >> s) | (nhi << (64 - s)) : nlo;
+    rhi = nhi >> s;
 }
 
 }  // namespace
@@ -2422,6 +2433,11 @@ int gk_support_size(const gk_support *s, uint64_t *pairs, uint64_t *bad_pairs, u
     if (pairs) *pairs = s->paths.size();
     if (bad_pairs) *bad_pairs = s->bad_pairs;
     if (walked) *walked = s->walked;
+    return GK_OK;
+}
+int gk_support_last_ms(const gk_support *s, float *ms5) {
+    if (!s || !ms5) return fail(nullptr, GK_E_INVALID, "gk_support_last_ms: null argument");
+    for (int i = 0; i < 5; i++) ms5[i] = s->last_ms[i];
     return GK_OK;
 }
 int gk_support_export(const gk_support *s, uint32_t *e1, uint32_t *e2, uint32_t *count, uint64_t cap, uint64_t *n) {
@@ -2449,8 +2465,11 @@ int gk_graph_walk_pairs(gk_graph *g, gk_vmap *positions, gk_support *sup, const 
     if (gk_vmap_k(positions) != g->k) return fail(ctx, GK_E_KLEN, "gk_graph_walk_pairs: the position map has another k");
     if (range_lo < 0 || range_hi < range_lo || range_hi > 65535) return fail(ctx, GK_E_INVALID, "gk_graph_walk_pairs: range must satisfy 0 <= lo <= hi <= 65535");
     const int k = g->k;
+    auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double t_begin = now();
     // ---- the pairs whose mates both hold k bases (:213), their four keys
     std::vector<u64> klo, khi;
+    klo.reserve((size_t)std::min<uint64_t>(npairs, nbytes / 2) * 4); khi.reserve(klo.capacity());
     size_t pos = 0;
     for (uint64_t p = 0; p < npairs && pos < nbytes; p++) {
         const uint8_t *r1 = bin + pos;
@@ -2463,7 +2482,7 @@ int gk_graph_walk_pairs(gk_graph *g, gk_vmap *positions, gk_support *sup, const 
         if (pos > nbytes) return fail(ctx, GK_E_FORMAT, "gk_graph_walk_pairs: the stream ends inside a record");
         if (l1 < k || l2 < k) continue;
         u64 alo, ahi, blo, bhi, ralo, rahi, rblo, rbhi;
-        first_kmer(r1 + 1, k, alo, ahi); first_kmer(r2 + 1, k, blo, bhi);
+        first_kmer(r1 + 1, (size_t)(l1 + 3) / 4, k, alo, ahi); first_kmer(r2 + 1, (size_t)(l2 + 3) / 4, k, blo, bhi);
         revcomp_host(alo, ahi, k, ralo, rahi); revcomp_host(blo, bhi, k, rblo, rbhi);
         // f1 = getAll(p1.take(k)), f2 = getAll(p2.take(k).revComplement), f3 = getAll(p2.take(k)), f4 = getAll(p1.take(k).revComplement)
         klo.insert(klo.end(), {alo, rblo, blo, ralo});
@@ -2471,11 +2490,13 @@ int gk_graph_walk_pairs(gk_graph *g, gk_vmap *positions, gk_support *sup, const 
     }
     const u64 nq = klo.size();
     if (nq == 0) return GK_OK;
+    const double t_keys = now();
     std::vector<u64> off(nq + 1), vals(std::max<u64>(nq * 2, 16));
     u64 total = 0;
     int rc = gk_vmap_get_all_batch(positions, klo.data(), khi.data(), nq, off.data(), vals.data(), vals.size(), &total);
     if (rc == GK_E_CAPACITY) { vals.resize(total); rc = gk_vmap_get_all_batch(positions, klo.data(), khi.data(), nq, off.data(), vals.data(), vals.size(), &total); }
     if (rc) return rc;
+    const double t_lookup = now();
     const HostGraph *Hp = nullptr;
     if (int rc2 = graph_snapshot_cached(g, &Hp)) return rc2;
     const HostGraph &H = *Hp;
@@ -2484,6 +2505,7 @@ int gk_graph_walk_pairs(gk_graph *g, gk_vmap *positions, gk_support *sup, const 
         if (p.is_edge ? (p.id >= H.n_edges || !H.e_alive[p.id] || p.dist >= H.e_len[p.id]) : (p.id >= H.n_nodes || !H.node_alive[p.id]))
             return fail(ctx, GK_E_STATE, "gk_graph_walk_pairs: the position map does not belong to this graph (rebuild it after edits)");
     }
+    const double t_snap = now();
     // ---- the walks, on host threads; every thread keeps its own counts
     const u64 norient = nq / 2;                              // two orientations per pair: (f1, f2) and (f3, f4)  :219
     const unsigned nthreads = (unsigned)std::max<u64>(1, std::min<u64>({(u64)std::thread::hardware_concurrency(), 16, norient / 64 + 1}));
@@ -2521,11 +2543,15 @@ int gk_graph_walk_pairs(gk_graph *g, gk_vmap *positions, gk_support *sup, const 
     for (unsigned t = 1; t < nthreads; t++) pool.emplace_back(work, t);
     work(0);
     for (auto &th : pool) th.join();
+    const double t_walks = now();
     for (unsigned t = 0; t < nthreads; t++) {
         for (const auto &kv : local[t]) sup->paths[kv.first] += kv.second;
         sup->bad_pairs += bad[t];
         sup->walked += walked[t];
     }
+    const double t_end = now();
+    sup->last_ms[0] = (float)(t_keys - t_begin); sup->last_ms[1] = (float)(t_lookup - t_keys); sup->last_ms[2] = (float)(t_snap - t_lookup);
+    sup->last_ms[3] = (float)(t_walks - t_snap); sup->last_ms[4] = (float)(t_end - t_walks);
     return GK_OK;
 }
 

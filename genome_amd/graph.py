@@ -248,6 +248,12 @@ class Support:
         L.check(L.lib().gk_support_size(self.h, C.byref(a), C.byref(b), C.byref(c)), self.ctx.h)
         return a.value, b.value, c.value
 
+    def last_ms(self):
+        """wall ms of the last walkPairs into this support: keys, getAll batch, snapshot + checks, walks, merge"""
+        arr = (C.c_float * 5)()
+        L.check(L.lib().gk_support_last_ms(self.h, arr), self.ctx.h)
+        return dict(zip(("keys", "lookup", "snapshot", "walks", "merge"), (float(x) for x in arr)))
+
     def items(self):
         n = self.sizes()[0]
         e1, e2, cnt = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint32)

@@ -323,6 +323,9 @@ typedef struct gk_support gk_support;
 int gk_support_create(gk_ctx *ctx, gk_support **out);
 void gk_support_destroy(gk_support *s);
 int gk_support_size(const gk_support *s, uint64_t *pairs, uint64_t *bad_pairs, uint64_t *walked_orientations);
+/* wall ms of the last gk_graph_walk_pairs into this support: {keys cut from the stream, getAll batch, graph snapshot + checks,
+ * walks, merge of the per-thread counts} */
+int gk_support_last_ms(const gk_support *s, float *ms5);
 int gk_support_export(const gk_support *s, uint32_t *e1, uint32_t *e2, uint32_t *count, uint64_t cap, uint64_t *n);   /* unordered */
 /* :213-247 for the first `npairs` pairs of a `.bin` stream (two records per pair; pairs with a mate shorter than k are
  * skipped, :213).  `positions` = gk_graph_position_map of THIS graph in its current state (GK_E_STATE otherwise).  For each

@@ -41,6 +41,7 @@ t0 = time.perf_counter(); vm = g.getGraphMap(); t_map = time.perf_counter() - t0
 sup = Support(ctx)
 t0 = time.perf_counter(); g.walkPairs(vm, sup, binb, npairs, 180, 250); t_walk = time.perf_counter() - t0
 pairs, bad, walked = sup.sizes()
+print('walkPairs phases ms:', {k_: round(v, 2) for k_, v in sup.last_ms().items()})
 t0 = time.perf_counter(); rm, nn = g.splitBySupport(sup, 3); t_only_split = time.perf_counter() - t0
 g.simplifyGraph(); t_split = time.perf_counter() - t0
 print(f"split alone {t_only_split * 1e3:.1f} ms, simplify {(t_split - t_only_split) * 1e3:.1f} ms")
