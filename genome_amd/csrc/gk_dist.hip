@@ -424,7 +424,7 @@ int gk_dist_count_routed(gk_dist *d, gk_map *local, uint64_t *occurrences_sent, 
     // the owner pipeline's launches.  The helper is the only thread that touches the communicator until it is joined below.
     std::thread helper;
     float hms[2] = {0, 0};
-    if (d->npending >= NR) {
+    if (d->npending >= NR && ctx->hook_dist_ahead != 0) {        // ("dist_exchange_ahead" = 0: the plain order, for A/B and as a fallback)
         const int b1 = (b + 1) % NR;
         if (!d->route[b1].exchanged && !d->route[b1].error) {
             helper = std::thread([d, b1, &hms]() {

@@ -64,7 +64,7 @@ def test_one_rank_communicator_matches_oracle(dist, k, L_):
     g.close(); full.close(); pm.close(); ctx.free(d)
 
 
-@pytest.mark.parametrize("depth", [2, 3])
+@pytest.mark.parametrize("depth", [2, 3, -3])
 @pytest.mark.parametrize("k,L_", [(31, 150), (47, 120)])
 def test_streaming_route_begin_count_routed(dist, k, L_, depth):
     """The two-halves form of FreqFilter.add over a partitioned map.  depth 2: the route of batch i+1 is launched before batch
@@ -72,6 +72,9 @@ def test_streaming_route_begin_count_routed(dist, k, L_, depth):
     communication stream before it counts batch i (three send buffers, two receive buffers).  Same table as one count over all
     the reads; a size query in the middle (an RCCL operation on the other stream) must not disturb a posted exchange."""
     ctx = dist.ctx
+    if depth < 0:                                    # three deep, the exchange NOT posted ahead (the fallback order)
+        depth = -depth
+        ctx.set_option("dist_exchange_ahead", 0)
     n, nb = 40000, 5
     rec = synth.reads_mode_g(n, L_, 60000, 0.01, config_id=500 + k)
     d = ctx.alloc(rec.size + 64)
@@ -103,4 +106,5 @@ def test_streaming_route_begin_count_routed(dist, k, L_, depth):
     for a, b in zip(pm.local.sorted_items(), ref.export_sorted()):
         assert np.array_equal(a, b)
     assert pm.local.verify()[1] == 0
+    ctx.set_option("dist_exchange_ahead", -1)
     pm.close(); ctx.free(d)
