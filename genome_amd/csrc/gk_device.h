@@ -205,9 +205,13 @@ GK_D Stored<2> load_stored(const Slot<2> *s) { return Stored<2>{s->w0, s->w1}; }
 // slots), and linear probing wraps INSIDE a segment.  A segment is the unit one workgroup can hold
 // in LDS, which is what lets a batch be radix-partitioned by segment and built there with LDS
 // atomics and coalesced HBM traffic (gk_partition.hip) instead of one global atomic per key.
-// Segment id = (L1 bucket, fine bucket): L1 = top lnb1 bits of the slot hash (<= 256 buckets),
+// Segment id = (L1 bucket, fine bucket): L1 = top lnb1 bits of the slot hash (<= 256 buckets; 512 or 1024 only
+// for tables that would otherwise need more than MAX_NB2 fine buckets per L1 bucket, i.e. beyond 34 GB),
 // fine = 32 middle bits scaled to nb2 — so the number of segments need not be a power of two and
 // the table can be sized to the load factor wanted.  Start position = low seg_bits bits.
+// The 32 fine bits are bits 24..55, directly below the L1 bits of a 256-bucket table; with 9 or 10 L1 bits they move down
+// with them (bits 23..54, 22..53) — shared bits would pin the top of the fine value inside an L1 bucket and leave half or
+// three quarters of its fine buckets empty.  They stay clear of the start position (bits 0..10) and of the sample bits (11..20).
 template <int W> struct SegBits;
 #ifndef GK_SEG_BITS1
 #define GK_SEG_BITS1 11
@@ -215,10 +219,11 @@ template <int W> struct SegBits;
 template <> struct SegBits<1> { static constexpr u32 value = GK_SEG_BITS1; };
 template <> struct SegBits<2> { static constexpr u32 value = GK_SEG_BITS1 - 1; };
 
+static constexpr u32 MAX_LNB1 = 10;      // up to 1024 L1 buckets
 template <int W> struct Table {
     Slot<W> *slots;
     u32 nb2;           // fine buckets per L1 bucket
-    u32 lnb1;          // log2(L1 buckets), 0..8
+    u32 lnb1;          // log2(L1 buckets), 0..MAX_LNB1
     u32 tagged;        // 1 for k = 64: slot index mod 4 carries the key's last base
     u32 both;          // 1: the table may hold ANY orientation of a k-mer (keys inserted verbatim through the ABI), not only
                        // the hash-rule one: strand-agnostic lookups (table_find_either) must probe both, always
@@ -229,7 +234,10 @@ template <int W> struct Table {
     GK_HD u64 capacity() const { return nseg() << SegBits<W>::value; }
 };
 template <int W> GK_HD u32 seg_l1(const Table<W> &t, u64 h) { return t.lnb1 ? (u32)(h >> (64 - t.lnb1)) : 0u; }
-template <int W> GK_HD u32 seg_fine(const Table<W> &t, u64 h) { return (u32)((((h >> 24) & 0xffffffffULL) * (u64)t.nb2) >> 32); }
+template <int W> GK_HD u32 seg_fine(const Table<W> &t, u64 h) {
+    const u32 shift = t.lnb1 > 8 ? 32u - t.lnb1 : 24u;
+    return (u32)((((h >> shift) & 0xffffffffULL) * (u64)t.nb2) >> 32);
+}
 template <int W> GK_HD u32 seg_of(const Table<W> &t, u64 h) { return seg_l1(t, h) * t.nb2 + seg_fine(t, h); }
 template <int W> GK_HD u32 seg_pos(u64 h) { return (u32)h & ((1u << SegBits<W>::value) - 1u); }
 // where a key's probe starts in its segment

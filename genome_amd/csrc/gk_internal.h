@@ -31,6 +31,7 @@ struct gk_ctx {
     int hook_p4_direct = -1;         // exact fine level: -1 auto (by nb2), 0 chunk sorted in LDS, 1 straight scatter with per-range cursors
     int hook_p2_wide = -1;           // over-provisioned L1 scatter: 1 = 1024 threads per tile (A/B)
     int hook_p2_sorted = -1;         // over-provisioned L1 scatter: 1 = bucket-ordered write-out (A/B)
+    int hook_min_lnb1 = 0;           // test hook: tables of enough segments get at least 2^this L1 buckets (9, 10: the fan-out of tables beyond 34 GB)
     int hook_dist_ahead = -1;        // gk_dist_count_routed with three batches begun: 0 = do not post the next batch's exchange ahead (every rank alike)
     int hook_p24_pieces = -1;        // pipelined batch (both levels over-provisioned): pieces whose P4 overlaps the next piece's scatter (-1: default, 0/1: off)
     int hook_p45_stripes = -1;       // over-provisioned fine level: stripes of L1 buckets whose P5 overlaps the next stripe's P4 (-1/1: none)
@@ -151,13 +152,20 @@ inline bool k_supported(int k) { return (k >= 2 && k <= 31) || (k >= 34 && k <= 
 inline int words_for_k(int k) { return k <= 32 ? 1 : 2; }
 inline size_t slot_bytes(int W) { return W == 1 ? 16 : 32; }
 inline uint32_t seg_bits_for(int W) { return W == 1 ? gk::SegBits<1>::value : gk::SegBits<2>::value; }
-// segment geometry for at least `want_slots` slots: nb1 = 2^lnb1 <= 256 L1 buckets x nb2 fine buckets
-inline void plan_segments(int W, uint64_t want_slots, uint32_t *nb2, uint32_t *lnb1, uint64_t *capacity) {
+// segment geometry for at least `want_slots` slots: nb1 = 2^lnb1 L1 buckets x nb2 fine buckets.  256 L1 buckets at most
+// — unless that would take more fine buckets per L1 bucket than the partitioned insert pipeline handles (PLAN_MAX_NB2):
+// then 512 or 1024 (tables beyond 34 GB).  min_lnb1: a test hook that forces a larger fan-out on small tables too;
+// keep_lnb1 >= 0: the L1 bucket of a key must not change (growth between the two levels of a running batch).
+static constexpr uint32_t PLAN_MAX_NB2 = 4096;
+inline void plan_segments(int W, uint64_t want_slots, uint32_t *nb2, uint32_t *lnb1, uint64_t *capacity, uint32_t min_lnb1 = 0,
+                          int keep_lnb1 = -1) {
     const uint64_t S = 1ull << seg_bits_for(W);
     uint64_t want_seg = (want_slots + S - 1) / S;
     if (want_seg < 1) want_seg = 1;
     uint32_t l = 0;
     while (l < 8 && (2ull << l) <= want_seg) l++;
+    while (l < gk::MAX_LNB1 && (want_seg > ((uint64_t)PLAN_MAX_NB2 << l) || (l < min_lnb1 && (2ull << l) <= want_seg))) l++;
+    if (keep_lnb1 >= 0) l = (uint32_t)keep_lnb1;
     const uint64_t nb1 = 1ull << l;
     *lnb1 = l;
     *nb2 = (uint32_t)((want_seg + nb1 - 1) / nb1);
@@ -191,7 +199,7 @@ int part_count(gk_map *m, PartScratch **pps, const ReadSrc &src, const uint64_t 
                bool from_empty, const PartPlan &plan);
 int map_ensure_sample(gk_map *m);                    // allocate the distinct-key sample set on first use
 // if the table cannot take `new_distinct` more keys, grow it (rehash, or plain re-allocation from empty) for `size_for` more
-int map_make_room(gk_map *m, uint64_t new_distinct, uint64_t size_for, bool from_empty);
+int map_make_room(gk_map *m, uint64_t new_distinct, uint64_t size_for, bool from_empty, bool keep_lnb1 = false);
 uint64_t part_max_slots(int W);                      // largest table the partitioned path can address
 int ctx_check_format(gk_ctx *ctx);                   // GK_E_FORMAT (and reset) if a map-less kernel raised ctx->d_flags[0]
 // super-k-mer routing in two halves (gk_skm.hip): launch on any stream without waiting, finish after that stream was synchronised

@@ -62,6 +62,7 @@ static constexpr int KEYS_PER_THREAD = 8;
 static constexpr int PTILE_READS = 256;     // reads per LDS tile in P1/P2 (runs of ~120 keys per bucket)
 static constexpr int PTILE_WORDS = PTILE_READS * 65 / 4 + 64;
 static constexpr int TILE2 = PBLOCK * KEYS_PER_THREAD;   // keys per chunk in P3/P4
+static constexpr u32 MAXB1 = 1u << MAX_LNB1;      // L1 buckets at most (256 for every table up to 34 GB, see plan_segments)
 static constexpr u32 MAX_NB2 = 4096;        // LDS bound in P3/P4 (16 B per fine bucket on top of the sorted chunk)
 static constexpr u32 MAX_RANGE_CHUNKS = 16; // a range = up to 16 consecutive chunks of one L1 bucket (64 Ki keys)
 
@@ -88,11 +89,12 @@ __device__ __forceinline__ u32 sample_key(const Sampler &sp, u64 h) {
 }
 
 struct PartArrays {
-    unsigned long long *hist1;      // [256]
-    unsigned long long *l1_base;    // [257] dense prefix of the keys kept per L1 bucket (= region bases in exact mode)
-    unsigned long long *cursor1;    // [256]
-    unsigned long long *cbase;      // [257] chunk prefix
-    unsigned long long *rbase;      // [257] range prefix
+    // (per L1 bucket: MAXB1 entries, prefixes MAXB1 + 1; entries from the table's own bucket count up hold the total)
+    unsigned long long *hist1;      // [MAXB1]
+    unsigned long long *l1_base;    // [MAXB1 + 1] dense prefix of the keys kept per L1 bucket (= region bases in exact mode)
+    unsigned long long *cursor1;    // [MAXB1]
+    unsigned long long *cbase;      // [MAXB1 + 1] chunk prefix
+    unsigned long long *rbase;      // [MAXB1 + 1] range prefix
     u32 *hist2;                     // [nseg] keys per segment (exact fine level)
     unsigned long long *fine_base;  // [nseg + 1]
     u32 *cursor2;                   // [nseg] (over-provisioned fine level)
@@ -200,8 +202,8 @@ __global__ __launch_bounds__(PBLOCK) void k_part_hist1_reads(const uint8_t *__re
                                                             u32 stride, int k, int group, int max_len, Table<W> t, unsigned long long *hist1,
                                                             Sampler sp, Counters *ctr) {
     __shared__ __attribute__((aligned(16))) u32 tile[PTILE_WORDS];
-    __shared__ u32 hist[256];
-    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+    __shared__ u32 hist[MAXB1];
+    for (u32 b = threadIdx.x; b < MAXB1; b += PBLOCK) hist[b] = 0;
     u32 occ = 0, claims = 0;
     const u64 ntiles = (nreads + PTILE_READS - 1) / PTILE_READS;
     const WindowLimits lim{max_len, &ctr->format};
@@ -220,7 +222,8 @@ __global__ __launch_bounds__(PBLOCK) void k_part_hist1_reads(const uint8_t *__re
         });
     }
     __syncthreads();
-    if (threadIdx.x < 256 && hist[threadIdx.x]) atomicAdd(&hist1[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+    for (u32 b = threadIdx.x; b < MAXB1; b += PBLOCK) if (hist[b]) atomicAdd(&hist1[b], (unsigned long long)hist[b]);
+    __syncthreads();
     block_add_global(occ, &hist[0], &ctr->occurrences);
     if (sp.set) block_add_global(claims, &hist[0], sp.claims);
 }
@@ -230,8 +233,8 @@ __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_reads(const uint8_t *_
                                                                u32 stride, int k, int group, int max_len, Table<W> t, const unsigned long long *l1_base,
                                                                unsigned long long *cursor1, u64 *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) u32 tile[PTILE_WORDS];
-    __shared__ u32 hist[256];
-    __shared__ unsigned long long base[256];
+    __shared__ u32 hist[MAXB1];
+    __shared__ unsigned long long base[MAXB1];
     const u64 ntiles = (nreads + PTILE_READS - 1) / PTILE_READS;
     const WindowLimits lim{max_len, nullptr};            // P1 has already reported oversized length bytes
     for (u64 tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
@@ -239,17 +242,17 @@ __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_reads(const uint8_t *_
         const int nr = (int)min((u64)PTILE_READS, nreads - r0);
         const u64 gb = offsets ? (u64)offsets[r0] : r0 * stride, ge = offsets ? (u64)offsets[r0 + nr] : (r0 + nr) * stride;
         __syncthreads();
-        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+        for (u32 b = threadIdx.x; b < MAXB1; b += PBLOCK) hist[b] = 0;
         const u64 a0 = stage_tile(tile, rec, gb, ge);
         __syncthreads();
         for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, group, lim, [&](Kmer<W> x) {
             atomicAdd(&hist[seg_l1(t, slot_hash(canonical(x, k)))], 1u);
         });
         __syncthreads();
-        if (threadIdx.x < 256) {
-            const u32 c = hist[threadIdx.x];
-            if (c) base[threadIdx.x] = l1_base[threadIdx.x] + atomicAdd(&cursor1[threadIdx.x], (unsigned long long)c);
-            hist[threadIdx.x] = 0;          // becomes the rank counter
+        for (u32 b = threadIdx.x; b < MAXB1; b += PBLOCK) {
+            const u32 c = hist[b];
+            if (c) base[b] = l1_base[b] + atomicAdd(&cursor1[b], (unsigned long long)c);
+            hist[b] = 0;                    // becomes the rank counter
         }
         __syncthreads();
         for_each_window<W>(tile, a0, r0, nr, offsets, stride, k, group, lim, [&](Kmer<W> x) {
@@ -265,13 +268,13 @@ __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_reads(const uint8_t *_
 // ---------------------------------------------------------------------------------------------
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_part_hist1_keys(const u64 *__restrict__ keys, u64 n, Table<W> t, unsigned long long *hist1) {
-    __shared__ u32 hist[256];
-    hist[threadIdx.x] = 0;
+    __shared__ u32 hist[MAXB1];
+    for (u32 b = threadIdx.x; b < MAXB1; b += BLOCK) hist[b] = 0;
     __syncthreads();
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK)
         atomicAdd(&hist[seg_l1(t, slot_hash(load_key<W>(keys, i)))], 1u);
     __syncthreads();
-    if (hist[threadIdx.x]) atomicAdd(&hist1[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+    for (u32 b = threadIdx.x; b < MAXB1; b += BLOCK) if (hist[b]) atomicAdd(&hist1[b], (unsigned long long)hist[b]);
 }
 
 // Chunked scatter of a key range into `nbins` bins, used for P2 from keys (bin = L1 bucket) and P4
@@ -397,7 +400,8 @@ template <int W>
 __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_keys(const u64 *__restrict__ keys, u64 n, Table<W> t, PartArrays a,
                                                                u64 *__restrict__ out, Sampler sp) {
     extern __shared__ unsigned long long lds_dyn1[];
-    ScatterLds<W> L(lds_dyn1, 256u);
+    const u32 nb1 = max(256u, 1u << t.lnb1);
+    ScatterLds<W> L(lds_dyn1, nb1);
     const u64 nchunks = (n + TILE2 - 1) / TILE2;
     u32 claims = 0;
     GK_T0();
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_keys(const u64 *__rest
         const u32 cnt = (u32)min((u64)TILE2, n - begin);
         Kmer<W> key[KEYS_PER_THREAD];
         load_chunk<W, 1, PBLOCK>(key, keys, a, 0u, 0ull, begin, cnt);
-        scatter_chunk<W, 1, false, PBLOCK>(key, cnt, t, 256u, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a, 0, out, sp, claims, GK_TARGS);
+        scatter_chunk<W, 1, false, PBLOCK>(key, cnt, t, nb1, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a, 0, out, sp, claims, GK_TARGS);
     }
     if (sp.set) block_add_global(claims, &L.off[0], sp.claims);
 }
@@ -432,15 +436,18 @@ static constexpr int OP_TILE_WORDS = OP_TILE_READS * 65 / 4 + 64;
 #ifndef GK_OP_WGS_PER_CU
 #define GK_OP_WGS_PER_CU 2          // workgroups of the persistent grid per CU: what the LDS tile and the VGPR count let reside
 #endif
-template <int W, int NT, bool SORTED>
+// NB1: L1 buckets the LDS arrays are sized for — 256 (every table up to 34 GB) or MAXB1.  The 1024-bucket form carries
+// 15 KB more LDS per workgroup, so only one fits a CU beside its 45 KB key buffer; it exists so that tables beyond 34 GB
+// stay on this pipeline at all (the direct path costs 45-62 ps per window).
+template <int W, int NT, bool SORTED, int NB1>
 __global__ __launch_bounds__(NT, GK_OP_MIN_WAVES) void k_op_scatter1_reads(const uint8_t *__restrict__ rec, u64 nreads, u32 stride, int k, int group,
                                                               int rs /* reads per tile */, int max_len, int exact_len, Table<W> t, PartArrays a,
                                                               Sampler sp, Counters *ctr, u64 *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) u32 tile[OP_TILE_WORDS];
     __shared__ u64 flat[OP_CAP];
     __shared__ uint16_t fbin[OP_CAP / W];      // 0xffff = hole (bucket ids use all 256 byte values)
-    __shared__ u32 hist[256], rank[256], lim[256];
-    __shared__ unsigned long long gb[256];
+    __shared__ u32 hist[NB1], rank[NB1], lim[NB1];
+    __shared__ unsigned long long gb[NB1];
     __shared__ uint16_t perm[SORTED ? OP_CAP / W : 1];
     __shared__ u32 wsum[NT / 64];
     u32 occ = 0, claims = 0;
@@ -461,7 +468,7 @@ __global__ __launch_bounds__(NT, GK_OP_MIN_WAVES) void k_op_scatter1_reads(const
         const u32 nflat = (u32)(nr * nk_max);
         __syncthreads();
         GK_TICK(5);
-        if (threadIdx.x < 256) { hist[threadIdx.x] = 0; rank[threadIdx.x] = 0; }
+        for (u32 b = threadIdx.x; b < (u32)NB1; b += NT) { hist[b] = 0; rank[b] = 0; }
         for (u32 i = threadIdx.x; i < nflat; i += NT) fbin[i] = 0xffff;
         const u64 a0 = stage_tile(tile, rec, r0 * stride, (r0 + nr) * stride);
         __syncthreads();
@@ -480,27 +487,27 @@ __global__ __launch_bounds__(NT, GK_OP_MIN_WAVES) void k_op_scatter1_reads(const
         GK_TICK(1);
         __syncthreads();
         GK_TICK(2);
-        if (threadIdx.x < 256) {
-            const u32 c = hist[threadIdx.x];
+        for (u32 b = threadIdx.x; b < (u32)NB1; b += NT) {
+            const u32 c = hist[b];
             u32 fit = 0;
             if (c) {
-                const unsigned long long at = atomicAdd(&a.cursor1[threadIdx.x], (unsigned long long)c);
-                gb[threadIdx.x] = at;                               // position inside the region (l1_slot maps it)
+                const unsigned long long at = atomicAdd(&a.cursor1[b], (unsigned long long)c);
+                gb[b] = at;                                         // position inside the region (l1_slot maps it)
                 fit = at >= a.cap1 ? 0u : (u32)min((unsigned long long)c, a.cap1 - at);
             }
-            lim[threadIdx.x] = fit;
-            if (SORTED) rank[threadIdx.x] = c;
+            lim[b] = fit;
+            if (SORTED) rank[b] = c;
         }
         __syncthreads();
         GK_TICK(3);
         if constexpr (SORTED) {
-            block_scan_inplace<NT>(rank, 256u, wsum);               // rank[b] = first sorted position of bucket b
+            block_scan_inplace<NT>(rank, (u32)NB1, wsum);           // rank[b] = first sorted position of bucket b
             for (u32 i = threadIdx.x; i < nflat; i += NT) {
                 const u32 b = fbin[i];
                 if (b != 0xffff) perm[atomicAdd(&rank[b], 1u)] = (uint16_t)i;      // rank[b] ends as the END of bucket b
             }
             __syncthreads();
-            const u32 ntot = rank[255];
+            const u32 ntot = rank[NB1 - 1];
             // four positions per thread and round: the chain perm -> (bin, key) -> (run start, limit, destination) is three LDS
             // round trips deep, one at a time it is all latency
             constexpr int U = 4;
@@ -551,43 +558,43 @@ __global__ __launch_bounds__(NT, GK_OP_MIN_WAVES) void k_op_scatter1_reads(const
     if (sp.set) block_add_global(claims, &hist[0], sp.claims);
 }
 
-// exclusive scan of the 256 L1 counts; chunk and range tables for P3/P4 (chunks and ranges never straddle L1 buckets)
-__global__ __launch_bounds__(256) void k_part_prefix1(PartArrays a, u32 nb1) {
-    __shared__ unsigned long long s[256], c[256], r[256];
+// exclusive scan of the L1 counts; chunk and range tables for P3/P4 (chunks and ranges never straddle L1 buckets).
+// One workgroup of MAXB1 threads, one per possible L1 bucket (buckets the table does not have count zero, so every prefix
+// entry from the table's bucket count up holds the total).
+__global__ __launch_bounds__(MAXB1) void k_part_prefix1(PartArrays a, u32 nb1) {
+    __shared__ unsigned long long ws[MAXB1 / 64], wc[MAXB1 / 64], wr[MAXB1 / 64];
     const u32 i = threadIdx.x;
-    s[i] = i < nb1 ? (a.op1 ? min(a.cursor1[i], a.cap1) : a.hist1[i]) : 0;
-    c[i] = (s[i] + a.chunk_keys - 1) / a.chunk_keys;                                  // P4's unit of work (over-provisioned fine level)
-    r[i] = ((s[i] + TILE2 - 1) / TILE2 + a.range_chunks - 1) / a.range_chunks;        // ranges of range_chunks x TILE2 keys (exact fine level)
-    // three exclusive scans over 256 entries: inclusive inside each wave by shuffles, then the four wave totals
+    const unsigned long long v = i < nb1 ? (a.op1 ? min(a.cursor1[i], a.cap1) : a.hist1[i]) : 0;
+    const unsigned long long cv = (v + a.chunk_keys - 1) / a.chunk_keys;                        // P4's unit of work (over-provisioned fine level)
+    const unsigned long long rv = ((v + TILE2 - 1) / TILE2 + a.range_chunks - 1) / a.range_chunks;   // ranges of range_chunks x TILE2 keys (exact fine level)
+    // three exclusive scans: inclusive inside each wave by shuffles, then the wave totals
     // (this kernel sits between P2 and P4 on the critical path; the serial loop it replaces took 10 us)
-    unsigned long long v = s[i], cv = c[i], rv = r[i];
     unsigned long long iv = v, icv = cv, irv = rv;
     const int lane = i & 63, wave = i >> 6;
     for (int d = 1; d < 64; d <<= 1) {
         const unsigned long long t0 = __shfl_up(iv, d), t1 = __shfl_up(icv, d), t2 = __shfl_up(irv, d);
         if (lane >= d) { iv += t0; icv += t1; irv += t2; }
     }
-    __syncthreads();                       // s, c, r are read: reuse their first words for the wave totals
-    if (lane == 63) { s[wave] = iv; c[wave] = icv; r[wave] = irv; }
+    if (lane == 63) { ws[wave] = iv; wc[wave] = icv; wr[wave] = irv; }
     __syncthreads();
     unsigned long long p0 = 0, p1 = 0, p2 = 0;
-    for (int w = 0; w < wave; w++) { p0 += s[w]; p1 += c[w]; p2 += r[w]; }
+    for (int w = 0; w < wave; w++) { p0 += ws[w]; p1 += wc[w]; p2 += wr[w]; }
     a.l1_base[i] = p0 + iv - v;
     a.cbase[i] = p1 + icv - cv;
     a.rbase[i] = p2 + irv - rv;
-    if (i == 255) {
-        a.l1_base[256] = p0 + iv;
-        a.cbase[256] = p1 + icv;
-        a.rbase[256] = p2 + irv;
+    if (i == MAXB1 - 1) {
+        a.l1_base[MAXB1] = p0 + iv;
+        a.cbase[MAXB1] = p1 + icv;
+        a.rbase[MAXB1] = p2 + irv;
     }
 }
 
 // The same for ONE PIECE of a pipelined batch (over-provisioned L1 level): the slice of every L1 region that the scatters
 // launched so far have filled beyond the previous piece's end — [prev_to[b], min(cursor1[b], cap1)) — and its chunk table.
 // Runs on the scattering stream between two pieces' scatters, so the cursors it reads are quiescent.
-__global__ __launch_bounds__(256) void k_part_prefix1_piece(PartArrays a, u32 nb1, const unsigned long long *prev_to, unsigned long long *from_out,
-                                                            unsigned long long *to_out, unsigned long long *cbase_out) {
-    __shared__ unsigned long long c[4];
+__global__ __launch_bounds__(MAXB1) void k_part_prefix1_piece(PartArrays a, u32 nb1, const unsigned long long *prev_to, unsigned long long *from_out,
+                                                              unsigned long long *to_out, unsigned long long *cbase_out) {
+    __shared__ unsigned long long c[MAXB1 / 64];
     const u32 i = threadIdx.x;
     const unsigned long long to = i < nb1 ? min(a.cursor1[i], a.cap1) : 0ull;
     const unsigned long long from = (i < nb1 && prev_to) ? min(prev_to[i], to) : 0ull;
@@ -605,12 +612,12 @@ __global__ __launch_bounds__(256) void k_part_prefix1_piece(PartArrays a, u32 nb
     from_out[i] = from;
     to_out[i] = to;
     cbase_out[i] = p1 + icv - cv;
-    if (i == 255) cbase_out[256] = p1 + icv;
+    if (i == MAXB1 - 1) cbase_out[MAXB1] = p1 + icv;
 }
 
-// which L1 bucket does chunk / range `c` belong to (binary search over a 257-entry prefix)
-__device__ __forceinline__ u32 chunk_bucket(const unsigned long long *cbase, u64 c) {
-    u32 lo = 0, hi = 256;
+// which L1 bucket does chunk / range `c` belong to (binary search over the prefix of nb1 + 1 entries)
+__device__ __forceinline__ u32 chunk_bucket(const unsigned long long *cbase, u64 c, u32 nb1) {
+    u32 lo = 0, hi = nb1;
     while (hi - lo > 1) {
         const u32 mid = (lo + hi) >> 1;
         if (cbase[mid] <= c) lo = mid; else hi = mid;
@@ -622,9 +629,9 @@ __device__ __forceinline__ u32 chunk_bucket(const unsigned long long *cbase, u64
 // P3 (exact fine level): per-RANGE histogram of the fine bucket -> one row of the range matrix
 // ---------------------------------------------------------------------------------------------
 struct RangeGeom { u32 b1; u64 begin; u32 cnt; };      // L1 bucket, first key inside it, number of keys
-__device__ __forceinline__ RangeGeom range_geom(const unsigned long long *s_rbase, const unsigned long long *s_l1n, u64 r, u32 range_chunks) {
+__device__ __forceinline__ RangeGeom range_geom(const unsigned long long *s_rbase, const unsigned long long *s_l1n, u64 r, u32 range_chunks, u32 nb1) {
     RangeGeom g;
-    g.b1 = chunk_bucket(s_rbase, r);
+    g.b1 = chunk_bucket(s_rbase, r, nb1);
     g.begin = (r - s_rbase[g.b1]) * (u64)range_chunks * TILE2;
     g.cnt = (u32)min((u64)range_chunks * TILE2, s_l1n[g.b1] - g.begin);
     return g;
@@ -633,13 +640,14 @@ __device__ __forceinline__ RangeGeom range_geom(const unsigned long long *s_rbas
 template <int W>
 __global__ __launch_bounds__(PBLOCK) void k_part_hist2r(const u64 *__restrict__ bufA, Table<W> t, PartArrays a, u64 max_ranges) {
     extern __shared__ u32 lds_hist[];
-    __shared__ unsigned long long s_rbase[257], s_l1n[256];
-    for (u32 b = threadIdx.x; b < 257u; b += PBLOCK) s_rbase[b] = a.rbase[b];
-    for (u32 b = threadIdx.x; b < 256u; b += PBLOCK) s_l1n[b] = b < (1u << t.lnb1) ? l1_count(a, b) : 0ull;
+    __shared__ unsigned long long s_rbase[MAXB1 + 1], s_l1n[MAXB1];
+    const u32 nb1 = 1u << t.lnb1;
+    for (u32 b = threadIdx.x; b <= nb1; b += PBLOCK) s_rbase[b] = a.rbase[b];
+    for (u32 b = threadIdx.x; b < nb1; b += PBLOCK) s_l1n[b] = l1_count(a, b);
     __syncthreads();
-    const u64 total = min((u64)s_rbase[256], max_ranges);
+    const u64 total = min((u64)s_rbase[nb1], max_ranges);
     for (u64 r = blockIdx.x; r < total; r += gridDim.x) {
-        const RangeGeom g = range_geom(s_rbase, s_l1n, r, a.range_chunks);
+        const RangeGeom g = range_geom(s_rbase, s_l1n, r, a.range_chunks, nb1);
         for (u32 b = threadIdx.x; b < t.nb2; b += PBLOCK) lds_hist[b] = 0;
         __syncthreads();
         for (u32 cb = 0; cb < g.cnt; cb += TILE2) {
@@ -720,22 +728,24 @@ template <int W, bool RANGED, int NT>
 __global__ __launch_bounds__(NT) void k_part_scatter2(const u64 *__restrict__ bufA, Table<W> t, PartArrays a, u64 max_units,
                                                           u64 *__restrict__ bufB, u32 b_lo, u32 b_hi) {
     extern __shared__ unsigned long long lds_dyn[];
-    ScatterLds<W, NT> L(lds_dyn, t.nb2);
     constexpr u32 TILE = NT * KEYS_PER_THREAD;          // keys this workgroup sorts at a time (ranges and the chunk table stay in TILE2 units)
     // chunk / range table and L1 bucket extents: LDS copies (the binary search below was eight dependent global
-    // loads per chunk: 16 % of the kernel by the phase timers)
-    __shared__ unsigned long long s_ubase[257], s_l1n[256], s_l1b[256], s_l1f[256];
-    for (u32 b = threadIdx.x; b < 257u; b += NT) s_ubase[b] = RANGED ? a.rbase[b] : a.cbase[b];
-    for (u32 b = threadIdx.x; b < 256u; b += NT) {
-        const bool live = b < (1u << t.lnb1);
+    // loads per chunk: 16 % of the kernel by the phase timers); in the dynamic area, sized by the table's L1 bucket count
+    // (part_tables_bytes), in front of the sort buffers
+    const u32 nb1 = 1u << t.lnb1;
+    unsigned long long *s_ubase = lds_dyn, *s_l1n = s_ubase + nb1 + 1, *s_l1b = s_l1n + nb1, *s_l1f = s_l1b + nb1;
+    ScatterLds<W, NT> L(s_l1f + nb1, t.nb2);
+    for (u32 b = threadIdx.x; b <= nb1; b += NT) s_ubase[b] = RANGED ? a.rbase[b] : a.cbase[b];
+    for (u32 b = threadIdx.x; b < nb1; b += NT) {
         const bool slice = !RANGED && a.l1_to != nullptr;              // (a slice of every region: pipelined pieces)
-        s_l1f[b] = live && slice ? a.l1_from[b] : 0ull;
-        s_l1n[b] = !live ? 0ull : slice ? a.l1_to[b] - a.l1_from[b] : l1_count(a, b);
+        s_l1f[b] = slice ? a.l1_from[b] : 0ull;
+        s_l1n[b] = slice ? a.l1_to[b] - a.l1_from[b] : l1_count(a, b);
         s_l1b[b] = l1_begin(a, b);
     }
     __syncthreads();
+    if (!RANGED) b_hi = min(b_hi, nb1);
     const u64 first = RANGED ? 0ull : (u64)s_ubase[b_lo];
-    const u64 total = min((u64)s_ubase[RANGED ? 256u : b_hi], max_units);
+    const u64 total = min((u64)s_ubase[RANGED ? nb1 : b_hi], max_units);
     const Sampler nosp{nullptr, 0, nullptr};
     u32 noclaims = 0;
     GK_T0();
@@ -748,7 +758,7 @@ __global__ __launch_bounds__(NT) void k_part_scatter2(const u64 *__restrict__ bu
         // (the exact fine level keeps the plain form: it has no atomics, hence nothing in a chunk that waits on vmcnt but the
         //  loads themselves; measured at C3 and at C2 with fine_exact = 1, the prefetching form is 3-7 % SLOWER there)
         for (u64 r = blockIdx.x; r < total; r += gridDim.x) {
-            const RangeGeom g = range_geom(s_ubase, s_l1n, r, a.range_chunks);
+            const RangeGeom g = range_geom(s_ubase, s_l1n, r, a.range_chunks, nb1);
             const u64 bin0 = (u64)g.b1 * t.nb2;
             const u32 *row = a.rmat + r * t.nb2;
             for (u32 b = threadIdx.x; b < t.nb2; b += NT) L.gb[b] = a.fine_base[bin0 + b] + row[b];
@@ -765,7 +775,7 @@ __global__ __launch_bounds__(NT) void k_part_scatter2(const u64 *__restrict__ bu
         auto geom = [&](u64 c) {
             Pos p{c, 0u, 0ull, 0u};
             if (c < total) {
-                p.b1 = chunk_bucket(s_ubase, c);
+                p.b1 = chunk_bucket(s_ubase, c, nb1);
                 const u64 rel = (c - s_ubase[p.b1]) * TILE;
                 p.begin = s_l1f[p.b1] + rel;
                 p.cnt = (u32)min((u64)TILE, s_l1n[p.b1] - rel);
@@ -805,13 +815,14 @@ template <int W>
 __global__ __launch_bounds__(PBLOCK) void k_part_scatter2_direct(const u64 *__restrict__ bufA, Table<W> t, PartArrays a, u64 max_ranges,
                                                                  u64 *__restrict__ bufB) {
     extern __shared__ u32 lds_cur[];                 // [nb2] next free position of every bin, relative to the L1 bucket's first key in bufB
-    __shared__ unsigned long long s_rbase[257], s_l1n[256];
-    for (u32 b = threadIdx.x; b < 257u; b += PBLOCK) s_rbase[b] = a.rbase[b];
-    for (u32 b = threadIdx.x; b < 256u; b += PBLOCK) s_l1n[b] = b < (1u << t.lnb1) ? l1_count(a, b) : 0ull;
+    __shared__ unsigned long long s_rbase[MAXB1 + 1], s_l1n[MAXB1];
+    const u32 nb1 = 1u << t.lnb1;
+    for (u32 b = threadIdx.x; b <= nb1; b += PBLOCK) s_rbase[b] = a.rbase[b];
+    for (u32 b = threadIdx.x; b < nb1; b += PBLOCK) s_l1n[b] = l1_count(a, b);
     __syncthreads();
-    const u64 total = min((u64)s_rbase[256], max_ranges);
+    const u64 total = min((u64)s_rbase[nb1], max_ranges);
     for (u64 r = blockIdx.x; r < total; r += gridDim.x) {
-        const RangeGeom g = range_geom(s_rbase, s_l1n, r, a.range_chunks);
+        const RangeGeom g = range_geom(s_rbase, s_l1n, r, a.range_chunks, nb1);
         const u64 bin0 = (u64)g.b1 * t.nb2;
         const u64 base = a.fine_base[bin0];          // (= l1_base[b1]: bufB is dense)
         const u32 *row = a.rmat + r * t.nb2;
@@ -1077,13 +1088,16 @@ struct PartScratch {
     u64 bufA_keys = 0, bufB_keys = 0, spill_keys = 0;     // capacities in keys
     int W = 1;
     bool lds_attr_set = false;
-    unsigned long long *piece_tables = nullptr;      // inside blob: per piece [from 256][to 256][cbase 257] (pipelined batches)
+    unsigned long long *piece_tables = nullptr;      // inside blob: per piece [from MAXB1][to MAXB1][cbase MAXB1 + 1] (pipelined batches)
 };
 static constexpr int MAX_PIECES = 8;
 #ifndef GK_P24_PIECES_DEFAULT
 #define GK_P24_PIECES_DEFAULT 1          // pieces of a pipelined batch ("p24_pieces"; 0/1 = one piece: the default, see part_run)
 #endif
-static constexpr size_t PIECE_WORDS = 256 + 256 + 257 + 7;
+static constexpr size_t PIECE_WORDS = MAXB1 + MAXB1 + (MAXB1 + 1) + 7;
+// LDS the P4 kernels take for their chunk / range table and L1 extents, in front of the sort buffers
+static size_t part_tables_bytes(u32 nb1) { return ((size_t)4 * nb1 + 1) * 8; }
+static constexpr size_t LDS_BYTES_PER_CU = 160u << 10;
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -1115,7 +1129,7 @@ static int part_prepare_l1(gk_map *m, PartScratch *ps, u64 nkeys, bool op1, Part
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     // (nspill, overflow, n_failed are read back together at the end of a batch: contiguous, one copy)
-    const size_t o_hist1 = take(256 * 8), o_l1 = take(257 * 8), o_cur1 = take(256 * 8), o_cb = take(257 * 8), o_rb = take(257 * 8),
+    const size_t o_hist1 = take(MAXB1 * 8), o_l1 = take((MAXB1 + 1) * 8), o_cur1 = take(MAXB1 * 8), o_cb = take((MAXB1 + 1) * 8), o_rb = take((MAXB1 + 1) * 8),
                  o_nsp = take(16), o_ovf = o_nsp + 8, o_nf = o_nsp + 12, o_pieces = take((size_t)MAX_PIECES * PIECE_WORDS * 8);
     if (int rc = grow_raw(ctx, &ps->blob, &ps->blob_bytes, off)) return rc;
     ps->piece_tables = (unsigned long long *)((char *)ps->blob + o_pieces);
@@ -1183,7 +1197,7 @@ static int part_prepare_fine(gk_map *m, PartScratch *ps, u64 nkeys, bool op2, Pa
         arr->cap2 = (u64)(m2 + 8.0 * std::sqrt(m2) + 64.0);
         wantB = nseg * arr->cap2;
     } else {
-        const u64 max_ranges = (nkeys / TILE2 + 257) / arr->range_chunks + 257;
+        const u64 max_ranges = (nkeys / TILE2 + MAXB1 + 1) / arr->range_chunks + MAXB1 + 1;
         const u64 words = max_ranges * m->nb2;
         if (ps->rmat_words < words) {
             if (ps->rmat) GK_HIP(ctx, hipFree(ps->rmat));
@@ -1222,17 +1236,16 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
     const int cu8 = ctx->cu_count * 8;
     const size_t lds = ((size_t)1 << SegBits<W>::value) * sizeof(Slot<W>) + 16;
     if (!ps->lds_attr_set) {
-        GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<W, false, PBLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)ScatterLds<W>::bytes(MAX_NB2)));
-        GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<W, true, PBLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)ScatterLds<W>::bytes(MAX_NB2)));
+        const int narrow_max = (int)std::min(ScatterLds<W>::bytes(MAX_NB2) + part_tables_bytes(MAXB1), LDS_BYTES_PER_CU);
+        GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<W, false, PBLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, narrow_max));
+        GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<W, true, PBLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, narrow_max));
         if constexpr (W == 1) {
-            const int wide_max = (int)ScatterLds<1, 1024>::bytes(MAX_NB2);
+            const int wide_max = (int)std::min(ScatterLds<1, 1024>::bytes(MAX_NB2) + part_tables_bytes(MAXB1), LDS_BYTES_PER_CU);
             GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<1, true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, wide_max));
             GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<1, false, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, wide_max));
         }
         GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter1_keys<W>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)ScatterLds<W>::bytes(256u)));
+                                        (int)ScatterLds<W>::bytes(MAXB1)));
         GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_seg_insert<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ps->lds_attr_set = true;
     }
@@ -1244,7 +1257,9 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
     const Sampler sp = m->d_sample ? Sampler{m->d_sample, m->sample_mask, &m->d_ctr->sample_claims} : Sampler{nullptr, 0, nullptr};
     // Over-provisioned fine level with 8-byte keys: 8192-key chunks on 1024 threads when asked for (gk_ctx_set_option "p4_wide")
     // (measured at C2, nb2 = 370: P4 0.66 -> 0.62 ms in mode U, 0.64 -> 0.62 in mode G: half the per-bin bookkeeping per key)
-    auto op_wide_now = [&]() { return W == 1 && (ctx->hook_p4_wide >= 0 ? ctx->hook_p4_wide != 0 : m->nb2 >= 256); };
+    // (the 8192-key forms need the CU's whole LDS: not with more fine buckets than fit beside the tables of a 512/1024-bucket L1 level)
+    auto wide_fits = [&]() { return W == 1 && ScatterLds<1, 1024>::bytes(m->nb2) + part_tables_bytes(nb1) <= LDS_BYTES_PER_CU; };
+    auto op_wide_now = [&]() { return wide_fits() && (ctx->hook_p4_wide >= 0 ? ctx->hook_p4_wide != 0 : m->nb2 >= 256); };
     // Over-provisioned segment regions are only safe to try on a table that is being rebuilt from empty (if they and
     // the spill list overflow, the table is simply cleared again); a table that holds data gets the exact fine level
     // unless the sample says the batch is near-distinct.
@@ -1259,7 +1274,7 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
     // GPU idle (28 GB/s: 2.99 -> 2.71 ms; 56 GB/s: 2.45 -> 2.47-2.55, the scatter alone keeps pace with the link).
     const int want_pieces = ctx->hook_p24_pieces >= 0 ? ctx->hook_p24_pieces : GK_P24_PIECES_DEFAULT;
     const bool pipelined = d_rec && op1 && !fine_exact && !sync_between && want_pieces > 1 && ctx->hook_p45_stripes <= 1 && m->nb2 <= MAX_NB2;
-    const u64 max_chunks = nkeys_bound / TILE2 + 257;
+    const u64 max_chunks = nkeys_bound / TILE2 + MAXB1 + 1;          // (every L1 bucket may end in a partial chunk)
     if (pipelined) {
         if (int rc = part_prepare_fine(m, ps, nkeys_bound, true, &a)) return rc;
         if (op_wide_now()) a.chunk_keys = 2 * TILE2;
@@ -1270,23 +1285,23 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         const int gchunks = (int)std::min<u64>(max_chunks / share + 1, (u64)ctx->cu_count * per_cu);
         if (aa.chunk_keys == 2 * TILE2) {
             if constexpr (W == 1) {
-                const size_t wide_lds = ScatterLds<1, 1024>::bytes(m->nb2);
+                const size_t wide_lds = ScatterLds<1, 1024>::bytes(m->nb2) + part_tables_bytes(nb1);
                 hipLaunchKernelGGL((k_part_scatter2<1, false, 1024>), dim3(std::min(gchunks, ctx->cu_count * std::min(per_cu, 2))), dim3(1024), wide_lds, st, ps->bufA, t, aa,
                                    max_chunks, ps->bufB, b_lo, b_hi);
             }
         } else
-            hipLaunchKernelGGL((k_part_scatter2<W, false, PBLOCK>), dim3(gchunks), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2), st, ps->bufA, t, aa, max_chunks,
-                               ps->bufB, b_lo, b_hi);
+            hipLaunchKernelGGL((k_part_scatter2<W, false, PBLOCK>), dim3(gchunks), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2) + part_tables_bytes(nb1), st, ps->bufA, t, aa,
+                               max_chunks, ps->bufB, b_lo, b_hi);
     };
     PartArrays a_last = a;          // pipelined: the last piece's view (its P4 runs on the main stream, after the join)
     bool have_last = false;
     // after piece j's scatter: its slice tables; every piece but the last goes to the second stream at once
     auto piece_done = [&](int j, int npieces) -> int {
         unsigned long long *tab = ps->piece_tables + (size_t)j * PIECE_WORDS;
-        const unsigned long long *prev = j ? ps->piece_tables + (size_t)(j - 1) * PIECE_WORDS + 256 : nullptr;
-        hipLaunchKernelGGL(k_part_prefix1_piece, dim3(1), dim3(256), 0, ctx->stream, a, nb1, prev, tab, tab + 256, tab + 512);
+        const unsigned long long *prev = j ? ps->piece_tables + (size_t)(j - 1) * PIECE_WORDS + MAXB1 : nullptr;
+        hipLaunchKernelGGL(k_part_prefix1_piece, dim3(1), dim3(MAXB1), 0, ctx->stream, a, nb1, prev, tab, tab + MAXB1, tab + 2 * MAXB1);
         PartArrays aj = a;
-        aj.l1_from = tab; aj.l1_to = tab + 256; aj.cbase = tab + 512;
+        aj.l1_from = tab; aj.l1_to = tab + MAXB1; aj.cbase = tab + 2 * MAXB1;
         if (j == npieces - 1) { a_last = aj; have_last = true; return GK_OK; }
         hipEvent_t ev = ctx->cev[8 + j % 8];
         GK_HIP(ctx, hipEventRecord(ev, ctx->stream));
@@ -1310,13 +1325,16 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         const bool p2_sorted = ctx->hook_p2_sorted >= 0 ? ctx->hook_p2_sorted > 0 : W == 2;
         const int vu = src.verify_uniform ? 1 : 0;
         auto launch_p2 = [&](int g, const uint8_t *recs, u64 nr) {
-#define GK_P2(NT, SORTED)                                                                                                                 \
-    hipLaunchKernelGGL((k_op_scatter1_reads<W, NT, SORTED>), dim3(g), dim3(NT), 0, ctx->stream, recs, nr, src.stride, m->k, src.group, rs, \
+#define GK_P2(NT, SORTED, NB1)                                                                                                                 \
+    hipLaunchKernelGGL((k_op_scatter1_reads<W, NT, SORTED, NB1>), dim3(g), dim3(NT), 0, ctx->stream, recs, nr, src.stride, m->k, src.group, rs, \
                        src.max_len, vu, t, a, sp, m->d_ctr, ps->bufA)
-            if (p2_wide && p2_sorted) GK_P2(1024, true);
-            else if (p2_wide) GK_P2(1024, false);
-            else if (p2_sorted) GK_P2(PBLOCK, true);
-            else GK_P2(PBLOCK, false);
+            if (nb1 > 256) {                          // tables beyond 34 GB (or the test hook): the 1024-bucket form
+                if (p2_sorted) GK_P2(PBLOCK, true, (int)MAXB1);
+                else GK_P2(PBLOCK, false, (int)MAXB1);
+            } else if (p2_wide && p2_sorted) GK_P2(1024, true, 256);
+            else if (p2_wide) GK_P2(1024, false, 256);
+            else if (p2_sorted) GK_P2(PBLOCK, true, 256);
+            else GK_P2(PBLOCK, false, 256);
 #undef GK_P2
         };
         if (!src.host && !pipelined) {
@@ -1372,7 +1390,7 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         const int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)ctx->cu_count * 4);
         hipLaunchKernelGGL(k_part_hist1_reads<W>, dim3(grid), dim3(PBLOCK), 0, ctx->stream, d_rec, src.nreads, d_off, src.stride, m->k, src.group,
                            src.max_len, t, a.hist1, sp, m->d_ctr);
-        hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(256), 0, ctx->stream, a, nb1);
+        hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(MAXB1), 0, ctx->stream, a, nb1);
         GK_HIP(ctx, hipEventRecord(ctx->pev[1], ctx->stream));
         // (A variant that also sorts THIS kernel's keys in LDS before writing was measured slower,
         //  0.76 vs 0.68 ms at C2: P2 is bound by the two window-extraction passes, not by its stores.)
@@ -1382,15 +1400,15 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         if (!op1) {
             const int grid = (int)std::min<u64>(std::max<u64>((nkeys_in + BLOCK - 1) / BLOCK, 1), (u64)cu8);
             hipLaunchKernelGGL(k_part_hist1_keys<W>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_keys, nkeys_in, t, a.hist1);
-            hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(256), 0, ctx->stream, a, nb1);
+            hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(MAXB1), 0, ctx->stream, a, nb1);
         }
         GK_HIP(ctx, hipEventRecord(ctx->pev[1], ctx->stream));
         const int g2 = (int)std::min<u64>(std::max<u64>((nkeys_in + TILE2 - 1) / TILE2, 1), (u64)ctx->cu_count * 4);
-        hipLaunchKernelGGL(k_part_scatter1_keys<W>, dim3(g2), dim3(PBLOCK), ScatterLds<W>::bytes(256u), ctx->stream, d_keys, nkeys_in, t, a, ps->bufA, sp);
+        hipLaunchKernelGGL(k_part_scatter1_keys<W>, dim3(g2), dim3(PBLOCK), ScatterLds<W>::bytes(std::max(256u, nb1)), ctx->stream, d_keys, nkeys_in, t, a, ps->bufA, sp);
     }
     if (!pipelined) {
         if (op_wide_now()) a.chunk_keys = 2 * TILE2;      // (only the over-provisioned fine level's P4 reads it)
-        if (op1) hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(256), 0, ctx->stream, a, nb1);     // chunk / range tables from the cursors
+        if (op1) hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(MAXB1), 0, ctx->stream, a, nb1);     // chunk / range tables from the cursors
     }
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipEventRecord(ctx->pev[2], ctx->stream));
@@ -1456,20 +1474,20 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
             if (!ctx->hook_no_reserve) {
                 // (error k-mers accumulate sub-linearly with the reads: 60 % of the proportional extrapolation)
                 const u64 ahead = (u64)((double)est_new * (1.0 + 0.6 * (std::max(plan.grow_ahead, 1.0) - 1.0)));
-                if (int rc = map_make_room(m, est_new, ahead, from_empty)) return rc;     // may replace the table (same lnb1)
+                if (int rc = map_make_room(m, est_new, ahead, from_empty, true)) return rc;     // may replace the table (same lnb1: P2 has cut the batch by L1 bucket)
             }
             t = Table<W>{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u, 0u, m->aligned ? 1u : 0u};
             // many repeats: segment sizes are far from binomial -> exact fine level
             fine_exact = !op1 || plan.fine_exact || (double)est_new < 0.5 * (double)nkeys_bound;
         }
     }
-    if (m->nb2 > MAX_NB2) return fail(ctx, GK_E_CAPACITY, "table outgrew the partitioned insert path");   // (callers check part_supported first)
+    if (!part_supported(m)) return fail(ctx, GK_E_CAPACITY, "table outgrew the partitioned insert path");   // (callers check part_supported first)
     if (!pipelined) { if (int rc = part_prepare_fine(m, ps, nkeys_bound, !fine_exact, &a)) return rc; }
     const u64 nseg = t.nseg();
     GK_HIP(ctx, hipEventRecord(ctx->gev, ctx->stream));
 
     // ---- stage B: P3 + scans + P4 (the fine level) ---------------------------------------------------------
-    const u64 max_ranges = max_chunks / a.range_chunks + 257;
+    const u64 max_ranges = max_chunks / a.range_chunks + MAXB1 + 1;
     const u64 *fine_keys = ps->bufB;
     if (fine_exact) {
         const int gr = (int)std::min<u64>(max_ranges, (u64)ctx->cu_count * 4);
@@ -1484,16 +1502,17 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         if (direct)
             hipLaunchKernelGGL(k_part_scatter2_direct<W>, dim3((int)std::min<u64>(max_ranges, (u64)ctx->cu_count * 8)), dim3(PBLOCK), m->nb2 * 4,
                                ctx->stream, ps->bufA, t, a, max_ranges, ps->bufB);
-        else if (W == 1 && (ctx->hook_p4_wide >= 0 ? ctx->hook_p4_wide != 0 : m->nb2 >= 512)) {
+        else if (wide_fits() && (ctx->hook_p4_wide >= 0 ? ctx->hook_p4_wide != 0 : m->nb2 >= 512)) {
             // many fine buckets: sort 8192 keys at a time (1024 threads) — twice the keys per bin and visit, so fewer
             // partial-line writes, and half the per-bin bookkeeping per key
             if constexpr (W == 1) {
-                const size_t wide_lds = ScatterLds<1, 1024>::bytes(m->nb2);
+                const size_t wide_lds = ScatterLds<1, 1024>::bytes(m->nb2) + part_tables_bytes(nb1);
                 const int gw = (int)std::min<u64>(max_ranges, (u64)ctx->cu_count * 2);
-                hipLaunchKernelGGL((k_part_scatter2<1, true, 1024>), dim3(gw), dim3(1024), wide_lds, ctx->stream, ps->bufA, t, a, max_ranges, ps->bufB, 0u, 256u);
+                hipLaunchKernelGGL((k_part_scatter2<1, true, 1024>), dim3(gw), dim3(1024), wide_lds, ctx->stream, ps->bufA, t, a, max_ranges, ps->bufB, 0u, nb1);
             }
         } else
-            hipLaunchKernelGGL((k_part_scatter2<W, true, PBLOCK>), dim3(gr), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2), ctx->stream, ps->bufA, t, a, max_ranges, ps->bufB, 0u, 256u);
+            hipLaunchKernelGGL((k_part_scatter2<W, true, PBLOCK>), dim3(gr), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2) + part_tables_bytes(nb1), ctx->stream, ps->bufA, t, a,
+                               max_ranges, ps->bufB, 0u, nb1);
     }
     auto launch_p5 = [&](hipStream_t st, u64 seg_lo, u64 seg_hi) {
         const int gseg = (int)std::min<u64>(seg_hi - seg_lo, (u64)ctx->cu_count * 24);
@@ -1596,7 +1615,13 @@ int part_count(gk_map *m, PartScratch **pps, const ReadSrc &src, const u64 *d_ke
     return part_run<2>(m, *pps, src, d_keys, nkeys_in, nkeys_bound, from_empty, plan);
 }
 
-bool part_supported(const gk_map *m) { return m->nb2 <= MAX_NB2; }
-uint64_t part_max_slots(int W) { return ((u64)MAX_NB2 << 8) << seg_bits_for(W); }
+// the fine level's 4096-key sort must fit the CU's LDS beside its per-bin arrays and the L1 tables (16-byte keys with 1024 L1
+// buckets: ~3500 fine buckets, a 117 GB table)
+bool part_supported(const gk_map *m) {
+    if (m->nb2 > MAX_NB2) return false;
+    const size_t need = (m->W == 1 ? ScatterLds<1>::bytes(m->nb2) : ScatterLds<2>::bytes(m->nb2)) + part_tables_bytes(1u << m->lnb1);
+    return need <= LDS_BYTES_PER_CU;
+}
+uint64_t part_max_slots(int W) { return ((u64)MAX_NB2 << MAX_LNB1) << seg_bits_for(W); }
 
 }  // namespace gk

@@ -449,11 +449,11 @@ static inline double target_load(const gk_map *m) { return m->k == 64 ? 0.45 : 0
 // clear is pending and the caller is about to rebuild every segment from EMPTY): nothing is moved and nothing is cleared.
 // The old table is only released once the new one is known to be good: a rehash that fails (a segment of the NEW table
 // filled up — a sizing error) leaves the map exactly as it was.
-static int map_grow_to(gk_map *m, uint64_t want_slots, bool rehash) {
+static int map_grow_to(gk_map *m, uint64_t want_slots, bool rehash, bool keep_lnb1 = false) {
     gk_ctx *ctx = m->ctx;
     uint32_t nnb2, nlnb1;
     uint64_t ncap;
-    plan_segments(m->W, want_slots, &nnb2, &nlnb1, &ncap);
+    plan_segments(m->W, want_slots, &nnb2, &nlnb1, &ncap, (uint32_t)ctx->hook_min_lnb1, keep_lnb1 ? (int)m->lnb1 : -1);
     if (rehash && m->k != 64 && nlnb1 == m->lnb1 && ctx->hook_filter_classic <= 0) {
         // same L1 fan-out: the keys move between neighbouring segments only — one streaming pass instead of a CAS per key
         bool done = false;
@@ -497,7 +497,7 @@ int map_reserve(gk_map *m, uint64_t extra_keys) {
 }
 
 // the partitioned pipeline's mid-batch form: room for `new_distinct` more keys; from_empty = the table's contents are void
-int map_make_room(gk_map *m, uint64_t new_distinct, uint64_t size_for, bool from_empty) {
+int map_make_room(gk_map *m, uint64_t new_distinct, uint64_t size_for, bool from_empty, bool keep_lnb1) {
     const uint64_t have = from_empty ? 0 : m->size + m->tombstones;
     // (a table whose contents are void is replaced for free — nothing to rehash — so it is sized for what the whole call
     //  is expected to bring, `size_for`, right away: the second count over a map that had been compacted in between kept
@@ -506,7 +506,7 @@ int map_make_room(gk_map *m, uint64_t new_distinct, uint64_t size_for, bool from
     if ((double)(have + fit_now) <= max_load(m) * (double)m->capacity) return GK_OK;
     const uint64_t want = std::max<uint64_t>((uint64_t)((double)(have + std::max(new_distinct, size_for)) / target_load(m)) + 1,
                                              from_empty ? 0 : m->capacity + m->capacity / 2);
-    return map_grow_to(m, want, !from_empty);
+    return map_grow_to(m, want, !from_empty, keep_lnb1);
 }
 
 static constexpr uint64_t SAMPLE_SLOTS = 1ull << 23;      // 64 MB: 4 M sample keys at load 0.5 = 4.3e9 distinct keys
@@ -589,6 +589,7 @@ int gk_ctx_create(int device, gk_ctx **out) {
     ctx->hook_host_ragged = getenv("GK_HOST_RAGGED") != nullptr;
     ctx->hook_part_exact = getenv("GK_PART_EXACT") != nullptr;
     if (const char *u = getenv("GK_P45_STRIPES")) ctx->hook_p45_stripes = atoi(u);
+    if (const char *u = getenv("GK_MIN_LNB1")) ctx->hook_min_lnb1 = std::max(0, std::min((int)gk::MAX_LNB1, atoi(u)));      // (tests: the whole suite over 512 / 1024 L1 buckets)
     if (const char *u = getenv("GK_GRAPH_UNITIGS")) ctx->hook_unitigs = !strcmp(u, "walk") ? 1 : !strcmp(u, "pj") ? 2 : 0;
     *out = ctx;
     return GK_OK;
@@ -642,6 +643,10 @@ int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value) {
     else if (n == "p45_stripes") ctx->hook_p45_stripes = (int)value;
     else if (n == "p24_pieces") ctx->hook_p24_pieces = (int)value;
     else if (n == "dist_exchange_ahead") ctx->hook_dist_ahead = (int)value;
+    else if (n == "min_lnb1") {
+        if (value < 0 || value > (int64_t)gk::MAX_LNB1) return fail(ctx, GK_E_INVALID, "min_lnb1: 0..10");
+        ctx->hook_min_lnb1 = (int)value;
+    }
     else if (n == "p4_grid") ctx->hook_p4_grid = (int)value;
     else if (n == "graph_walk_queue") ctx->hook_walk_queue = (int)value;
     else if (n == "graph_mem") ctx->hook_graph_mem = (int)value;
@@ -781,7 +786,7 @@ int gk_map_create(gk_ctx *ctx, int k, uint64_t capacity_hint, gk_map **out) {
     m->k = k;
     m->W = words_for_k(k);
     uint64_t want = capacity_hint ? capacity_hint : 1024;
-    plan_segments(m->W, (uint64_t)((double)want / target_load(m)) + 1, &m->nb2, &m->lnb1, &m->capacity);
+    plan_segments(m->W, (uint64_t)((double)want / target_load(m)) + 1, &m->nb2, &m->lnb1, &m->capacity, (uint32_t)ctx->hook_min_lnb1);
     int rc = alloc_table(ctx, m->W, m->capacity, &m->slots);
     if (rc == GK_OK) {
         hipError_t e = hipMalloc((void **)&m->d_ctr, sizeof(Counters));
@@ -1372,7 +1377,7 @@ static int map_compact(gk_map *m) {
         free_b += ctx->pool_held;               // (what the context's pool has parked is as good as free)
         if ((double)m->size / graph_load * (double)slot_bytes(m->W) > (double)free_b / 3.0) graph_load = m->k == 64 ? 0.3 : 0.4;
     }
-    plan_segments(m->W, (uint64_t)((double)m->size / graph_load) + 1, &nnb2, &nlnb1, &ncap);
+    plan_segments(m->W, (uint64_t)((double)m->size / graph_load) + 1, &nnb2, &nlnb1, &ncap, (uint32_t)ctx->hook_min_lnb1);
     if (ncap > m->capacity) { nnb2 = m->nb2; nlnb1 = m->lnb1; ncap = m->capacity; }
     void *nslots = nullptr;
     if (alloc_table(ctx, m->W, ncap, &nslots, ctx->hook_graph_mem > 0 ? ctx->hook_graph_mem : 0) != GK_OK) { if (nslots) (void)hipFree(nslots); return GK_OK; }   // keep tombstones if memory is short
@@ -1476,7 +1481,7 @@ static int filter_compact_streaming(gk_map *m, int32_t rounds, bool *done) {
     }
     uint32_t nnb2, nlnb1;
     uint64_t ncap;
-    plan_segments(m->W, (uint64_t)((double)est / graph_load) + 1, &nnb2, &nlnb1, &ncap);
+    plan_segments(m->W, (uint64_t)((double)est / graph_load) + 1, &nnb2, &nlnb1, &ncap, (uint32_t)ctx->hook_min_lnb1);
     if (ncap > m->capacity) { nnb2 = m->nb2; nlnb1 = m->lnb1; ncap = m->capacity; }
     if (nlnb1 != m->lnb1) return GK_OK;                    // the L1 bucket of a key would change: not a segment-local move
     return streaming_rebuild(m, nnb2, nlnb1, ncap, rounds, done);

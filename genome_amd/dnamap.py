@@ -139,7 +139,8 @@ class HipDNAMap:
 
     def close(self):
         if self.h:
-            L.lib().gk_map_destroy(self.h)
+            if self.ctx.h:               # (a handle that outlived its context — a failed test's traceback — is dropped, not followed)
+                L.lib().gk_map_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -309,7 +310,8 @@ class HipValueMap:
 
     def close(self):
         if self.h:
-            L.lib().gk_vmap_destroy(self.h)
+            if self.ctx.h:
+                L.lib().gk_vmap_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -23,7 +23,8 @@ class HipGraph:
 
     def close(self):
         if self.h:
-            L.lib().gk_graph_destroy(self.h)
+            if self.ctx.h:               # (see HipDNAMap.close)
+                L.lib().gk_graph_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -185,3 +185,38 @@ def test_c5_one_rank_share_k63_partitioned_prefiltered(ctx):
     """configs[4] / 8: 250 M x 150 bp over 387.5 Mbp (~97x), k = 63, e = 0.2 %; 2.2e10 windows.  The unfiltered table
     (~5e9 16-byte keys) does not fit one GPU — which is what the pre-filter is for — so no with/without comparison here."""
     _share(ctx, k=63, n=250_000_000, G=387_500_000, e=0.002, cfg=5, chunk=25_000_000, with_plain=False)
+
+
+@pytest.mark.parametrize("k,L_,hint", [(31, 150, 1_500_000_000), (55, 150, 720_000_000)])
+def test_table_beyond_34_gb_stays_on_the_partitioned_pipeline(ctx, k, L_, hint):
+    """C4's and C5's per-rank tables are 50-100 GB.  256 L1 buckets x 4096 fine buckets x 32 KiB end at 34 GB: a table that
+    needs more gets 512 or 1024 L1 buckets (plan_segments) and keeps the LDS segment build — which used to hand such tables to
+    the direct path.  A table created for `hint` keys (36-37 GB), two batches through the forced partitioned path (from empty,
+    then on top of the content): every window counted, every key at its own slot and stored once (gk_map_verify), no direct
+    launch, and the (key, count) set equal to what a small table holds after the same two batches (order-independent
+    checksum).  The oracle cannot follow 2.4e8 windows; parity of the 512/1024-bucket forms at oracle sizes is what the whole
+    suite checks under GK_MIN_LNB1=9|10."""
+    n = 1_000_000
+    nk = L_ - k + 1
+    d = ctx.alloc(n * synth.record_stride(L_) + 64)
+    sums = []
+    for cap in (hint, n * nk):
+        m = HipDNAMap(ctx, k, cap)
+        if cap == hint:
+            st = m.stats()
+            assert st["slots"] * st["slot_bytes"] > 35e9, st
+            m.set_insert_path("partitioned")
+        ctx.synth_reads(d, n, L_, "U", 70 + k, 0, 0, 0.0)
+        assert m.count_reads_dev(d, n, L_) == n * nk
+        ctx.synth_reads(d, n, L_, "G", 71 + k, 0, 3_000_000, 0.01)
+        assert m.count_reads_dev(d, n, L_) == n * nk
+        st = m.stats()
+        if cap == hint:
+            assert st["partitioned_launches"] == 2 and st["direct_launches"] == 0 and st["retries_direct"] == 0, st
+        live, bad, total, chk = m.verify_checksum()
+        assert bad == 0 and total == 2 * n * nk and live == m.size()
+        sums.append((live, chk))
+        m.close()
+    assert sums[0] == sums[1]
+    ctx.free(d)
+    ctx.trim()

@@ -5,6 +5,7 @@ atomics) and the heavy-segment loop of k_seg_insert must give the oracle's table
 record must be refused, and a table filled with verbatim non-canonical keys must still build the reference's
 graph (Graph.scala:270 probes both strands).
 """
+import os
 import random
 
 import numpy as np
@@ -18,6 +19,8 @@ from oracle import oracle as O
 from oracle import pyref as R
 
 pytestmark = pytest.mark.gpu
+# GK_MIN_LNB1=9|10 runs the whole suite over 512 / 1024 L1 buckets (the fan-out of tables beyond 34 GB) on small tables
+FORCED_FANOUT = bool(os.environ.get("GK_MIN_LNB1"))
 
 
 @pytest.fixture(scope="module")
@@ -51,6 +54,8 @@ def test_high_coverage_batch_sizes_table_for_distinct_keys(ctx, k, L_, path):
     """60 000 reads over a 3 kbp genome (coverage in the thousands): 5-8 million windows, a few 10^4 distinct k-mers,
     into a table created with no hint.  One call; the table must end up sized for the distinct keys (not for the
     windows), through the estimator, the exact fine level and segments that receive more keys than they have slots."""
+    if FORCED_FANOUT:
+        pytest.skip("sizing behaviour of 256 L1 buckets: a 3 kbp genome leaves ~30 heavy k-mers per bucket of 1024, whose sizes no region bound covers")
     n, G = 60000, 3000
     rec = synth.reads_mode_g(n, L_, G, 0.001, config_id=900 + k)
     d = ctx.alloc(rec.size + 64)
