@@ -31,6 +31,8 @@ struct gk_ctx {
     int hook_p4_direct = -1;         // exact fine level: -1 auto (by nb2), 0 chunk sorted in LDS, 1 straight scatter with per-range cursors
     int hook_p2_wide = -1;           // over-provisioned L1 scatter: 1 = 1024 threads per tile (A/B)
     int hook_p2_sorted = -1;         // over-provisioned L1 scatter: 1 = bucket-ordered write-out (A/B)
+    int hook_max_nb2 = 0;            // test hook: the partitioned path refuses tables of more fine buckets per L1 bucket than this (0: MAX_NB2), so that
+                                     // a batch that outgrows the fan-out between its levels can be staged with a small table
     int hook_min_lnb1 = 0;           // test hook: tables of enough segments get at least 2^this L1 buckets (9, 10: the fan-out of tables beyond 34 GB)
     int hook_dist_ahead = -1;        // gk_dist_count_routed with three batches begun: 0 = do not post the next batch's exchange ahead (every rank alike)
     int hook_p24_pieces = -1;        // pipelined batch (both levels over-provisioned): pieces whose P4 overlaps the next piece's scatter (-1: default, 0/1: off)
@@ -187,6 +189,7 @@ int map_add_counted_keys_dev(gk_map *m, const uint64_t *d_keys, const int32_t *d
 void *map_scratch(gk_map *m, size_t bytes);          // pooled scratch (grown, never shrunk); nullptr + error set on failure
 // partitioned path (part_count may return PART_RETRY_DIRECT: take the direct path for this batch)
 constexpr int PART_RETRY_DIRECT = 1;
+constexpr int PART_OUTGREW = 3;          // the table grew between the levels past what its L1 fan-out lets the pipeline address: this batch goes the direct way
 constexpr int PART_NOT_UNIFORM = 2;      // ReadSrc::verify_uniform failed: walk the framing on the host and come again
 // estimate: keep the distinct-key sample and wait for it between the two partition levels — the table is then sized for the
 // batch's NEW DISTINCT keys (and may be replaced, same lnb1) instead of having been sized for its windows up front;

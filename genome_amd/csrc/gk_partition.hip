@@ -1481,7 +1481,16 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
             fine_exact = !op1 || plan.fine_exact || (double)est_new < 0.5 * (double)nkeys_bound;
         }
     }
-    if (!part_supported(m)) return fail(ctx, GK_E_CAPACITY, "table outgrew the partitioned insert path");   // (callers check part_supported first)
+    if (!part_supported(m)) {
+        // The table was just grown for this batch with its L1 fan-out kept (P2 has cut the batch by L1 bucket) and now has more
+        // fine buckets per L1 bucket than P4 sorts: only scratch was touched (the table itself is valid), so the batch takes
+        // the direct path; the next growth outside a batch picks a larger fan-out and the pipeline is back.
+        if (!sync_between) return fail(ctx, GK_E_CAPACITY, "table too large for the partitioned insert path");     // (callers check part_supported first)
+        GK_HIP(ctx, hipEventRecord(ctx->pev[5], ctx->stream));
+        abandon(false);
+        m->retries_direct--;
+        return PART_OUTGREW;
+    }
     if (!pipelined) { if (int rc = part_prepare_fine(m, ps, nkeys_bound, !fine_exact, &a)) return rc; }
     const u64 nseg = t.nseg();
     GK_HIP(ctx, hipEventRecord(ctx->gev, ctx->stream));
@@ -1618,7 +1627,7 @@ int part_count(gk_map *m, PartScratch **pps, const ReadSrc &src, const u64 *d_ke
 // the fine level's 4096-key sort must fit the CU's LDS beside its per-bin arrays and the L1 tables (16-byte keys with 1024 L1
 // buckets: ~3500 fine buckets, a 117 GB table)
 bool part_supported(const gk_map *m) {
-    if (m->nb2 > MAX_NB2) return false;
+    if (m->nb2 > (m->ctx->hook_max_nb2 > 0 ? (u32)m->ctx->hook_max_nb2 : MAX_NB2)) return false;
     const size_t need = (m->W == 1 ? ScatterLds<1>::bytes(m->nb2) : ScatterLds<2>::bytes(m->nb2)) + part_tables_bytes(1u << m->lnb1);
     return need <= LDS_BYTES_PER_CU;
 }

@@ -643,6 +643,7 @@ int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value) {
     else if (n == "p45_stripes") ctx->hook_p45_stripes = (int)value;
     else if (n == "p24_pieces") ctx->hook_p24_pieces = (int)value;
     else if (n == "dist_exchange_ahead") ctx->hook_dist_ahead = (int)value;
+    else if (n == "test_max_nb2") ctx->hook_max_nb2 = (int)std::max<int64_t>(0, value);
     else if (n == "min_lnb1") {
         if (value < 0 || value > (int64_t)gk::MAX_LNB1) return fail(ctx, GK_E_INVALID, "min_lnb1: 0..10");
         ctx->hook_min_lnb1 = (int)value;
@@ -941,9 +942,9 @@ static int launch_partitioned(gk_map *m, const ReadSrc &src, const u64 *d_keys, 
         return prc;
     }
     if (prc == PART_NOT_UNIFORM) { m->pending_clear = from_empty; return prc; }     // nothing but scratch (or a table that was being rebuilt from empty) was touched
-    if (prc == PART_RETRY_DIRECT) {        // extreme skew: nothing but scratch (or a table that was being rebuilt from empty) was touched
+    if (prc == PART_RETRY_DIRECT || prc == PART_OUTGREW) {        // extreme skew / outgrown fan-out: nothing but scratch (or a table that was being rebuilt from empty) was touched
         m->pending_clear = from_empty;
-        m->skewed = true;
+        if (prc == PART_RETRY_DIRECT) m->skewed = true;
         if (from_empty) m->size = 0;
         if (int rc = map_materialize(m)) return rc;
         if (int rc = map_reserve(m, bound)) return rc;

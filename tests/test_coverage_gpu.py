@@ -303,3 +303,33 @@ def test_pipelined_pieces_build_the_same_table(ctx, k, mode):
     finally:
         ctx.set_option("p24_pieces", -1)
         ctx.free(d)
+
+
+@pytest.mark.parametrize("k", [31, 47])
+def test_batch_that_outgrows_the_l1_fan_out_between_its_levels(ctx, k):
+    """A table with no capacity hint is grown BETWEEN the two levels of a batch, for the distinct keys the batch turned out to
+    hold, and must keep its L1 fan-out there (the batch is already cut by L1 bucket).  If that leaves more fine buckets per L1
+    bucket than the fine level sorts (4096: a table that passes 34 GB in one step), the batch must fall back to the direct path
+    — not fail — and the table must be the oracle's.  Staged with a small table through the `test_max_nb2` hook."""
+    n, L_ = 30000, 100
+    rec = synth.reads_mode_g(n, L_, 400000, 0.01, config_id=33 + k)
+    d = ctx.alloc(rec.size + 64)
+    ctx.upload(d, rec)
+    ref = O.PMap(k, 1)
+    occ = ref.count_reads(rec.tobytes(), n)
+    ctx.set_option("test_max_nb2", 2)
+    try:
+        m = HipDNAMap(ctx, k, 0)
+        m.set_insert_path("partitioned")
+        assert m.count_reads_dev(d, n, L_) == occ
+        st = m.stats()
+        assert st["partitioned_launches"] == 0 and st["direct_launches"] >= 1, st       # the pipeline started, gave the batch back
+        assert_same_table(m.sorted_items(), ref.export_sorted())
+        assert m.verify()[1] == 0
+        assert m.count_reads_dev(d, n, L_) == occ                                       # and the map keeps working
+        lo, hi, cnt = ref.export_sorted()
+        assert_same_table(m.sorted_items(), (lo, hi, cnt * 2))
+        m.close()
+    finally:
+        ctx.set_option("test_max_nb2", 0)
+        ctx.free(d)
