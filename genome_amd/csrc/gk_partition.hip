@@ -48,6 +48,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "gk_internal.h"
@@ -446,8 +447,13 @@ __global__ __launch_bounds__(NT, GK_OP_MIN_WAVES) void k_op_scatter1_reads(const
     __shared__ __attribute__((aligned(16))) u32 tile[OP_TILE_WORDS];
     __shared__ u64 flat[OP_CAP];
     __shared__ uint16_t fbin[OP_CAP / W];      // 0xffff = hole (bucket ids use all 256 byte values)
-    __shared__ u32 hist[NB1], rank[NB1], lim[NB1];
-    __shared__ unsigned long long gb[NB1];
+    // (the 1024-bucket form keeps its per-bucket arrays narrow — a tile holds < 2^16 keys, a region < 2^32 — so that two
+    //  workgroups still fit a CU: 79 KB each)
+    using LimT = typename std::conditional<NB1 == 256, u32, uint16_t>::type;
+    using GbT = typename std::conditional<NB1 == 256, unsigned long long, u32>::type;
+    __shared__ u32 hist[NB1], rank[NB1];
+    __shared__ LimT lim[NB1];
+    __shared__ GbT gb[NB1];
     __shared__ uint16_t perm[SORTED ? OP_CAP / W : 1];
     __shared__ u32 wsum[NT / 64];
     u32 occ = 0, claims = 0;
@@ -492,10 +498,10 @@ __global__ __launch_bounds__(NT, GK_OP_MIN_WAVES) void k_op_scatter1_reads(const
             u32 fit = 0;
             if (c) {
                 const unsigned long long at = atomicAdd(&a.cursor1[b], (unsigned long long)c);
-                gb[b] = at;                                         // position inside the region (l1_slot maps it)
+                gb[b] = (GbT)at;                                    // position inside the region (l1_slot maps it; only used where at < cap1)
                 fit = at >= a.cap1 ? 0u : (u32)min((unsigned long long)c, a.cap1 - at);
             }
-            lim[b] = fit;
+            lim[b] = (LimT)fit;
             if (SORTED) rank[b] = c;
         }
         __syncthreads();
@@ -526,7 +532,7 @@ __global__ __launch_bounds__(NT, GK_OP_MIN_WAVES) void k_op_scatter1_reads(const
 #pragma unroll
                 for (int q = 0; q < U; q++) {
                     if (idx[q] == 0xffffffffu) continue;
-                    if (jj[q] < lim[bb[q]]) store_key<W>(out, l1_slot(a, bb[q], gb[bb[q]] + jj[q]), xx[q]);
+                    if (jj[q] < (u32)lim[bb[q]]) store_key<W>(out, l1_slot(a, bb[q], (u64)gb[bb[q]] + jj[q]), xx[q]);
                     else if constexpr (W == 1) spill_key<1>(a, xx[q].lo, 0);
                     else spill_key<2>(a, xx[q].lo, xx[q].hi);
                 }
@@ -545,7 +551,7 @@ __global__ __launch_bounds__(NT, GK_OP_MIN_WAVES) void k_op_scatter1_reads(const
                 for (int q = 0; q < U; q++) {
                     if (b[q] == 0xffffu) continue;
                     const Kmer<W> x = load_key<W>(flat, i0 + q * NT);
-                    if (j[q] < lim[b[q]]) store_key<W>(out, l1_slot(a, b[q], gb[b[q]] + j[q]), x);
+                    if (j[q] < (u32)lim[b[q]]) store_key<W>(out, l1_slot(a, b[q], (u64)gb[b[q]] + j[q]), x);
                     else if constexpr (W == 1) spill_key<1>(a, x.lo, 0);
                     else spill_key<2>(a, x.lo, x.hi);
                 }
