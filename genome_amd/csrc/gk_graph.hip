@@ -2469,24 +2469,59 @@ int gk_graph_walk_pairs(gk_graph *g, gk_vmap *positions, gk_support *sup, const 
     const double t_begin = now();
     // ---- the pairs whose mates both hold k bases (:213), their four keys
     std::vector<u64> klo, khi;
-    klo.reserve((size_t)std::min<uint64_t>(npairs, nbytes / 2) * 4); khi.reserve(klo.capacity());
-    size_t pos = 0;
-    for (uint64_t p = 0; p < npairs && pos < nbytes; p++) {
-        const uint8_t *r1 = bin + pos;
-        const int l1 = r1[0];
-        pos += 1 + (size_t)(l1 + 3) / 4;
-        if (pos >= nbytes) return fail(ctx, GK_E_FORMAT, "gk_graph_walk_pairs: the stream ends inside a pair");
-        const uint8_t *r2 = bin + pos;
-        const int l2 = r2[0];
-        pos += 1 + (size_t)(l2 + 3) / 4;
-        if (pos > nbytes) return fail(ctx, GK_E_FORMAT, "gk_graph_walk_pairs: the stream ends inside a record");
-        if (l1 < k || l2 < k) continue;
+    auto four_keys = [k](const uint8_t *r1, int l1, const uint8_t *r2, int l2, u64 *lo4, u64 *hi4) {
         u64 alo, ahi, blo, bhi, ralo, rahi, rblo, rbhi;
         first_kmer(r1 + 1, (size_t)(l1 + 3) / 4, k, alo, ahi); first_kmer(r2 + 1, (size_t)(l2 + 3) / 4, k, blo, bhi);
         revcomp_host(alo, ahi, k, ralo, rahi); revcomp_host(blo, bhi, k, rblo, rbhi);
         // f1 = getAll(p1.take(k)), f2 = getAll(p2.take(k).revComplement), f3 = getAll(p2.take(k)), f4 = getAll(p1.take(k).revComplement)
-        klo.insert(klo.end(), {alo, rblo, blo, ralo});
-        khi.insert(khi.end(), {ahi, rbhi, bhi, rahi});
+        lo4[0] = alo; lo4[1] = rblo; lo4[2] = blo; lo4[3] = ralo;
+        hi4[0] = ahi; hi4[1] = rbhi; hi4[2] = bhi; hi4[3] = rahi;
+    };
+    // A stream of equal-length records (what a sequencer's run is) is cut by several threads, each checking the length bytes
+    // of its share; one that turns out ragged is walked serially.
+    bool cut = false;
+    if (npairs >= 65536 && nbytes && bin[0] >= k) {
+        const int l0 = bin[0];
+        const size_t rb = 1 + (size_t)(l0 + 3) / 4;
+        if (nbytes >= 2 * npairs * rb) {
+            klo.resize((size_t)npairs * 4); khi.resize((size_t)npairs * 4);
+            const unsigned nt = (unsigned)std::max<u64>(1, std::min<u64>({(u64)std::thread::hardware_concurrency(), 16, npairs / 32768}));
+            std::vector<uint8_t> ragged(nt, 0);
+            auto share = [&](unsigned t) {
+                const uint64_t p0 = npairs * t / nt, p1 = npairs * (t + 1) / nt;
+                for (uint64_t p = p0; p < p1; p++) {
+                    const uint8_t *r1 = bin + 2 * p * rb, *r2 = r1 + rb;
+                    if (r1[0] != l0 || r2[0] != l0) { ragged[t] = 1; return; }
+                    four_keys(r1, l0, r2, l0, &klo[4 * p], &khi[4 * p]);
+                }
+            };
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < nt; t++) th.emplace_back(share, t);
+            share(0);
+            for (auto &x : th) x.join();
+            cut = true;
+            for (unsigned t = 0; t < nt; t++) if (ragged[t]) cut = false;
+            if (!cut) { klo.clear(); khi.clear(); }
+        }
+    }
+    if (!cut) {
+        klo.reserve((size_t)std::min<uint64_t>(npairs, nbytes / 2) * 4); khi.reserve(klo.capacity());
+        size_t pos = 0;
+        for (uint64_t p = 0; p < npairs && pos < nbytes; p++) {
+            const uint8_t *r1 = bin + pos;
+            const int l1 = r1[0];
+            pos += 1 + (size_t)(l1 + 3) / 4;
+            if (pos >= nbytes) return fail(ctx, GK_E_FORMAT, "gk_graph_walk_pairs: the stream ends inside a pair");
+            const uint8_t *r2 = bin + pos;
+            const int l2 = r2[0];
+            pos += 1 + (size_t)(l2 + 3) / 4;
+            if (pos > nbytes) return fail(ctx, GK_E_FORMAT, "gk_graph_walk_pairs: the stream ends inside a record");
+            if (l1 < k || l2 < k) continue;
+            u64 lo4[4], hi4[4];
+            four_keys(r1, l1, r2, l2, lo4, hi4);
+            klo.insert(klo.end(), lo4, lo4 + 4);
+            khi.insert(khi.end(), hi4, hi4 + 4);
+        }
     }
     const u64 nq = klo.size();
     if (nq == 0) return GK_OK;

@@ -231,3 +231,31 @@ def test_walk_pairs_fuzz_small_cyclic_graphs(ctx, seed):
     g_.simplifyGraph()
     assert gpu_canonical(g_) == oracle_canonical(og)
     vm.close(); g_.close(); m.close()
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_walk_pairs_large_uniform_stream_is_cut_by_threads(ctx, ragged):
+    """From 65 536 pairs up a stream of equal-length records is cut into its k-mers by several host threads, each checking the
+    length bytes of its share; one that turns out ragged (here: one mate in the middle a base shorter) is walked serially.
+    Both give the oracle's support counts."""
+    k, rng = 21, (60, 95)
+    reads = make_pairs(11, k, npairs=70000)
+    if ragged:
+        reads[70001] = reads[70001][:-1]
+    binb = dna.reads_to_bin(reads)
+    npairs = len(reads) // 2
+    m, ref = HipDNAMap(ctx, k), O.PMap(k, 1)
+    m.count_reads(binb, len(reads)); ref.count_reads(binb, len(reads))
+    m.deleteAll_lt(2); ref.delete_lt(2)
+    g, og = buildGraph(k, m), O.Graph(ref)
+    assert gpu_canonical(g) == oracle_canonical(og)
+    vm = g.getGraphMap()
+    sup, osup = Support(ctx), O.Support()
+    g.walkPairs(vm, sup, binb, npairs, *rng)
+    walked = og.walk_pairs(osup, binb, npairs, *rng)
+    pairs, bad, w = sup.sizes()
+    assert w == walked and bad == osup.bad_pairs()
+    want = oracle_support_by_content(og, k, osup)
+    assert len(want) > 0
+    assert gpu_support_by_content(g, k, sup) == want
+    vm.close(); g.close(); m.close()
