@@ -333,3 +333,40 @@ def test_batch_that_outgrows_the_l1_fan_out_between_its_levels(ctx, k):
     finally:
         ctx.set_option("test_max_nb2", 0)
         ctx.free(d)
+
+
+@pytest.mark.parametrize("k", [31, 55])
+def test_growth_across_a_change_of_the_l1_fan_out(ctx, k):
+    """A table that grows past 34 GB changes its L1 fan-out (256 -> 512 / 1024 L1 buckets) and with it the hash bits its fine
+    buckets use: that growth is a k_rehash into the new geometry, not the segment-local streaming rebuild.  Staged small: a
+    table built with 256 L1 buckets, then `min_lnb1` raised so that the next growth picks 1024 — direct inserts and a
+    partitioned batch on both sides of the change, against the oracle."""
+    n, L_ = 24000, 100
+    rec = synth.reads_mode_g(n, L_, 500000, 0.01, config_id=91 + k)
+    d = ctx.alloc(rec.size + 64)
+    ctx.upload(d, rec)
+    stride = rec.shape[1]
+    ref = O.PMap(k, 1)
+    m = HipDNAMap(ctx, k, 360000)                     # ~270 segments: 256 L1 buckets, and too small for two thirds of the keys
+    try:
+        third = n // 3
+        m.set_insert_path("partitioned")
+        assert m.count_reads_dev(d, third, L_) == ref.count_reads(rec[:third].tobytes(), third)
+        slots0 = m.stats()["slots"]
+        ctx.set_option("min_lnb1", 10)
+        m.set_insert_path("direct")                   # grows by map_reserve -> k_rehash into a 1024-bucket table
+        assert m.count_reads_dev(d + third * stride, third, L_) == ref.count_reads(rec[third:2 * third].tobytes(), third)
+        assert m.stats()["slots"] > slots0
+        assert_same_table(m.sorted_items(), ref.export_sorted())
+        assert m.verify()[1] == 0
+        m.set_insert_path("partitioned")              # the pipeline over the new geometry
+        rest = n - 2 * third
+        assert m.count_reads_dev(d + 2 * third * stride, rest, L_) == ref.count_reads(rec[2 * third:].tobytes(), rest)
+        assert m.stats()["partitioned_launches"] >= 1
+        assert_same_table(m.sorted_items(), ref.export_sorted())
+        assert m.verify()[1] == 0
+        m.deleteAll_lt(2); ref.delete_lt(2)           # and the filter + rebuild on the 1024-bucket table
+        assert_same_table(m.sorted_items(), ref.export_sorted())
+    finally:
+        ctx.set_option("min_lnb1", 0)
+        m.close(); ctx.free(d)
