@@ -72,8 +72,13 @@ int gk_ctx_trim(gk_ctx *ctx);
  * "graph_unitigs" (0 auto, 1 walk, 2 pointer jumping), "graph_walk_queue" (0: one edge per lane), "graph_load_pct" (load factor
  * of the compacted table, percent), "graph_mem" (1 uncached / 2 fine-grained memory for it), "graph_aligned" (1: probes start at
  * the first slot of a 128-byte line), "p4_direct" / "fine_exact" / "p4_wide" / "p2_wide" / "p2_sorted" (-1 auto, 0, 1),
- * "p45_stripes" (P5 of one stripe of L1 buckets beside P4 of the next), "p4_grid" (P4 workgroups per CU): A/B switches of
- * the kernels in gk_partition.hip / gk_graph.hip; what each measured is in DESIGN.md and profiles/r02. */
+ * "p45_stripes" (P5 of one stripe of L1 buckets beside P4 of the next), "p24_pieces" (P4 of one piece of a batch beside the L1
+ * scatter of the next), "p4_grid" (P4 workgroups per CU), "filter_classic" (1: tombstones + rehash instead of the streaming
+ * rebuild), "dist_exchange_ahead" (0: gk_dist_count_routed does not post the next batch's exchange ahead; every rank alike):
+ * A/B switches of the kernels in gk_partition.hip / gk_graph.hip / gk_dist.hip; what each measured is in DESIGN.md and
+ * profiles/r02.  "min_lnb1" (also GK_MIN_LNB1; 9 / 10: tables of enough segments get 512 / 1024 L1 buckets, the fan-out of
+ * tables beyond 34 GB) and "test_max_nb2" (the pipeline refuses tables of more fine buckets per L1 bucket) stage the
+ * large-table paths on small tables. */
 int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value);
 /* Pinned host memory: gk_map_count_reads / gk_prefilter_add_reads read the caller's `.bin` buffer with asynchronous copies
  * that overlap the insert kernels only if the buffer is page-locked — allocate it here, or register an existing one (a JNI
