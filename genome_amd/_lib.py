@@ -93,6 +93,7 @@ SIGNATURES = {
     "gk_map_count_superkmers_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, u64p]),
     "gk_dist_unique_id": (C.c_int, [vp]),
     "gk_dist_create": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]),
+    "gk_dist_create_loopback": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]),
     "gk_dist_destroy": (None, [vp]),
     "gk_dist_rank": (C.c_int, [vp]),
     "gk_dist_world": (C.c_int, [vp]),

@@ -21,7 +21,12 @@
 #include <time.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -84,10 +89,41 @@ Rccl *rccl() {
 }
 }  // namespace
 
+// ---- loopback transport (tests): the ranks of one "node" are threads of ONE process on ONE device --------------------------
+// RCCL refuses two ranks on one GPU, and only one GPU is reachable from the build box: gk_dist_create_loopback gives every
+// rank a handle whose sends, receives and reductions go through this hub instead — device-to-device copies between the
+// ranks' buffers, matched pairwise in posting order like RCCL's — so that the exchange logic of gk_dist_* (sizes, regions,
+// buffer rotation, the order of operations across ranks) runs with world > 1 before it ever meets a real communicator.  It is
+// STRICTER than RCCL in two ways that make it a better test: a group's end blocks until every peer has posted the matching
+// operation (an inconsistent order of operations across ranks deadlocks here at once), and a send whose size differs from
+// the matching receive is an error.
+namespace {
+struct LoopHub {
+    std::mutex mu;
+    std::condition_variable cv;
+    int world = 0, refs = 0;
+    struct Op { void *ptr; size_t bytes; hipStream_t stream; hipEvent_t ready; bool *done; int *err; };
+    std::deque<Op> sends[64][64], recvs[64][64];          // [src][dst], in posting order
+    // reductions / gathers: one at a time, every rank contributes
+    unsigned long long gen = 0;
+    int arrived = 0;
+    double contrib[64][32];
+    double result[64 * 32];
+    std::vector<hipEvent_t> events;                       // every event the transport made; destroyed with the hub
+    ~LoopHub() { for (hipEvent_t e : events) if (e) (void)hipEventDestroy(e); }
+};
+std::mutex g_hubs_mu;
+std::map<std::string, std::shared_ptr<LoopHub>> g_hubs;
+}  // namespace
+
 struct gk_dist {
     gk_ctx *ctx = nullptr;
     int rank = 0, world = 1;
     ncclComm_t comm = nullptr;
+    std::shared_ptr<LoopHub> loop;                   // the loopback transport (tests) instead of RCCL
+    std::string loop_key;
+    struct Posted { bool send; void *ptr; size_t bytes; int peer; hipStream_t stream; };
+    std::vector<Posted> group;                       // loopback: the operations of the group being built
     // Every RCCL call of this handle goes to ONE stream of its own (operations on a communicator must not run concurrently):
     // the exchange of batch i+1 can then be in flight while the owner pipeline of batch i runs on the context's stream.
     hipStream_t comm_stream = nullptr;
@@ -120,12 +156,130 @@ struct gk_dist {
     float last_helper_ms = 0;                        // host time of the exchange that ran beside the last owner count
 };
 
+static std::string comm_error_text(int code) {
+    if (code == 3) return "transport error (loopback: a send and its receive differ in size, or a HIP call failed)";
+    Rccl *r = rccl();
+    return r->GetErrorString ? r->GetErrorString(code) : "RCCL error";
+}
 #define GK_NCCL(ctx, call)                                                                                        \
     do {                                                                                                          \
         int r__ = (call);                                                                                         \
         if (r__ != ncclSuccess)                                                                                   \
-            return gk::fail((ctx), GK_E_COMM, std::string(#call) + ": " + (rccl()->GetErrorString ? rccl()->GetErrorString(r__) : "RCCL error")); \
+            return gk::fail((ctx), GK_E_COMM, std::string(#call) + ": " + comm_error_text(r__)); \
     } while (0)
+
+// ---- transport: RCCL, or the loopback hub -----------------------------------------------------------------------------------
+static size_t dtype_bytes(int dt) { return dt == ncclUint64 || dt == ncclFloat64 ? 8 : 1; }
+static int xGroupStart(gk_dist *d) {
+    if (!d->loop) return rccl()->GroupStart();
+    d->group.clear();
+    return ncclSuccess;
+}
+static int xSend(gk_dist *d, const void *p, size_t count, int dt, int peer, hipStream_t st) {
+    if (!d->loop) return rccl()->Send(p, count, dt, peer, d->comm, st);
+    d->group.push_back({true, const_cast<void *>(p), count * dtype_bytes(dt), peer, st});
+    return ncclSuccess;
+}
+static int xRecv(gk_dist *d, void *p, size_t count, int dt, int peer, hipStream_t st) {
+    if (!d->loop) return rccl()->Recv(p, count, dt, peer, d->comm, st);
+    d->group.push_back({false, p, count * dtype_bytes(dt), peer, st});
+    return ncclSuccess;
+}
+static int xGroupEnd(gk_dist *d) {
+    if (!d->loop) return rccl()->GroupEnd();
+    LoopHub &h = *d->loop;
+    const size_t n = d->group.size();
+    std::unique_ptr<bool[]> done(new bool[n]());
+    int err = 0;
+    std::unique_lock<std::mutex> lk(h.mu);
+    for (size_t i = 0; i < n; i++) {
+        const gk_dist::Posted &o = d->group[i];
+        hipEvent_t ev = nullptr;
+        if (o.send) {                                 // the data is ready once the sender's stream reaches this point
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, o.stream) != hipSuccess) err = 1;
+            h.events.push_back(ev);
+            h.sends[d->rank][o.peer].push_back({o.ptr, o.bytes, o.stream, ev, &done[i], &err});
+        } else {
+            h.recvs[o.peer][d->rank].push_back({o.ptr, o.bytes, o.stream, nullptr, &done[i], &err});
+        }
+    }
+    // match whatever can be matched (any thread may complete any pair), then wait for the rest of this group
+    auto match_all = [&]() {
+        for (int s = 0; s < h.world; s++)
+            for (int r = 0; r < h.world; r++)
+                while (!h.sends[s][r].empty() && !h.recvs[s][r].empty()) {
+                    LoopHub::Op a = h.sends[s][r].front(), b = h.recvs[s][r].front();
+                    h.sends[s][r].pop_front(); h.recvs[s][r].pop_front();
+                    int e = 0;
+                    if (a.bytes != b.bytes) e = 2;                               // RCCL would hang or corrupt here
+                    else if (a.bytes) {
+                        hipEvent_t copied = nullptr;
+                        if (hipStreamWaitEvent(b.stream, a.ready, 0) != hipSuccess) e = 1;
+                        if (!e && hipMemcpyAsync(b.ptr, a.ptr, a.bytes, hipMemcpyDeviceToDevice, b.stream) != hipSuccess) e = 1;
+                        // the sender may reuse its buffer only after the copy: its stream waits for it
+                        if (!e && (hipEventCreateWithFlags(&copied, hipEventDisableTiming) != hipSuccess || hipEventRecord(copied, b.stream) != hipSuccess ||
+                                   hipStreamWaitEvent(a.stream, copied, 0) != hipSuccess)) e = 1;
+                        if (copied) h.events.push_back(copied);
+                    }
+                    if (e) { *a.err = e; *b.err = e; }
+                    *a.done = true; *b.done = true;
+                }
+    };
+    auto all_done = [&]() { for (size_t i = 0; i < n; i++) if (!done[i]) return false; return true; };
+    match_all();
+    h.cv.notify_all();
+    while (!all_done()) {
+        h.cv.wait(lk);
+        match_all();
+        h.cv.notify_all();
+    }
+    lk.unlock();
+    d->group.clear();
+    return err ? 3 /* ncclInternalError */ : ncclSuccess;
+}
+// all-reduce (sum / max) of n <= 32 values of 8 bytes, or (gather = true) one value from every rank to every rank
+static int loop_collective(gk_dist *d, const void *in, void *out, size_t n, int dt, int op, bool gather, hipStream_t st) {
+    LoopHub &h = *d->loop;
+    if (n > 32 || (gather && n != 1)) return 3;
+    double mine[32];
+    if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(mine, in, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 3;
+    double res[64 * 32];
+    size_t nres = gather ? (size_t)h.world : n;
+    {
+        std::unique_lock<std::mutex> lk(h.mu);
+        const unsigned long long gen = h.gen;
+        memcpy(h.contrib[d->rank], mine, n * 8);
+        if (++h.arrived == h.world) {
+            for (size_t i = 0; i < nres; i++) {
+                if (gather) { memcpy(&h.result[i], &h.contrib[i][0], 8); continue; }
+                if (dt == ncclFloat64) {
+                    double acc = h.contrib[0][i];
+                    for (int r = 1; r < h.world; r++) acc = op == ncclMax ? std::max(acc, h.contrib[r][i]) : acc + h.contrib[r][i];
+                    h.result[i] = acc;
+                } else {
+                    unsigned long long acc = 0, v;
+                    for (int r = 0; r < h.world; r++) { memcpy(&v, &h.contrib[r][i], 8); acc = op == ncclMax ? std::max(acc, v) : acc + v; }
+                    memcpy(&h.result[i], &acc, 8);
+                }
+            }
+            h.arrived = 0;
+            h.gen++;
+            h.cv.notify_all();
+        } else {
+            h.cv.wait(lk, [&]() { return h.gen != gen; });
+        }
+        memcpy(res, h.result, nres * 8);
+    }
+    return hipMemcpyAsync(out, res, nres * 8, hipMemcpyHostToDevice, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess ? ncclSuccess : 3;
+}
+static int xAllReduce(gk_dist *d, const void *in, void *out, size_t n, int dt, int op, hipStream_t st) {
+    if (!d->loop) return rccl()->AllReduce(in, out, n, dt, op, d->comm, st);
+    return loop_collective(d, in, out, n, dt, op, false, st);
+}
+static int xAllGather(gk_dist *d, const void *in, void *out, size_t n_per_rank, int dt, hipStream_t st) {
+    if (!d->loop) return rccl()->AllGather(in, out, n_per_rank, dt, d->comm, st);
+    return loop_collective(d, in, out, n_per_rank, dt, ncclSum, true, st);
+}
 
 // live (key, count) of a table packed for the wire: keys interleaved W words each (what k_add_keys takes), counts apart
 template <int W>
@@ -158,7 +312,7 @@ __global__ __launch_bounds__(BLOCK) void k_export_packed(const Slot<W> *__restri
 }
 
 static int dist_check(const gk_dist *d) {
-    if (!d || !d->ctx || !d->comm) return fail(nullptr, GK_E_INVALID, "null or closed gk_dist handle");
+    if (!d || !d->ctx || (!d->comm && !d->loop)) return fail(nullptr, GK_E_INVALID, "null or closed gk_dist handle");
     hipError_t e = hipSetDevice(d->ctx->device);
     if (e != hipSuccess) return hip_fail(d->ctx, e, "hipSetDevice");
     return GK_OK;
@@ -182,21 +336,32 @@ int gk_dist_unique_id(void *id128) {
     return GK_OK;
 }
 
-int gk_dist_create(gk_ctx *ctx, int rank, int world, const void *id128, gk_dist **out) {
+static int dist_create(gk_ctx *ctx, int rank, int world, const void *id128, bool loopback, gk_dist **out) {
     if (!ctx || !out || !id128) return fail(ctx, GK_E_INVALID, "gk_dist_create: null argument");
     *out = nullptr;
     if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail(ctx, GK_E_INVALID, "gk_dist_create: need 0 <= rank < world <= 64");
-    Rccl *r = rccl();
-    if (!r->why.empty()) return fail(ctx, GK_E_COMM, r->why);
+    Rccl *r = loopback ? nullptr : rccl();
+    if (r && !r->why.empty()) return fail(ctx, GK_E_COMM, r->why);
     GK_HIP(ctx, hipSetDevice(ctx->device));
     gk_dist *d = new gk_dist();
     d->ctx = ctx; d->rank = rank; d->world = world;
-    ncclUniqueId id;
-    memcpy(id.internal, id128, 128);
-    int rc = r->CommInitRank(&d->comm, world, id, rank);
-    if (rc != ncclSuccess) {
-        delete d;
-        return fail(ctx, GK_E_COMM, std::string("ncclCommInitRank: ") + (r->GetErrorString ? r->GetErrorString(rc) : "error"));
+    if (loopback) {
+        // the ranks of one loopback "node" find each other by the id (any 128 bytes every rank was given alike)
+        d->loop_key.assign((const char *)id128, 128);
+        std::lock_guard<std::mutex> lk(g_hubs_mu);
+        std::shared_ptr<LoopHub> &h = g_hubs[d->loop_key];
+        if (!h) { h = std::make_shared<LoopHub>(); h->world = world; }
+        if (h->world != world) { delete d; return fail(ctx, GK_E_INVALID, "gk_dist_create_loopback: the ranks of one id disagree about the world size"); }
+        h->refs++;
+        d->loop = h;
+    } else {
+        ncclUniqueId id;
+        memcpy(id.internal, id128, 128);
+        int rc = r->CommInitRank(&d->comm, world, id, rank);
+        if (rc != ncclSuccess) {
+            delete d;
+            return fail(ctx, GK_E_COMM, std::string("ncclCommInitRank: ") + (r->GetErrorString ? r->GetErrorString(rc) : "error"));
+        }
     }
     hipError_t e = hipMalloc((void **)&d->d_cnt, 4 * 64 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc((void **)&d->h_cnt, 4 * 64 * sizeof(unsigned long long), hipHostMallocDefault);
@@ -206,10 +371,13 @@ int gk_dist_create(gk_ctx *ctx, int rank, int world, const void *id128, gk_dist 
     if (e == hipSuccess) e = hipEventCreateWithFlags(&d->join, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipHostMalloc((void **)&d->h_route_cnt, gk_dist::NROUTE * SKM_COUNT_WORDS * sizeof(unsigned long long), hipHostMallocDefault);
-    if (e != hipSuccess) { int c = hip_fail(ctx, e, "gk_dist_create"); r->CommDestroy(d->comm); delete d; return c; }
+    if (e != hipSuccess) { int c = hip_fail(ctx, e, "gk_dist_create"); gk_dist_destroy(d); return c; }
     *out = d;
     return GK_OK;
 }
+
+int gk_dist_create(gk_ctx *ctx, int rank, int world, const void *id128, gk_dist **out) { return dist_create(ctx, rank, world, id128, false, out); }
+int gk_dist_create_loopback(gk_ctx *ctx, int rank, int world, const void *id128, gk_dist **out) { return dist_create(ctx, rank, world, id128, true, out); }
 
 void gk_dist_destroy(gk_dist *d) {
     if (!d) return;
@@ -217,6 +385,11 @@ void gk_dist_destroy(gk_dist *d) {
     if (d->ctx) { (void)hipSetDevice(d->ctx->device); (void)hipStreamSynchronize(d->ctx->stream); }
     if (d->comm_stream) (void)hipStreamSynchronize(d->comm_stream);
     if (d->comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(d->comm);
+    if (d->loop) {
+        std::lock_guard<std::mutex> lk(g_hubs_mu);
+        if (--d->loop->refs == 0) g_hubs.erase(d->loop_key);
+        d->loop.reset();
+    }
     if (d->ctx && d->ctx->copy_stream) (void)hipStreamSynchronize(d->ctx->copy_stream);
     for (int i = 0; i < gk_dist::NROUTE; i++) if (d->d_sendbuf[i]) (void)hipFree(d->d_sendbuf[i]);
     for (int i = 0; i < 2; i++) if (d->d_recv[i]) (void)hipFree(d->d_recv[i]);
@@ -246,7 +419,7 @@ int gk_dist_barrier(gk_dist *d) {
     gk_ctx *ctx = d->ctx;
     if (int rc = dist_quiesce(d)) return rc;
     GK_HIP(ctx, hipMemsetAsync(d->d_cnt, 0, 8, ctx->stream));
-    GK_NCCL(ctx, rccl()->AllReduce(d->d_cnt, d->d_cnt, 1, ncclUint64, ncclSum, d->comm, ctx->stream));
+    GK_NCCL(ctx, xAllReduce(d, d->d_cnt, d->d_cnt, 1, ncclUint64, ncclSum, ctx->stream));
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GK_OK;
 }
@@ -258,7 +431,7 @@ int gk_dist_allreduce_f64(gk_dist *d, double *values, int n, int op_max) {
     if (int rc = dist_quiesce(d)) return rc;
     double *dv = reinterpret_cast<double *>(d->d_cnt);
     GK_HIP(ctx, hipMemcpyAsync(dv, values, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    GK_NCCL(ctx, rccl()->AllReduce(dv, dv, (size_t)n, ncclFloat64, op_max ? ncclMax : ncclSum, d->comm, ctx->stream));
+    GK_NCCL(ctx, xAllReduce(d, dv, dv, (size_t)n, ncclFloat64, op_max ? ncclMax : ncclSum, ctx->stream));
     GK_HIP(ctx, hipMemcpyAsync(values, dv, n * 8, hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GK_OK;
@@ -271,7 +444,7 @@ int gk_dist_size(gk_dist *d, gk_map *local, uint64_t *total) {
     if (int rc = dist_quiesce(d)) return rc;
     unsigned long long v = local->size;
     GK_HIP(ctx, hipMemcpyAsync(d->d_cnt, &v, 8, hipMemcpyHostToDevice, ctx->stream));
-    GK_NCCL(ctx, rccl()->AllReduce(d->d_cnt, d->d_cnt, 1, ncclUint64, ncclSum, d->comm, ctx->stream));
+    GK_NCCL(ctx, xAllReduce(d, d->d_cnt, d->d_cnt, 1, ncclUint64, ncclSum, ctx->stream));
     GK_HIP(ctx, hipMemcpyAsync(&v, d->d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *total = v;
@@ -361,13 +534,12 @@ static int dist_exchange(gk_dist *d, int b, float *ms2) {
     for (int p = 0; p < P; p++) { d->h_cnt[2 * p] = recs[p]; d->h_cnt[2 * p + 1] = kmers[p]; sent += kmers[p]; }
     unsigned long long *d_in = d->d_cnt, *d_out = d->d_cnt + 2 * 64;
     GK_HIP(ctx, hipMemcpyAsync(d_in, d->h_cnt, 2 * P * 8, hipMemcpyHostToDevice, cs));
-    Rccl *r = rccl();
-    GK_NCCL(ctx, r->GroupStart());
+    GK_NCCL(ctx, xGroupStart(d));
     for (int p = 0; p < P; p++) {
-        GK_NCCL(ctx, r->Send(d_in + 2 * p, 2, ncclUint64, p, d->comm, cs));
-        GK_NCCL(ctx, r->Recv(d_out + 2 * p, 2, ncclUint64, p, d->comm, cs));
+        GK_NCCL(ctx, xSend(d, d_in + 2 * p, 2, ncclUint64, p, cs));
+        GK_NCCL(ctx, xRecv(d, d_out + 2 * p, 2, ncclUint64, p, cs));
     }
-    GK_NCCL(ctx, r->GroupEnd());
+    GK_NCCL(ctx, xGroupEnd(d));
     unsigned long long *h_out = d->h_cnt + 2 * 64;
     GK_HIP(ctx, hipMemcpyAsync(h_out, d_out, 2 * P * 8, hipMemcpyDeviceToHost, cs));
     GK_HIP(ctx, hipStreamSynchronize(cs));                     // (also: the previous batch's records have arrived)
@@ -377,14 +549,14 @@ static int dist_exchange(gk_dist *d, int b, float *ms2) {
     //         that is NOT being counted (the batch counted two exchanges ago has returned)
     const int rb = (int)(d->nexchanged & 1);
     if (int rc = dist_grow(ctx, &d->d_recv[rb], &d->recv_records[rb], std::max<u64>(nrec_in, d->recv_records[rb]), slot)) return rc;
-    GK_NCCL(ctx, r->GroupStart());
+    GK_NCCL(ctx, xGroupStart(d));
     u64 roff = 0;
     for (int p = 0; p < P; p++) {
-        if (recs[p]) GK_NCCL(ctx, r->Send(d->d_sendbuf[b] + (u64)p * region * slot, (size_t)recs[p] * slot, ncclUint8, p, d->comm, cs));
-        if (h_out[2 * p]) GK_NCCL(ctx, r->Recv(d->d_recv[rb] + roff * slot, (size_t)h_out[2 * p] * slot, ncclUint8, p, d->comm, cs));
+        if (recs[p]) GK_NCCL(ctx, xSend(d, d->d_sendbuf[b] + (u64)p * region * slot, (size_t)recs[p] * slot, ncclUint8, p, cs));
+        if (h_out[2 * p]) GK_NCCL(ctx, xRecv(d, d->d_recv[rb] + roff * slot, (size_t)h_out[2 * p] * slot, ncclUint8, p, cs));
         roff += h_out[2 * p];
     }
-    GK_NCCL(ctx, r->GroupEnd());
+    GK_NCCL(ctx, xGroupEnd(d));
     GK_HIP(ctx, hipEventRecord(d->exch_done[b], cs));
     rt.exchanged = true; rt.rbuf = rb; rt.nrec_in = nrec_in; rt.nkm_in = nkm_in; rt.sent = sent;
     d->nexchanged++;
@@ -478,11 +650,10 @@ int gk_dist_gather_map(gk_dist *d, gk_map *local, gk_map **full) {
     if (int rc = dist_quiesce(d)) return rc;
     if (int rc = map_materialize(local)) return rc;
     const int P = d->world, W = local->W;
-    Rccl *r = rccl();
     // sizes
     unsigned long long mine = local->size;
     GK_HIP(ctx, hipMemcpyAsync(d->d_cnt + 64, &mine, 8, hipMemcpyHostToDevice, ctx->stream));
-    GK_NCCL(ctx, r->AllGather(d->d_cnt + 64, d->d_cnt, 1, ncclUint64, d->comm, ctx->stream));
+    GK_NCCL(ctx, xAllGather(d, d->d_cnt + 64, d->d_cnt, 1, ncclUint64, ctx->stream));
     GK_HIP(ctx, hipMemcpyAsync(d->h_cnt, d->d_cnt, P * 8, hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     u64 total = 0, my_off = 0;
@@ -515,20 +686,20 @@ int gk_dist_gather_map(gk_dist *d, gk_map *local, gk_map **full) {
         if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_dist_gather_map: export"));
     }
     // all-gather-v: my part to every peer, every peer's part to its offset (device to device over xGMI)
-    int grc = r->GroupStart();
+    int grc = xGroupStart(d);
     u64 off = 0;
     for (int p = 0; p < P && grc == ncclSuccess; p++) {
         const u64 n = d->h_cnt[p];
         if (p != d->rank) {
-            if (mine) grc = r->Send(d_keys + my_off * W, (size_t)mine * W, ncclUint64, p, d->comm, ctx->stream);
-            if (mine && grc == ncclSuccess) grc = r->Send(d_cnt + my_off, (size_t)mine * 4, ncclUint8, p, d->comm, ctx->stream);
-            if (n && grc == ncclSuccess) grc = r->Recv(d_keys + off * W, (size_t)n * W, ncclUint64, p, d->comm, ctx->stream);
-            if (n && grc == ncclSuccess) grc = r->Recv(d_cnt + off, (size_t)n * 4, ncclUint8, p, d->comm, ctx->stream);
+            if (mine) grc = xSend(d, d_keys + my_off * W, (size_t)mine * W, ncclUint64, p, ctx->stream);
+            if (mine && grc == ncclSuccess) grc = xSend(d, d_cnt + my_off, (size_t)mine * 4, ncclUint8, p, ctx->stream);
+            if (n && grc == ncclSuccess) grc = xRecv(d, d_keys + off * W, (size_t)n * W, ncclUint64, p, ctx->stream);
+            if (n && grc == ncclSuccess) grc = xRecv(d, d_cnt + off, (size_t)n * 4, ncclUint8, p, ctx->stream);
         }
         off += n;
     }
-    if (grc == ncclSuccess) grc = r->GroupEnd();
-    if (grc != ncclSuccess) return done(fail(ctx, GK_E_COMM, std::string("gk_dist_gather_map: ") + (r->GetErrorString ? r->GetErrorString(grc) : "RCCL error")));
+    if (grc == ncclSuccess) grc = xGroupEnd(d);
+    if (grc != ncclSuccess) return done(fail(ctx, GK_E_COMM, std::string("gk_dist_gather_map: ") + comm_error_text(grc)));
     // one table holding every partition's keys (each key has exactly one owner: nothing merges)
     gk_map *m = nullptr;
     if (int rc = gk_map_create(ctx, local->k, total, &m)) return done(rc);

@@ -24,11 +24,13 @@ def unique_id() -> bytes:
 class HipDist:
     """One rank of the communicator (gk_dist_create is collective: every rank calls it with the same id)."""
 
-    def __init__(self, ctx: Context, rank: int, world: int, id128: bytes):
+    def __init__(self, ctx: Context, rank: int, world: int, id128: bytes, loopback: bool = False):
+        """loopback: the test transport (gk_dist_create_loopback) — the ranks are threads of this process on one device."""
         assert len(id128) == 128
         self.ctx, self.rank, self.world = ctx, rank, world
         self.h = L.vp()
-        L.check(L.lib().gk_dist_create(ctx.h, rank, world, C.create_string_buffer(id128, 128), C.byref(self.h)), ctx.h)
+        create = L.lib().gk_dist_create_loopback if loopback else L.lib().gk_dist_create
+        L.check(create(ctx.h, rank, world, C.create_string_buffer(id128, 128), C.byref(self.h)), ctx.h)
 
     def close(self):
         if self.h:

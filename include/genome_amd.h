@@ -240,6 +240,12 @@ int gk_vmap_export(gk_vmap *m, uint64_t *lo, uint64_t *hi, uint64_t *values, uin
  * All gk_dist_* calls that move data are COLLECTIVE: every rank of the communicator must make them, in the same order. */
 int gk_dist_unique_id(void *id128);                                   /* out: 128 bytes */
 int gk_dist_create(gk_ctx *ctx, int rank, int world, const void *id128, gk_dist **out);
+/* TEST transport: the ranks are threads of ONE process on ONE device; sends, receives and reductions go through a hub in the
+ * library (device-to-device copies matched pairwise in posting order) instead of RCCL, which refuses two ranks on one GPU.  Every
+ * rank passes the same 128 id bytes (any) and its own context; calls block until the peers have posted the matching operation
+ * (an inconsistent order of operations across ranks deadlocks at once; a send and its receive that differ in size are GK_E_COMM).
+ * Everything else about the handle is the product code path. */
+int gk_dist_create_loopback(gk_ctx *ctx, int rank, int world, const void *id128, gk_dist **out);
 void gk_dist_destroy(gk_dist *d);
 int gk_dist_rank(const gk_dist *d);
 int gk_dist_world(const gk_dist *d);

@@ -1,8 +1,11 @@
 """gk_dist_*: PartitionedDNAMap over RCCL behind the C-ABI (-m gpu).  The 1-GPU box can only form a communicator of ONE
 rank: route -> counts exchange -> record exchange (ncclSend/Recv to self) -> owner count -> all-reduce -> all-gather all run
-through RCCL, with every record going to rank 0.  N > 1 placement logic is covered by the logical-partition tests
-(test_table_gpu.py, test_configs_gpu.py) and the 2-rank gloo tests (test_exchange_cpu.py); N > 1 over RCCL is measured
-only by the driver's 8-GPU run."""
+through RCCL, with every record going to rank 0.  world = 2 and 3 run over the library's loopback transport (ranks as
+threads of this process, gk_dist_create_loopback): everything above the transport is the product code.  N > 1 placement logic
+is also covered by the logical-partition tests (test_table_gpu.py, test_configs_gpu.py) and the 2-rank gloo tests
+(test_exchange_cpu.py); N > 1 over RCCL is measured only by the driver's 8-GPU run."""
+import random
+
 import numpy as np
 import pytest
 
@@ -108,3 +111,65 @@ def test_streaming_route_begin_count_routed(dist, k, L_, depth):
     assert pm.local.verify()[1] == 0
     ctx.set_option("dist_exchange_ahead", -1)
     pm.close(); ctx.free(d)
+
+
+@pytest.mark.parametrize("world,k,L_", [(2, 31, 150), (3, 47, 120)])
+def test_several_ranks_over_the_loopback_transport(world, k, L_):
+    """gk_dist_* with world > 1 on the one-GPU box: RCCL refuses two ranks on one device, so the ranks are THREADS of this
+    process, each with its own context, handle and partition, talking through the library's loopback transport (device-to-
+    device copies matched pairwise in posting order; a group's end blocks until the peers have posted theirs, so an inconsistent
+    order of operations across ranks would deadlock here, and a send whose size differs from its receive is an error).  Each
+    rank streams its own reads three batches deep (the exchange of batch i+1 on the helper thread beside the count of batch i),
+    with a size query in the middle.  Then: windows sent == windows counted by their owners == all windows, the partitions'
+    sizes add up to the oracle's table, every stored key is at its owner, and the table gathered on EVERY rank is the
+    oracle's, bit for bit."""
+    import threading
+    n, nb = 30000, 5
+    rec = synth.reads_mode_g(n * world, L_, 50000 * world, 0.01, config_id=700 + k)
+    stride = rec.shape[1]
+    ref = O.PMap(k, 1)
+    occ = ref.count_reads(rec.tobytes(), n * world)
+    want = ref.export_sorted()
+    id128 = bytes(random.Random(world * 1000 + k).getrandbits(8) for _ in range(128))
+    out, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            c = Context(0)
+            hd = HipDist(c, rank, world, id128, loopback=True)
+            pm = DistDNAMap(hd, k, 1 << 10)
+            d = c.alloc(n * stride + 64)
+            c.upload(d, rec[rank * n:(rank + 1) * n])
+            per = n // nb
+            begun = sent = owned = 0
+            for i in range(nb):
+                while begun < min(i + 3, nb):
+                    pm.route_begin(d + begun * per * stride, per, L_)
+                    begun += 1
+                s_, o_ = pm.count_routed()
+                sent += s_; owned += o_
+                if i == 2:
+                    assert pm.size() <= len(want[0])
+            tot = hd.allreduce([float(sent), float(owned)], "sum")
+            size = pm.size()
+            assert pm.local.verify()[1] == 0
+            full = pm.gathered()
+            out[rank] = (tot.tolist(), size, pm.local.size(), full.sorted_items())
+            hd.barrier()
+            full.close(); pm.close(); c.free(d); hd.close(); c.close()
+        except BaseException as e:          # noqa: BLE001 — reported by the main thread
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=240)
+    assert not any(t.is_alive() for t in threads), "a rank is stuck: the ranks issued their operations in different orders"
+    assert not errors, errors
+    assert sum(o[2] for o in out) == len(want[0])
+    for tot, size, _local, items in out:
+        assert tot == [float(occ), float(occ)]
+        assert size == len(want[0])
+        for a, b in zip(items, want):
+            assert np.array_equal(a, b)
