@@ -113,7 +113,7 @@ def test_streaming_route_begin_count_routed(dist, k, L_, depth):
     pm.close(); ctx.free(d)
 
 
-@pytest.mark.parametrize("world,k,L_", [(2, 31, 150), (3, 47, 120)])
+@pytest.mark.parametrize("world,k,L_", [(2, 31, 150), (3, 47, 120), (8, 31, 100)])
 def test_several_ranks_over_the_loopback_transport(world, k, L_):
     """gk_dist_* with world > 1 on the one-GPU box: RCCL refuses two ranks on one device, so the ranks are THREADS of this
     process, each with its own context, handle and partition, talking through the library's loopback transport (device-to-
