@@ -143,7 +143,7 @@ __global__ __launch_bounds__(BLOCK) void k_skm_route(const uint8_t *__restrict__
                 // window minimum over w = k-m+1 scores.  A plain loop is w dependent LDS round trips per
                 // block (the reads are not batched: 90 % of the kernel by the phase timers); instead the
                 // minimum of every 8 consecutive scores is parked once per position, and a window takes the
-                // min of at most 7 of those (clamped offsets repeat harmlessly), all reads issued together.
+                // min of ceil(w / 8) of those (the last one clamped to the window's end), all reads issued together.
                 const u32 *mins = strip;
                 if (w >= 8) {
                     u32 *m8 = strip2;
@@ -159,13 +159,15 @@ __global__ __launch_bounds__(BLOCK) void k_skm_route(const uint8_t *__restrict__
                 }
                 GK_TICK(6);
                 const int step = w >= 8 ? 8 : 1, last = w >= 8 ? w - 8 : w - 1;
+                const int nterms = w >= 8 ? (w + 7) / 8 : w;         // 3 for k = 31 (w = 21): offsets 0, 8, 13; 7 at most (k = 63, or w = 7)
                 for (int pb = 0; pb < nk; pb += 64) {
                     const int p = pb + lane;
                     const bool valid = p < nk;
                     u32 best = 0xffffffffu;
                     if (valid) {
 #pragma unroll
-                        for (int j = 0; j < 7; j++) best = min(best, mins[p + min(j * step, last)]);
+                        for (int j = 0; j < 7; j++)
+                            if (j < nterms) best = min(best, mins[p + min(j * step, last)]);
                     }
                     const int o = (int)(((u64)hash32(best ^ 0x5bd1e995u) * (u64)P) >> 32);      // == gk::owner_of
                     const int prev = __shfl_up(o, 1);
