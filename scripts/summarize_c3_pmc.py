@@ -22,7 +22,7 @@ for r in csv.DictReader(open(f)):
     stats[r["Name"].replace("void ", "").split("(")[0]] = (int(r["Calls"]), float(r["TotalDurationNs"]) / 1e6)
 fetch, write, req = counters("fetch"), counters("write"), counters("req")
 try:
-    rdsz = counters("rdsz")          # optional fourth pass: TCC_EA0_RDREQ_{32B,64B,128B}_sum (scripts/gpu_run33.sh)
+    rdsz = counters("rdsz")          # optional fourth pass: TCC_EA0_RDREQ_{32B,64B,128B}_sum (scripts/runs/gpu_run33.sh)
 except ValueError:
     rdsz = {}
 occ, distinct, good = res["occurrences"], res["distinct_in_table"], res["good_kmers"]
