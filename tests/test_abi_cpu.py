@@ -25,6 +25,16 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
 
 
+def test_integration_md_accounts_for_every_declared_symbol():
+    """INTEGRATION.md shows the reference-side binding of the path's entry points (its JNI layer, §2-§4) and lists the rest with
+    the reason they are not bound (§7): together they must cover the header."""
+    hdr = open(os.path.join(ROOT, "include", "genome_amd.h")).read()
+    declared = set(re.findall(r"\b(gk_[a-z0-9_]+)\s*\(", hdr))
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = sorted(s for s in declared if s not in text)
+    assert not missing, missing
+
+
 def test_no_cpu_fallback_without_device(gpu_available):
     if gpu_available:
         pytest.skip("a GPU is present")
