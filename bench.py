@@ -396,14 +396,25 @@ def main():
                          "traffic_source": (os.path.relpath(pmc_file, ROOT) if traffic else None)},
         }
         # the same figures against what THIS card streams, measured in this run (after the timed region)
-        sb = ctx.stream_bench(1 << 30, 10)
+        # (the objects measured NEXT to the headline must never cost the line itself: one that fails is reported in place)
+        def extra(name, fn):
+            try:
+                return fn()
+            except Exception as e:          # noqa: BLE001
+                print(f"bench.py: {name} failed: {e!r}", file=sys.stderr)
+                return {"error": repr(e)}
+
         rl = out["roofline"]
-        rl["measured_stream"] = dict(sb, what="gk_dev_stream_bench: 16-byte copy / fill / sum kernels over 1 GiB buffers, GB/s "
-                                             "(copy counts bytes read + written)")
-        rl["frac_of_measured_copy"] = achieved / sb["copy_GBps"] if sb["copy_GBps"] else None
-        if traffic:
-            rl["traffic_GBps"] = traffic / (avg_kernel_ms * 1e-3) / 1e9
-            rl["traffic_over_measured_copy"] = rl["traffic_GBps"] / sb["copy_GBps"] if sb["copy_GBps"] else None
+        sb = extra("measured_stream", lambda: ctx.stream_bench(1 << 30, 10))
+        if "error" in sb:
+            rl["measured_stream"] = sb
+        else:
+            rl["measured_stream"] = dict(sb, what="gk_dev_stream_bench: 16-byte copy / fill / sum kernels over 1 GiB buffers, GB/s "
+                                                 "(copy counts bytes read + written)")
+            rl["frac_of_measured_copy"] = achieved / sb["copy_GBps"] if sb["copy_GBps"] else None
+            if traffic:
+                rl["traffic_GBps"] = traffic / (avg_kernel_ms * 1e-3) / 1e9
+                rl["traffic_over_measured_copy"] = rl["traffic_GBps"] / sb["copy_GBps"] if sb["copy_GBps"] else None
         if sharded and dist_ms:
             out["per_rank_step_ms"] = {k_: float(np.mean([x[k_] for x in dist_ms])) for k_ in dist_ms[0]}
             out["per_rank_step_ms"]["what"] = ("rank 0, wall ms inside gk_dist_count_routed: route_wait = waiting for the routing kernel (reads -> super-k-mer records "
@@ -412,24 +423,35 @@ def main():
                                                "the pipeline over what arrived (stream-ordered behind the receives)")
         default_workload = args.mode == "U" and n == 1_000_000 and L == 150 and k == 31
         if world == 1 and not sharded and not args.no_extras and default_workload:
-            recg = ctx.alloc(n * stride + 64)
-            ctx.synth_reads(recg, n, L, "G", 2, 0, 5_000_000, 0.01)
-            out["mode_G"] = c2_variant(ctx, recg, n, L, k, "G", 5, 2)
-            out["mode_G"]["workload"] = "C2 mode G: 5 Mbp genome, 30x, 1 % error (SURVEY.md §8d) — the same reads count, with repeats"
-            ctx.free(recg)
-            hb[:] = ctx.download(rec, n * stride)
-            out["pcie_inclusive"] = c2_variant(ctx, None, n, L, k, "U", 10, 2, host_buf=hb)
-            out["pcie_inclusive"]["host_buffer_pages_per_numa_node"] = numa_of(hb.ctypes.data)
-            out["pcie_inclusive"]["gpu_numa_nodes_sysfs"] = gpu_numa_node()
-            out["pcie_inclusive"]["workload"] = ("SURVEY.md §8(d) reading of the metric: the headline's reads as a `.bin` stream in PINNED HOST memory -> complete "
-                                                 "table in HBM (gk_map_count_reads; host framing walk + PCIe upload in sub-chunks overlapped with the L1 scatter)")
-            ctx.host_free(hb)
+            def mode_g():
+                recg = ctx.alloc(n * stride + 64)
+                ctx.synth_reads(recg, n, L, "G", 2, 0, 5_000_000, 0.01)
+                o = c2_variant(ctx, recg, n, L, k, "G", 5, 2)
+                o["workload"] = "C2 mode G: 5 Mbp genome, 30x, 1 % error (SURVEY.md §8d) — the same reads count, with repeats"
+                ctx.free(recg)
+                return o
+
+            def pcie():
+                hb[:] = ctx.download(rec, n * stride)
+                o = c2_variant(ctx, None, n, L, k, "U", 10, 2, host_buf=hb)
+                o["host_buffer_pages_per_numa_node"] = numa_of(hb.ctypes.data)
+                o["gpu_numa_nodes_sysfs"] = gpu_numa_node()
+                o["workload"] = ("SURVEY.md §8(d) reading of the metric: the headline's reads as a `.bin` stream in PINNED HOST memory -> complete "
+                                 "table in HBM (gk_map_count_reads; host framing walk + PCIe upload in sub-chunks overlapped with the L1 scatter)")
+                ctx.host_free(hb)
+                return o
+
+            out["mode_G"] = extra("mode_G", mode_g)
+            out["pcie_inclusive"] = extra("pcie_inclusive", pcie)
             if not args.no_c3:
-                out["c3"] = c3_object(ctx)
+                out["c3"] = extra("c3", lambda: c3_object(ctx))
         if not args.no_cpu_baseline and world == 1 and not sharded:
-            sample_reads = min(n, 400_000)
-            host = ctx.download(rec, sample_reads * stride).reshape(sample_reads, stride)
-            out["cpu_baseline"] = cpu_baseline(host, sample_reads, k)
+            def cpu():
+                sample_reads = min(n, 400_000)
+                host = ctx.download(rec, sample_reads * stride).reshape(sample_reads, stride)
+                return cpu_baseline(host, sample_reads, k)
+
+            out["cpu_baseline"] = extra("cpu_baseline", cpu)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
         sys.stdout.flush()
