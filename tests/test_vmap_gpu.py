@@ -231,3 +231,46 @@ def test_add_node_replace_start_end_vs_oracle(ctx, k, seed):
     with pytest.raises(L.GkError):
         g.addNode("T" * (k + 1))
     g.close(); m.close()
+
+
+@pytest.mark.parametrize("k", [21, 31, 47])
+def test_checkgraph_invariant_every_kmer_of_the_genome_is_in_the_graph_map(ctx, k):
+    """The reference's own validation script (S/scripts/CheckGraph.scala:48-55): every k-window of the genome the reads came
+    from must be found in Graph.getGraphMap (`graphMap.contains(read)`), and its contig statistics (:37-41: edges longer than a
+    cutoff, their count, summed length, median, maximum).  A 60 kbp genome with two repeated 300-base stretches, error-free
+    150-base mates tiled every 25 bases on both strands (every k-mer covered), count -> buildGraph -> getGraphMap: all
+    genome k-mers found (both strands — the graph holds a node per strand), k-mers of a sequence that is not in the genome
+    are not, and the contig statistics equal the oracle's."""
+    rnd = random.Random(5 + k)
+    G = 60000
+    g = [rnd.choice("AGCT") for _ in range(G)]
+    for _ in range(2):
+        a, b = rnd.randrange(1000, G // 2 - 1000), rnd.randrange(G // 2 + 1000, G - 1000)
+        g[b:b + 300] = g[a:a + 300]
+    g = "".join(g)
+    reads = []
+    for s in range(0, G - 150 + 1, 25):
+        frag = g[s:s + 150]
+        reads += [frag, R.rev_comp(frag)]
+    reads += [g[G - 150:], R.rev_comp(g[G - 150:])]
+    binb = dna.reads_to_bin(reads)
+    m, ref = HipDNAMap(ctx, k), O.PMap(k, 1)
+    m.count_reads(binb, len(reads)); ref.count_reads(binb, len(reads))
+    graph, og = buildGraph(k, m), O.Graph(ref)
+    vm = graph.getGraphMap()
+    windows = [g[i:i + k] for i in range(G - k + 1)]
+    for chunk in (windows, [R.rev_comp(w) for w in windows[::7]]):
+        _, found = vm.apply_batch(chunk)
+        assert found.all(), f"{(~found).sum()} genome k-mers are not in the graph map"
+    alien = "".join(rnd.choice("AGCT") for _ in range(3000))
+    in_genome = set(windows) | {R.rev_comp(w) for w in windows}
+    aw = [alien[i:i + k] for i in range(len(alien) - k + 1)]
+    _, found = vm.apply_batch(aw)
+    assert [bool(f) for f in found] == [w in in_genome for w in aw]
+    # :37-41 contigs = edge sequences longer than the cutoff (200 there; 100 here so that the small graph has some)
+    lens = sorted(len(e[2]) for e in graph.canonical()[1] if len(e[2]) > 100)
+    oe = og.edges()
+    olens = sorted(int(x) for x in oe["len"] if int(x) > 100)
+    assert lens == olens and len(lens) > 0
+    assert (len(lens), sum(lens), lens[len(lens) // 2], lens[-1]) == (len(olens), sum(olens), olens[len(olens) // 2], olens[-1])
+    vm.close(); graph.close(); m.close()
