@@ -65,7 +65,12 @@ static constexpr int PTILE_WORDS = PTILE_READS * 65 / 4 + 64;
 static constexpr int TILE2 = PBLOCK * KEYS_PER_THREAD;   // keys per chunk in P3/P4
 static constexpr u32 MAXB1 = 1u << MAX_LNB1;      // L1 buckets at most (256 for every table up to 34 GB, see plan_segments)
 static constexpr u32 MAX_NB2 = 4096;        // LDS bound in P3/P4 (16 B per fine bucket on top of the sorted chunk)
-static constexpr u32 MAX_RANGE_CHUNKS = 16; // a range = up to 16 consecutive chunks of one L1 bucket (64 Ki keys)
+#ifndef GK_MAX_RANGE_CHUNKS
+#define GK_MAX_RANGE_CHUNKS 24
+#endif
+// a range = up to 24 consecutive chunks of one L1 bucket (96 Ki keys = 8 sorts of 12288 keys, 12 of 8192: no partial sort at a
+// range's end; measured at C3, P4: 16 chunks 41.7-44.9 ms, 24: 38.5-40.0, 48: 38.9-41.9, 96: 38.5)
+static constexpr u32 MAX_RANGE_CHUNKS = GK_MAX_RANGE_CHUNKS;
 
 // The distinct-key SAMPLE: a key belongs to it iff bits 11..20 of its slot hash are zero (1 key in 1024, independent
 // of the bits that pick its segment and its start slot); the set stores the 64-bit slot hash itself (a bijection of
@@ -292,11 +297,11 @@ __global__ __launch_bounds__(BLOCK) void k_part_hist1_keys(const u64 *__restrict
 // NEXT chunk before it sorts the current one, so the round trip hides behind a chunk's worth of LDS work.
 // lbase (LEVEL 2, exact L1 level only): l1_base[b1], handed in by the caller from its LDS copy — a global load of it here
 // would put a full vmcnt(0) wait, i.e. a wait for the previous chunk's stores, in front of the prefetch.
-template <int W, int LEVEL, int NT>
-__device__ __forceinline__ void load_chunk(Kmer<W> (&key)[KEYS_PER_THREAD], const u64 *__restrict__ in, const PartArrays &a, u32 b1, u64 lbase,
+template <int W, int LEVEL, int NT, int KPT>
+__device__ __forceinline__ void load_chunk(Kmer<W> (&key)[KPT], const u64 *__restrict__ in, const PartArrays &a, u32 b1, u64 lbase,
                                            u64 begin, u32 cnt) {
 #pragma unroll
-    for (int j = 0; j < KEYS_PER_THREAD; j++) {
+    for (int j = 0; j < KPT; j++) {
         const u32 i = threadIdx.x + j * NT;
         const u64 src = begin + (i < cnt ? i : cnt - 1);
         key[j] = load_key<W>(in, LEVEL == 2 ? (a.op1 ? l1_slot(a, b1, src) : lbase + src) : src);
@@ -310,18 +315,18 @@ __device__ __forceinline__ void load_chunk(Kmer<W> (&key)[KEYS_PER_THREAD], cons
 struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
 static constexpr bool is_prefetching(const NoPrefetch &) { return false; }
 template <class F> static constexpr bool is_prefetching(const F &) { return true; }
-template <int W, int LEVEL, bool RANGED, int NT, class Prefetch = NoPrefetch>
-__device__ __forceinline__ void scatter_chunk(const Kmer<W> (&key)[KEYS_PER_THREAD], u32 cnt, const Table<W> &t, u32 nbins,
+template <int W, int LEVEL, bool RANGED, int NT, class Prefetch = NoPrefetch, int KPT = KEYS_PER_THREAD>
+__device__ __forceinline__ void scatter_chunk(const Kmer<W> (&key)[KPT], u32 cnt, const Table<W> &t, u32 nbins,
                                               u64 *sorted, uint16_t *binof, u32 *off, u32 *lim, unsigned long long *gb, u32 *wsum,
                                               const PartArrays &a, u64 bin0, u64 *__restrict__ out, const Sampler &sp, u32 &claims,
                                               GK_TARGS_DECL, Prefetch prefetch = Prefetch()) {
-    u32 bin[KEYS_PER_THREAD], rank[KEYS_PER_THREAD];
+    u32 bin[KPT], rank[KPT];
     prefetch();
     for (u32 b = threadIdx.x; b < nbins; b += NT) off[b] = 0;
     __syncthreads();
     GK_TICK(0);
 #pragma unroll
-    for (int j = 0; j < KEYS_PER_THREAD; j++) {
+    for (int j = 0; j < KPT; j++) {
         const u32 i = threadIdx.x + j * NT;
         bin[j] = 0xffffffffu;
         if (i < cnt) {
@@ -358,7 +363,7 @@ __device__ __forceinline__ void scatter_chunk(const Kmer<W> (&key)[KEYS_PER_THRE
     block_scan_inplace<NT>(off, nbins, wsum);                      // counts -> offsets in the sorted chunk
     GK_TICK(4);
 #pragma unroll
-    for (int j = 0; j < KEYS_PER_THREAD; j++)
+    for (int j = 0; j < KPT; j++)
         if (bin[j] != 0xffffffffu) {
             const u32 pos = off[bin[j]] + rank[j];
             store_key<W>(sorted, pos, key[j]);
@@ -383,8 +388,8 @@ __device__ __forceinline__ void scatter_chunk(const Kmer<W> (&key)[KEYS_PER_THRE
 }
 
 // dynamic LDS carve for scatter_chunk
-template <int W, int NT = PBLOCK> struct ScatterLds {
-    static constexpr int TILE = NT * KEYS_PER_THREAD;
+template <int W, int NT = PBLOCK, int KPT = KEYS_PER_THREAD> struct ScatterLds {
+    static constexpr int TILE = NT * KPT;
     u64 *sorted; uint16_t *binof; u32 *off, *lim; unsigned long long *gb; u32 *wsum;
     __device__ __forceinline__ ScatterLds(unsigned long long *base, u32 nbins) {
         gb = base;                                                       // [nbins] u64
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(PBLOCK) void k_part_scatter1_keys(const u64 *__rest
         const u64 begin = c * TILE2;
         const u32 cnt = (u32)min((u64)TILE2, n - begin);
         Kmer<W> key[KEYS_PER_THREAD];
-        load_chunk<W, 1, PBLOCK>(key, keys, a, 0u, 0ull, begin, cnt);
+        load_chunk<W, 1, PBLOCK, KEYS_PER_THREAD>(key, keys, a, 0u, 0ull, begin, cnt);
         scatter_chunk<W, 1, false, PBLOCK>(key, cnt, t, nb1, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a, 0, out, sp, claims, GK_TARGS);
     }
     if (sp.set) block_add_global(claims, &L.off[0], sp.claims);
@@ -769,17 +774,18 @@ __global__ __launch_bounds__(256) void k_part_prefix2(PartArrays a, u32 nb1, u32
 // ---------------------------------------------------------------------------------------------
 // [b_lo, b_hi): the L1 buckets this launch covers (over-provisioned fine level only: a stripe of the batch, so that P5 of one
 // stripe can run beside P4 of the next; the exact fine level always covers all of them)
-template <int W, bool RANGED, int NT>
+// KPT: keys per thread and sort (8; 12 with 1024 threads for the exact fine level over MANY fine buckets: runs half again as long)
+template <int W, bool RANGED, int NT, int KPT = KEYS_PER_THREAD>
 __global__ __launch_bounds__(NT) void k_part_scatter2(const u64 *__restrict__ bufA, Table<W> t, PartArrays a, u64 max_units,
                                                           u64 *__restrict__ bufB, u32 b_lo, u32 b_hi) {
     extern __shared__ unsigned long long lds_dyn[];
-    constexpr u32 TILE = NT * KEYS_PER_THREAD;          // keys this workgroup sorts at a time (ranges and the chunk table stay in TILE2 units)
+    constexpr u32 TILE = NT * KPT;          // keys this workgroup sorts at a time (ranges and the chunk table stay in TILE2 units)
     // chunk / range table and L1 bucket extents: LDS copies (the binary search below was eight dependent global
     // loads per chunk: 16 % of the kernel by the phase timers); in the dynamic area, sized by the table's L1 bucket count
     // (part_tables_bytes), in front of the sort buffers
     const u32 nb1 = 1u << t.lnb1;
     unsigned long long *s_ubase = lds_dyn, *s_l1n = s_ubase + nb1 + 1, *s_l1b = s_l1n + nb1, *s_l1f = s_l1b + nb1;
-    ScatterLds<W, NT> L(s_l1f + nb1, t.nb2);
+    ScatterLds<W, NT, KPT> L(s_l1f + nb1, t.nb2);
     for (u32 b = threadIdx.x; b <= nb1; b += NT) s_ubase[b] = RANGED ? a.rbase[b] : a.cbase[b];
     for (u32 b = threadIdx.x; b < nb1; b += NT) {
         const bool slice = !RANGED && a.l1_to != nullptr;              // (a slice of every region: pipelined pieces)
@@ -808,9 +814,9 @@ __global__ __launch_bounds__(NT) void k_part_scatter2(const u64 *__restrict__ bu
             const u32 *row = a.rmat + r * t.nb2;
             for (u32 b = threadIdx.x; b < t.nb2; b += NT) L.gb[b] = a.fine_base[bin0 + b] + row[b];
             for (u32 cb = 0; cb < g.cnt; cb += TILE) {          // (scatter_chunk opens with a barrier: gb[] is visible)
-                Kmer<W> key[KEYS_PER_THREAD];
-                load_chunk<W, 2, NT>(key, bufA, a, g.b1, s_l1b[g.b1], g.begin + cb, min(TILE, g.cnt - cb));
-                scatter_chunk<W, 2, true, NT>(key, min(TILE, g.cnt - cb), t, t.nb2, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a, bin0, bufB,
+                Kmer<W> key[KPT];
+                load_chunk<W, 2, NT, KPT>(key, bufA, a, g.b1, s_l1b[g.b1], g.begin + cb, min(TILE, g.cnt - cb));
+                scatter_chunk<W, 2, true, NT, NoPrefetch, KPT>(key, min(TILE, g.cnt - cb), t, t.nb2, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a, bin0, bufB,
                                               nosp, noclaims, GK_TARGS);
             }
             __syncthreads();
@@ -827,17 +833,17 @@ __global__ __launch_bounds__(NT) void k_part_scatter2(const u64 *__restrict__ bu
             }
             return p;
         };
-        auto request = [&](Kmer<W> (&kk)[KEYS_PER_THREAD], const Pos &p) {
-            if (p.c < total) load_chunk<W, 2, NT>(kk, bufA, a, p.b1, s_l1b[p.b1], p.begin, p.cnt);
+        auto request = [&](Kmer<W> (&kk)[KPT], const Pos &p) {
+            if (p.c < total) load_chunk<W, 2, NT, KPT>(kk, bufA, a, p.b1, s_l1b[p.b1], p.begin, p.cnt);
         };
         Pos cur = geom(first + blockIdx.x);
-        auto step = [&](Kmer<W> (&kc)[KEYS_PER_THREAD], Kmer<W> (&kn)[KEYS_PER_THREAD]) {
+        auto step = [&](Kmer<W> (&kc)[KPT], Kmer<W> (&kn)[KPT]) {
             const Pos nxt = geom(cur.c + gridDim.x);
             scatter_chunk<W, 2, false, NT>(kc, cur.cnt, t, t.nb2, L.sorted, L.binof, L.off, L.lim, L.gb, L.wsum, a, (u64)cur.b1 * t.nb2, bufB,
                                            nosp, noclaims, GK_TARGS, [&]() { request(kn, nxt); });
             cur = nxt;
         };
-        Kmer<W> keyA[KEYS_PER_THREAD], keyB[KEYS_PER_THREAD];
+        Kmer<W> keyA[KPT], keyB[KPT];
         request(keyA, cur);
         __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0), once: both halves of the loop then know their keys are in
         while (cur.c < total) {
@@ -1288,6 +1294,7 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
             const int wide_max = (int)std::min(ScatterLds<1, 1024>::bytes(MAX_NB2) + part_tables_bytes(MAXB1), LDS_BYTES_PER_CU);
             GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<1, true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, wide_max));
             GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<1, false, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, wide_max));
+            GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<1, true, 1024, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES_PER_CU));
         }
         GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter1_keys<W>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)ScatterLds<W>::bytes(MAXB1)));
@@ -1562,7 +1569,11 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
             if constexpr (W == 1) {
                 const size_t wide_lds = ScatterLds<1, 1024>::bytes(m->nb2) + part_tables_bytes(nb1);
                 const int gw = (int)std::min<u64>(max_ranges, (u64)ctx->cu_count * 2);
-                hipLaunchKernelGGL((k_part_scatter2<1, true, 1024>), dim3(gw), dim3(1024), wide_lds, ctx->stream, ps->bufA, t, a, max_ranges, ps->bufB, 0u, nb1);
+                // from ~1000 fine buckets up a 12288-key sort where it still fits the LDS (runs half again as long: "p4_wide" = 2 forces it)
+                const size_t xl_lds = ScatterLds<1, 1024, 12>::bytes(m->nb2) + part_tables_bytes(nb1);
+                const bool xl = xl_lds <= LDS_BYTES_PER_CU && (ctx->hook_p4_wide >= 0 ? ctx->hook_p4_wide == 2 : m->nb2 >= 1024);
+                if (xl) hipLaunchKernelGGL((k_part_scatter2<1, true, 1024, 12>), dim3(gw), dim3(1024), xl_lds, ctx->stream, ps->bufA, t, a, max_ranges, ps->bufB, 0u, nb1);
+                else hipLaunchKernelGGL((k_part_scatter2<1, true, 1024>), dim3(gw), dim3(1024), wide_lds, ctx->stream, ps->bufA, t, a, max_ranges, ps->bufB, 0u, nb1);
             }
         } else
             hipLaunchKernelGGL((k_part_scatter2<W, true, PBLOCK>), dim3(gr), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2) + part_tables_bytes(nb1), ctx->stream, ps->bufA, t, a,

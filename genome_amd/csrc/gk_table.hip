@@ -639,7 +639,7 @@ int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "p4_direct") ctx->hook_p4_direct = value < 0 ? -1 : value != 0;
     else if (n == "p2_wide") ctx->hook_p2_wide = value < 0 ? -1 : value != 0;
     else if (n == "p2_sorted") ctx->hook_p2_sorted = value < 0 ? -1 : value != 0;
-    else if (n == "p4_wide") ctx->hook_p4_wide = value < 0 ? -1 : value != 0;
+    else if (n == "p4_wide") ctx->hook_p4_wide = value < 0 ? -1 : (value >= 2 ? 2 : value != 0);
     else if (n == "p45_stripes") ctx->hook_p45_stripes = (int)value;
     else if (n == "p24_pieces") ctx->hook_p24_pieces = (int)value;
     else if (n == "dist_exchange_ahead") ctx->hook_dist_ahead = (int)value;
