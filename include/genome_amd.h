@@ -71,7 +71,7 @@ int gk_ctx_trim(gk_ctx *ctx);
  * consults the environment afterwards.  Names: "test_no_reserve", "host_ragged", "part_exact" (0/1),
  * "graph_unitigs" (0 auto, 1 walk, 2 pointer jumping), "graph_walk_queue" (0: one edge per lane), "graph_load_pct" (load factor
  * of the compacted table, percent), "graph_mem" (1 uncached / 2 fine-grained memory for it), "graph_aligned" (1: probes start at
- * the first slot of a 128-byte line), "p4_direct" / "fine_exact" / "p4_wide" / "p2_wide" / "p2_sorted" (-1 auto, 0, 1),
+ * the first slot of a 128-byte line), "p4_direct" / "fine_exact" / "p2_wide" / "p2_sorted" (-1 auto, 0, 1), "p4_wide" (-1 auto, 0: 4096-key sorts, 1: 8192, 2: 12288),
  * "p45_stripes" (P5 of one stripe of L1 buckets beside P4 of the next), "p24_pieces" (P4 of one piece of a batch beside the L1
  * scatter of the next), "p4_grid" (P4 workgroups per CU), "filter_classic" (1: tombstones + rehash instead of the streaming
  * rebuild), "dist_exchange_ahead" (0: gk_dist_count_routed does not post the next batch's exchange ahead; every rank alike):
