@@ -1295,6 +1295,7 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
             GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<1, true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, wide_max));
             GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<1, false, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, wide_max));
             GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<1, true, 1024, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES_PER_CU));
+            GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<1, false, 1024, 12>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES_PER_CU));
         }
         GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter1_keys<W>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)ScatterLds<W>::bytes(MAXB1)));
@@ -1311,6 +1312,12 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
     // (measured at C2, nb2 = 370: P4 0.66 -> 0.62 ms in mode U, 0.64 -> 0.62 in mode G: half the per-bin bookkeeping per key)
     // (the 8192-key forms need the CU's whole LDS: not with more fine buckets than fit beside the tables of a 512/1024-bucket L1 level)
     auto wide_fits = [&]() { return W == 1 && ScatterLds<1, 1024>::bytes(m->nb2) + part_tables_bytes(nb1) <= LDS_BYTES_PER_CU; };
+    // 12288-key sorts (12 keys per thread) where they fit the LDS: measured at C2, nb2 = 370: P4 0.58 -> 0.52-0.56 ms in mode U, no
+    // change in mode G ("p4_wide" = 1 keeps 8192)
+    auto op_chunk_keys = [&]() -> u32 {
+        const bool xl = W == 1 && ctx->hook_p4_wide != 1 && ScatterLds<1, 1024, 12>::bytes(m->nb2) + part_tables_bytes(nb1) <= LDS_BYTES_PER_CU;
+        return (xl ? 3u : 2u) * (u32)TILE2;
+    };
     auto op_wide_now = [&]() { return wide_fits() && (ctx->hook_p4_wide >= 0 ? ctx->hook_p4_wide != 0 : m->nb2 >= 256); };
     // Over-provisioned segment regions are only safe to try on a table that is being rebuilt from empty (if they and
     // the spill list overflow, the table is simply cleared again); a table that holds data gets the exact fine level
@@ -1329,15 +1336,20 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
     const u64 max_chunks = nkeys_bound / TILE2 + MAXB1 + 1;          // (every L1 bucket may end in a partial chunk)
     if (pipelined) {
         if (int rc = part_prepare_fine(m, ps, nkeys_bound, true, &a)) return rc;
-        if (op_wide_now()) a.chunk_keys = 2 * TILE2;
+        if (op_wide_now()) a.chunk_keys = op_chunk_keys();
     }
     // P4 of the over-provisioned fine level over L1 buckets [b_lo, b_hi) of `aa` (the whole batch, a stripe, or a piece's slices)
     auto launch_p4_op = [&](const PartArrays &aa, hipStream_t st, u32 b_lo, u32 b_hi, u64 share) {
         const int per_cu = ctx->hook_p4_grid > 0 ? ctx->hook_p4_grid : 4;           // ("p4_grid": workgroups per CU, A/B)
         const int gchunks = (int)std::min<u64>(max_chunks / share + 1, (u64)ctx->cu_count * per_cu);
-        if (aa.chunk_keys == 2 * TILE2) {
+        if (aa.chunk_keys >= 2 * TILE2) {
             if constexpr (W == 1) {
                 const size_t wide_lds = ScatterLds<1, 1024>::bytes(m->nb2) + part_tables_bytes(nb1);
+                const size_t xl_lds = ScatterLds<1, 1024, 12>::bytes(m->nb2) + part_tables_bytes(nb1);
+                if (aa.chunk_keys == 3 * TILE2)
+                    hipLaunchKernelGGL((k_part_scatter2<1, false, 1024, 12>), dim3(std::min(gchunks, ctx->cu_count * std::min(per_cu, 2))), dim3(1024), xl_lds, st,
+                                       ps->bufA, t, aa, max_chunks, ps->bufB, b_lo, b_hi);
+                else
                 hipLaunchKernelGGL((k_part_scatter2<1, false, 1024>), dim3(std::min(gchunks, ctx->cu_count * std::min(per_cu, 2))), dim3(1024), wide_lds, st, ps->bufA, t, aa,
                                    max_chunks, ps->bufB, b_lo, b_hi);
             }
@@ -1459,7 +1471,7 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         hipLaunchKernelGGL(k_part_scatter1_keys<W>, dim3(g2), dim3(PBLOCK), ScatterLds<W>::bytes(std::max(256u, nb1)), ctx->stream, d_keys, nkeys_in, t, a, ps->bufA, sp);
     }
     if (!pipelined) {
-        if (op_wide_now()) a.chunk_keys = 2 * TILE2;      // (only the over-provisioned fine level's P4 reads it)
+        if (op_wide_now()) a.chunk_keys = op_chunk_keys();      // (only the over-provisioned fine level's P4 reads it)
         if (op1) hipLaunchKernelGGL(k_part_prefix1, dim3(1), dim3(MAXB1), 0, ctx->stream, a, nb1);     // chunk / range tables from the cursors
     }
     GK_HIP(ctx, hipGetLastError());
