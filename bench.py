@@ -365,9 +365,9 @@ def main():
         avg_kernel_ms = kernel_time_ms
         achieved = abytes / (avg_kernel_ms * 1e-3) / 1e9
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r02", "pmc_pipeline_v13.json") if partitioned else os.path.join(ROOT, "profiles", "r01", "pmc_count_reads_v2.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r02", "pmc_pipeline_v14.json") if partitioned else os.path.join(ROOT, "profiles", "r01", "pmc_count_reads_v2.json")
         if partitioned and not os.path.exists(pmc_file):
-            pmc_file = os.path.join(ROOT, "profiles", "r02", "pmc_pipeline_v12.json")
+            pmc_file = os.path.join(ROOT, "profiles", "r02", "pmc_pipeline_v13.json")
         if partitioned and not os.path.exists(pmc_file):
             pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_pipeline_v8.json")
         if not sharded and args.mode == "U" and n == 1_000_000 and L == 150 and k == 31 and os.path.exists(pmc_file):
