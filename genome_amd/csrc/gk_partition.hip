@@ -984,6 +984,9 @@ __device__ __forceinline__ int lds_add_look(Slot<2> *seg, u32 pos, Kmer<2> key) 
     return -1;
 }
 
+#ifndef GK_P5_GRID_PER_CU
+#define GK_P5_GRID_PER_CU 24          // workgroups of k_seg_insert's persistent grid per CU (four are resident)
+#endif
 #ifndef GK_SBLOCK
 #define GK_SBLOCK (GK_SEG_BITS1 <= 10 ? 256 : 512)
 #endif
@@ -1592,7 +1595,7 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
                                max_ranges, ps->bufB, 0u, nb1);
     }
     auto launch_p5 = [&](hipStream_t st, u64 seg_lo, u64 seg_hi) {
-        const int gseg = (int)std::min<u64>(seg_hi - seg_lo, (u64)ctx->cu_count * 24);
+        const int gseg = (int)std::min<u64>(seg_hi - seg_lo, (u64)ctx->cu_count * GK_P5_GRID_PER_CU);
         hipLaunchKernelGGL(k_seg_insert<W>, dim3(gseg), dim3(SBLOCK), lds, st, t, fine_keys, a, from_empty ? 1 : 0, m->d_ctr, seg_lo, seg_hi);
     };
     // Stripes (over-provisioned fine level): P4 is bound by its LDS sort and leaves half the memory system idle, P5 streams
