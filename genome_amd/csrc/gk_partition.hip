@@ -1293,6 +1293,8 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         const int narrow_max = (int)std::min(ScatterLds<W>::bytes(MAX_NB2) + part_tables_bytes(MAXB1), LDS_BYTES_PER_CU);
         GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<W, false, PBLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, narrow_max));
         GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<W, true, PBLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, narrow_max));
+        if constexpr (W == 2)
+            GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<2, false, 1024, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES_PER_CU));
         if constexpr (W == 1) {
             const int wide_max = (int)std::min(ScatterLds<1, 1024>::bytes(MAX_NB2) + part_tables_bytes(MAXB1), LDS_BYTES_PER_CU);
             GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<1, true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, wide_max));
@@ -1318,10 +1320,16 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
     // 12288-key sorts (12 keys per thread) where they fit the LDS: measured at C2, nb2 = 370: P4 0.58 -> 0.52-0.56 ms in mode U, no
     // change in mode G ("p4_wide" = 1 keeps 8192)
     auto op_chunk_keys = [&]() -> u32 {
-        const bool xl = W == 1 && ctx->hook_p4_wide != 1 && ScatterLds<1, 1024, 12>::bytes(m->nb2) + part_tables_bytes(nb1) <= LDS_BYTES_PER_CU;
+        if (W == 2) return 6144u;                        // 16-byte keys: 1024 threads x 6 keys (96 KB of keys)
+        const bool xl = ctx->hook_p4_wide != 1 && ScatterLds<1, 1024, 12>::bytes(m->nb2) + part_tables_bytes(nb1) <= LDS_BYTES_PER_CU;
         return (xl ? 3u : 2u) * (u32)TILE2;
     };
-    auto op_wide_now = [&]() { return wide_fits() && (ctx->hook_p4_wide >= 0 ? ctx->hook_p4_wide != 0 : m->nb2 >= 256); };
+    auto wide2_fits = [&]() { return W == 2 && ScatterLds<2, 1024, 6>::bytes(m->nb2) + part_tables_bytes(nb1) <= LDS_BYTES_PER_CU; };
+    auto op_wide_now = [&]() {
+        // (16-byte keys, measured at C2 scale: k = 55 P4 0.93 -> 0.85 ms, k = 63 0.86 -> 0.73-0.80; "p4_wide" = 0 keeps 4096-key sorts)
+        if (W == 2) return wide2_fits() && (ctx->hook_p4_wide >= 0 ? ctx->hook_p4_wide != 0 : m->nb2 >= 256);
+        return wide_fits() && (ctx->hook_p4_wide >= 0 ? ctx->hook_p4_wide != 0 : m->nb2 >= 256);
+    };
     // Over-provisioned segment regions are only safe to try on a table that is being rebuilt from empty (if they and
     // the spill list overflow, the table is simply cleared again); a table that holds data gets the exact fine level
     // unless the sample says the batch is near-distinct.
@@ -1345,7 +1353,13 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
     auto launch_p4_op = [&](const PartArrays &aa, hipStream_t st, u32 b_lo, u32 b_hi, u64 share) {
         const int per_cu = ctx->hook_p4_grid > 0 ? ctx->hook_p4_grid : 4;           // ("p4_grid": workgroups per CU, A/B)
         const int gchunks = (int)std::min<u64>(max_chunks / share + 1, (u64)ctx->cu_count * per_cu);
-        if (aa.chunk_keys >= 2 * TILE2) {
+        if (W == 2 && aa.chunk_keys == 6144u) {
+            if constexpr (W == 2) {
+                const size_t lds2 = ScatterLds<2, 1024, 6>::bytes(m->nb2) + part_tables_bytes(nb1);
+                hipLaunchKernelGGL((k_part_scatter2<2, false, 1024, 6>), dim3(std::min(gchunks, ctx->cu_count * std::min(per_cu, 2))), dim3(1024), lds2, st, ps->bufA, t, aa,
+                                   max_chunks, ps->bufB, b_lo, b_hi);
+            }
+        } else if (aa.chunk_keys >= 2 * TILE2) {
             if constexpr (W == 1) {
                 const size_t wide_lds = ScatterLds<1, 1024>::bytes(m->nb2) + part_tables_bytes(nb1);
                 const size_t xl_lds = ScatterLds<1, 1024, 12>::bytes(m->nb2) + part_tables_bytes(nb1);
