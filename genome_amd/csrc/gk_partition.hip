@@ -1293,8 +1293,10 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         const int narrow_max = (int)std::min(ScatterLds<W>::bytes(MAX_NB2) + part_tables_bytes(MAXB1), LDS_BYTES_PER_CU);
         GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<W, false, PBLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, narrow_max));
         GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<W, true, PBLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, narrow_max));
-        if constexpr (W == 2)
+        if constexpr (W == 2) {
             GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<2, false, 1024, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES_PER_CU));
+            GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<2, true, 1024, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES_PER_CU));
+        }
         if constexpr (W == 1) {
             const int wide_max = (int)std::min(ScatterLds<1, 1024>::bytes(MAX_NB2) + part_tables_bytes(MAXB1), LDS_BYTES_PER_CU);
             GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<1, true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, wide_max));
@@ -1603,6 +1605,12 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
                 const bool xl = xl_lds <= LDS_BYTES_PER_CU && (ctx->hook_p4_wide >= 0 ? ctx->hook_p4_wide == 2 : m->nb2 >= 1024);
                 if (xl) hipLaunchKernelGGL((k_part_scatter2<1, true, 1024, 12>), dim3(gw), dim3(1024), xl_lds, ctx->stream, ps->bufA, t, a, max_ranges, ps->bufB, 0u, nb1);
                 else hipLaunchKernelGGL((k_part_scatter2<1, true, 1024>), dim3(gw), dim3(1024), wide_lds, ctx->stream, ps->bufA, t, a, max_ranges, ps->bufB, 0u, nb1);
+            }
+        } else if (wide2_fits() && ctx->hook_p4_wide > 0) {
+            if constexpr (W == 2) {      // 16-byte keys: 6144-key sorts on 1024 threads — opt-in ("p4_wide" = 1): 1.00 / 0.94 -> 0.91 / 0.98 ms at k = 55, no clear gain
+                const size_t lds2 = ScatterLds<2, 1024, 6>::bytes(m->nb2) + part_tables_bytes(nb1);
+                const int gw = (int)std::min<u64>(max_ranges, (u64)ctx->cu_count * 2);
+                hipLaunchKernelGGL((k_part_scatter2<2, true, 1024, 6>), dim3(gw), dim3(1024), lds2, ctx->stream, ps->bufA, t, a, max_ranges, ps->bufB, 0u, nb1);
             }
         } else
             hipLaunchKernelGGL((k_part_scatter2<W, true, PBLOCK>), dim3(gr), dim3(PBLOCK), ScatterLds<W>::bytes(m->nb2) + part_tables_bytes(nb1), ctx->stream, ps->bufA, t, a,
