@@ -11,6 +11,8 @@ count).  Workload = BASELINE.json configs[1] ("C2"): 1M x 150 bp reads per GPU, 
           owner with the same pipeline as reads — all of it inside the C-ABI (gk_dist_count_reads_dev,
           csrc/gk_dist.hip).  torch.distributed (gloo) only carries the 128-byte RCCL id from rank 0 to
           the others.  value = distinct k-mers over all partitions / max-over-ranks time.
+          Launched by `torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or by itself: with
+          --gpus N and no WORLD_SIZE it starts its N ranks as child processes before touching torch or HIP.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -22,7 +24,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not os.environ.get("GK_BENCH_LAUNCH_ONLY"):
     # only to bootstrap the RCCL id across ranks — and FIRST: the HIP runtime (and RCCL) torch bundles must be the
     # process's only ones (the library dlopens whichever RCCL is already loaded)
     import torch  # noqa: E402
@@ -209,12 +211,45 @@ def c3_object(ctx):
     return res
 
 
+def launch_ranks(n, argv, launch_only):
+    """`bench.py --gpus N` without an outer launcher (WORLD_SIZE unset): start N fresh copies of this script, one rank per GPU,
+    BEFORE this process has imported torch or touched HIP (the reference driver deploys its own partitions too,
+    S/ds/PartitionedDNAMap.scala:20-28).  Rank 0's stdout — the one JSON line — is forwarded, everything else goes to stderr;
+    the exit code is the worst child's.  launch_only (--launch-only): the children only report their environment and exit —
+    the plumbing, testable without a GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if launch_only:
+            env["GK_BENCH_LAUNCH_ONLY"] = "1"
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if (r == 0 or launch_only) else sys.stderr, stderr=sys.stderr))
+    outs, worst = [], 0
+    for r, p in enumerate(procs):
+        o = p.communicate()[0] if (r == 0 or launch_only) else (p.wait(), None)[1]
+        outs.append(o.decode() if o else "")
+        if p.returncode != 0:
+            print(f"bench.py: rank {r} exited with {p.returncode}", file=sys.stderr)
+            worst = max(worst, abs(p.returncode) or 1)
+    if launch_only:
+        ranks = [json.loads(o.strip().splitlines()[-1]) for o in outs if o.strip()]
+        print(json.dumps({"launch_only": True, "n_gpus": n, "rc": worst, "ranks": ranks}), flush=True)
+    else:
+        lines = [ln for ln in outs[0].splitlines() if ln.startswith("{")]
+        if lines:
+            print(lines[-1], flush=True)
+        elif not worst:
+            worst = 1
+    return worst
+
+
 def main():
-    # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version banner) write to
-    # fd 1 behind Python's back, so fd 1 is pointed at stderr until the result is ready.
-    sys.stdout.flush()
-    saved_stdout = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -232,16 +267,28 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="gk_ctx_set_option name=value (A/B switches of the insert pipeline)")
     ap.add_argument("--no-extras", action="store_true", help="skip the objects measured next to the headline at N=1: mode_G, pcie_inclusive, c3")
     ap.add_argument("--no-c3", action="store_true", help="skip only the c3 object (A/B runs of the C2 pipeline)")
+    ap.add_argument("--launch-only", action="store_true", help="with --gpus N and no WORLD_SIZE: start the N ranks, let each report its "
+                    "environment and exit (checks the launcher without a GPU)")
     args = ap.parse_args()
+    if os.environ.get("GK_BENCH_LAUNCH_ONLY"):      # a child of --launch-only: no torch, no HIP
+        r = int(os.environ["RANK"])
+        print(json.dumps({"rank": r, "local_rank": int(os.environ["LOCAL_RANK"]), "world": int(os.environ["WORLD_SIZE"]),
+                          "master": os.environ["MASTER_ADDR"] + ":" + os.environ["MASTER_PORT"], "gpus_arg": args.gpus}), flush=True)
+        sys.exit(int(os.environ.get("GK_BENCH_TEST_EXIT", "0")) if r == int(os.environ.get("GK_BENCH_TEST_EXIT_RANK", "-1")) else 0)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, [a for a in sys.argv[1:] if a != "--launch-only"], args.launch_only))
+    # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version banner) write to
+    # fd 1 behind Python's back, so fd 1 is pointed at stderr until the result is ready.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running with {world} ranks", file=sys.stderr)
     sharded = world > 1 or args.sharded
 
     from genome_amd import synth
@@ -272,12 +319,8 @@ def main():
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            idt = torch.zeros(128, dtype=torch.uint8)
-            if rank == 0:
-                idt = torch.frombuffer(bytearray(unique_id()), dtype=torch.uint8).clone()
-            dist.broadcast(idt, 0)
-            id128 = bytes(idt.numpy().tobytes())
+            from genome_amd.dist import share_id
+            id128 = share_id(rank, world)               # gloo: only the 128-byte RCCL id travels over torch.distributed
         else:
             id128 = unique_id()
         hd = HipDist(ctx, rank, world, id128)
@@ -339,7 +382,7 @@ def main():
         phases = np.mean(np.array(phase_ms), axis=0)
         stats = m.stats()
         partitioned = stats["partitioned_launches"] > 0
-        slot_b = 16 if W == 1 else 32
+        slot_b = 16 if W == 1 else 24
         # ALGORITHMIC bytes of one insert+count pass, whatever kernels carry it
         abytes = (algorithmic_bytes_count_kernel(units, distinct_rank, L, k) if not sharded
                   else algorithmic_bytes_insert_kernel(units, distinct_rank, k))
@@ -384,7 +427,7 @@ def main():
                                    + ("single-partition DNAMap kernel" if not sharded else
                                       f"minimizer-sharded PartitionedDNAMap, {world} partitions, RCCL all-to-all"),
                        "reads_per_gpu": n, "read_len": L, "k": k, "mode": args.mode,
-                       "table_slots_per_gpu": m.slots(), "slot_bytes": 16 if W == 1 else 32,
+                       "table_slots_per_gpu": m.slots(), "slot_bytes": 16 if W == 1 else 24,
                        "insert_path": "partitioned" if partitioned else "direct"},
             "occurrences_per_s": occ_total / (dt_max / args.steps),
             "distinct_per_step": distinct_total, "occurrences_per_step": occ_total,

@@ -54,6 +54,9 @@ SIGNATURES = {
     "gk_ctx_device": (C.c_int, [vp]),
     "gk_ctx_trim": (C.c_int, [vp]),
     "gk_ctx_sync": (C.c_int, [vp]),
+    "gk_ctx_mem_stats": (C.c_int, [vp, u64p, u64p, u64p, C.c_int]),
+    "gk_ctx_set_mem_budget": (C.c_int, [vp, C.c_uint64]),
+    "gk_map_add_map": (C.c_int, [vp, vp]),
     "gk_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
     "gk_map_verify": (C.c_int, [vp, u64p, u64p, u64p, u64p]),
     "gk_map_set_max_batch_keys": (C.c_int, [vp, C.c_uint64]),
@@ -68,6 +71,7 @@ SIGNATURES = {
     "gk_dev_download": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "gk_dev_stream_bench": (C.c_int, [vp, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "gk_map_create": (C.c_int, [vp, C.c_int, C.c_uint64, C.POINTER(vp)]),
+    "gk_map_create_for_graph": (C.c_int, [vp, C.c_int, C.c_uint64, C.POINTER(vp)]),
     "gk_map_destroy": (None, [vp]),
     "gk_map_k": (C.c_int, [vp]),
     "gk_map_clear": (C.c_int, [vp]),

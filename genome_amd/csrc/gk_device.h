@@ -181,7 +181,11 @@ template <int W> struct Slot;
 // (v0 = 1, ArrayDNAMap.scala:146), so a new key costs ONE atomic (the CAS) and only repeats pay an
 // atomic add.  Readers add the 1 back (slot_count).
 template <> struct __attribute__((aligned(16))) Slot<1> { u64 w0; u32 extra; u32 aux; };
-template <> struct __attribute__((aligned(32))) Slot<2> { u64 w0; u64 w1; u32 extra; u32 aux; u64 pad; };
+// 24 bytes, nothing dead: the reference stores 16 bytes of key and a 4-byte value per slot (ArrayDNAMap.scala:74-89); `aux` is
+// the graph phase's annotation.  (Until round 3 the slot carried 8 bytes of padding to make it 32: a quarter of every table
+// pass and of C4/C5's HBM budget.)  A segment of 1024 slots is 24 KiB and still a whole number of 16-byte vectors.
+template <> struct __attribute__((aligned(8))) Slot<2> { u64 w0; u64 w1; u32 extra; u32 aux; };
+static_assert(sizeof(Slot<1>) == 16 && sizeof(Slot<2>) == 24, "slot layout");
 
 // Stored form.  W=1: the key itself (k<=31 leaves the two top bits clear).  W=2: two 63-bit
 // halves, bits 0..62 and 63..125 of the 128-bit k-mer, so each word has a spare top bit and each
@@ -201,8 +205,28 @@ GK_HD Kmer<2> from_stored(Stored<2> s, u32 tag = 0u) { return Kmer<2>{s.w0 | (s.
 GK_D Stored<1> load_stored(const Slot<1> *s) { return Stored<1>{s->w0}; }
 GK_D Stored<2> load_stored(const Slot<2> *s) { return Stored<2>{s->w0, s->w1}; }
 
-// The table is an array of SEGMENTS of 2^seg_bits slots (32 KiB each: 2048 16-B slots or 1024 32-B
-// slots), and linear probing wraps INSIDE a segment.  A segment is the unit one workgroup can hold
+// An array of EMPTY slots seen as 16-byte vectors (how the segment kernels clear and copy segments): vector i.
+// W = 1: one slot per vector {w0 = ~0, extra = 0, aux = 0}.  W = 2: three 64-bit words per slot {~0, ~0, 0}, two per vector.
+template <int W> GK_D uint4 empty_vec(u32 i) {
+    if constexpr (W == 1) { (void)i; return make_uint4(~0u, ~0u, 0u, 0u); }
+    else {
+        const u32 a = (2u * i) % 3u;                       // which word of its slot the vector's first 64-bit word is
+        const u32 lo = a == 2u ? 0u : ~0u, hi = a == 1u ? 0u : ~0u;      // (second word: (a + 1) % 3 == 2  <=>  a == 1)
+        return make_uint4(lo, lo, hi, hi);
+    }
+}
+// number of slots whose FIRST key word lies in vector i of a segment and is EMPTY (a slot is free iff its w0 is EMPTY)
+template <int W> GK_D u32 empty_w0_in_vec(u32 i, uint4 v) {
+    if constexpr (W == 1) { (void)i; return (v.x & v.y) == ~0u ? 1u : 0u; }
+    else {
+        const u32 a = (2u * i) % 3u;
+        if (a == 0u) return (v.x & v.y) == ~0u ? 1u : 0u;
+        if (a == 2u) return (v.z & v.w) == ~0u ? 1u : 0u;
+        return 0u;
+    }
+}
+
+// The table is an array of SEGMENTS of 2^seg_bits slots (2048 16-B slots = 32 KiB, or 1024 24-B slots = 24 KiB), and linear probing wraps INSIDE a segment.  A segment is the unit one workgroup can hold
 // in LDS, which is what lets a batch be radix-partitioned by segment and built there with LDS
 // atomics and coalesced HBM traffic (gk_partition.hip) instead of one global atomic per key.
 // Segment id = (L1 bucket, fine bucket): L1 = top lnb1 bits of the slot hash (<= 256 buckets; 512 or 1024 only
@@ -227,9 +251,6 @@ template <int W> struct Table {
     u32 tagged;        // 1 for k = 64: slot index mod 4 carries the key's last base
     u32 both;          // 1: the table may hold ANY orientation of a k-mer (keys inserted verbatim through the ABI), not only
                        // the hash-rule one: strand-agnostic lookups (table_find_either) must probe both, always
-    u32 aligned;       // 1: a key's probe starts at the FIRST slot of its 128-byte line (home_pos): every read request of this
-                       // chip is a whole line, so a lookup in a sparse table then costs exactly one (the table the graph phase
-                       // reads; never with `tagged`)
     GK_HD u64 nseg() const { return (u64)nb2 << lnb1; }
     GK_HD u64 capacity() const { return nseg() << SegBits<W>::value; }
 };
@@ -241,10 +262,7 @@ template <int W> GK_HD u32 seg_fine(const Table<W> &t, u64 h) {
 template <int W> GK_HD u32 seg_of(const Table<W> &t, u64 h) { return seg_l1(t, h) * t.nb2 + seg_fine(t, h); }
 template <int W> GK_HD u32 seg_pos(u64 h) { return (u32)h & ((1u << SegBits<W>::value) - 1u); }
 // where a key's probe starts in its segment
-template <int W> GK_HD u32 home_pos(const Table<W> &t, u64 h) {
-    constexpr u32 line_slots = 128u / (u32)sizeof(Slot<W>);
-    return t.aligned ? (seg_pos<W>(h) & ~(line_slots - 1u)) : seg_pos<W>(h);
-}
+template <int W> GK_HD u32 home_pos(const Table<W> &, u64 h) { return seg_pos<W>(h); }
 
 struct Counters {      // device-resident, one per map
     unsigned long long size;        // live keys

@@ -24,6 +24,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -136,10 +137,16 @@ struct gk_dist {
     // routes that were begun and not yet counted: at most three, first in, first out
     struct Route {
         int k = 0, read_len = 0; const void *records = nullptr; u64 nreads = 0;
+        // settled (owner thread): the routing kernel has finished, a region that was too small has been routed again, and
+        // this rank's verdict on its own half of the exchange is in local_rc — what it will tell its peers
+        bool settled = false;
+        int local_rc = 0;
+        std::string local_err;
+        uint64_t recs[64] = {}, kmers[64] = {};       // per owner
         bool exchanged = false;                      // counts known, records on the wire (or arrived) in d_recv[rbuf]
         int rbuf = 0;
         u64 nrec_in = 0, nkm_in = 0, sent = 0;
-        int error = 0;                               // its exchange, attempted ahead, failed: reported when the batch's turn comes
+        int error = 0;                               // the batch was dropped (by agreement of all ranks, or by the transport): reported when its turn comes
         std::string error_text;
     };
     Route route[NROUTE];
@@ -150,11 +157,63 @@ struct gk_dist {
     hipEvent_t route_done[NROUTE] = {nullptr, nullptr, nullptr};   // recorded behind each route's counter copy
     hipEvent_t exch_done[NROUTE] = {nullptr, nullptr, nullptr};    // recorded behind each batch's receives
     hipEvent_t join = nullptr;                       // main stream -> communication stream
-    unsigned long long *d_cnt = nullptr;             // [4 * world]: (records, k-mers) per peer to send, then as received
+    unsigned long long *d_cnt = nullptr;             // [8 x 64]: (records, k-mers, status) per peer to send [0, 3 x 64), as received [3 x 64, 6 x 64), scalars behind
     unsigned long long *h_cnt = nullptr;             // pinned mirror
     float last_ms[4] = {0, 0, 0, 0};                 // route, exchange, owner count, total (wall)
     float last_helper_ms = 0;                        // host time of the exchange that ran beside the last owner count
+    // ONE helper thread per handle, started on first use: it runs the exchange of the next batch beside the owner count
+    // (a std::thread per step was 30-50 us of clone + join each).  It never touches the context's error string, its
+    // streams or its block pool's frees: errors come back in the route, replaced buffers go to `garbage` for the owner thread.
+    std::thread worker;
+    std::mutex wmu;
+    std::condition_variable wcv;
+    std::function<void()> job;
+    bool job_pending = false, job_running = false, quit = false;
+    std::vector<void *> garbage;
 };
+
+static void helper_main(gk_dist *d) {
+    (void)hipSetDevice(d->ctx->device);
+    std::unique_lock<std::mutex> lk(d->wmu);
+    for (;;) {
+        d->wcv.wait(lk, [&]() { return d->job_pending || d->quit; });
+        if (d->quit) return;
+        std::function<void()> f = std::move(d->job);
+        d->job_pending = false; d->job_running = true;
+        lk.unlock();
+        f();
+        lk.lock();
+        d->job_running = false;
+        d->wcv.notify_all();
+    }
+}
+static void helper_submit(gk_dist *d, std::function<void()> f) {
+    std::unique_lock<std::mutex> lk(d->wmu);
+    if (!d->worker.joinable()) d->worker = std::thread(helper_main, d);
+    d->job = std::move(f);
+    d->job_pending = true;
+    d->wcv.notify_all();
+}
+static void helper_wait(gk_dist *d) {
+    std::unique_lock<std::mutex> lk(d->wmu);
+    d->wcv.wait(lk, [&]() { return !d->job_pending && !d->job_running; });
+}
+static void helper_stop(gk_dist *d) {
+    {
+        std::unique_lock<std::mutex> lk(d->wmu);
+        d->wcv.wait(lk, [&]() { return !d->job_pending && !d->job_running; });
+        d->quit = true;
+        d->wcv.notify_all();
+    }
+    if (d->worker.joinable()) d->worker.join();
+}
+// buffers the helper thread replaced: their frees wait for the owner thread (pool_free synchronises the context's streams)
+static void drain_garbage(gk_dist *d) {
+    gk_ctx *ctx = d->ctx;
+    std::vector<void *> g;
+    { std::lock_guard<std::mutex> lk(d->wmu); g.swap(d->garbage); }
+    for (void *p : g) (void)hipFree(p);
+}
 
 static std::string comm_error_text(int code) {
     if (code == 3) return "transport error (loopback: a send and its receive differ in size, or a HIP call failed)";
@@ -281,36 +340,6 @@ static int xAllGather(gk_dist *d, const void *in, void *out, size_t n_per_rank, 
     return loop_collective(d, in, out, n_per_rank, dt, ncclSum, true, st);
 }
 
-// live (key, count) of a table packed for the wire: keys interleaved W words each (what k_add_keys takes), counts apart
-template <int W>
-__global__ __launch_bounds__(BLOCK) void k_export_packed(const Slot<W> *__restrict__ slots, u64 ncap, u32 tagged, u64 *keys, i32 *cnt,
-                                                         unsigned long long *cursor) {
-    __shared__ unsigned long long s_base;
-    __shared__ u32 wsum[BLOCK / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const u64 ngroups = (ncap + BLOCK - 1) / BLOCK;
-    for (u64 g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        const u64 i = g * BLOCK + threadIdx.x;
-        const bool live = i < ncap && slot_live(&slots[i]);
-        const unsigned long long b = __ballot(live);
-        const u32 wprefix = (u32)__popcll(b & ((1ull << lane) - 1ull));
-        __syncthreads();
-        if (lane == 0) wsum[wave] = (u32)__popcll(b);
-        __syncthreads();
-        u32 base = 0, tot = 0;
-        for (int w = 0; w < BLOCK / 64; ++w) { if (w < wave) base += wsum[w]; tot += wsum[w]; }
-        if (threadIdx.x == 0 && tot) s_base = atomicAdd(cursor, (unsigned long long)tot);
-        __syncthreads();
-        if (live) {
-            const Kmer<W> key = slot_key(slots, i, tagged);
-            const u64 o = s_base + base + wprefix;
-            if constexpr (W == 1) keys[o] = key.lo;
-            else { keys[2 * o] = key.lo; keys[2 * o + 1] = key.hi; }
-            cnt[o] = (i32)slot_count(&slots[i]);
-        }
-    }
-}
-
 static int dist_check(const gk_dist *d) {
     if (!d || !d->ctx || (!d->comm && !d->loop)) return fail(nullptr, GK_E_INVALID, "null or closed gk_dist handle");
     hipError_t e = hipSetDevice(d->ctx->device);
@@ -363,8 +392,8 @@ static int dist_create(gk_ctx *ctx, int rank, int world, const void *id128, bool
             return fail(ctx, GK_E_COMM, std::string("ncclCommInitRank: ") + (r->GetErrorString ? r->GetErrorString(rc) : "error"));
         }
     }
-    hipError_t e = hipMalloc((void **)&d->d_cnt, 4 * 64 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipHostMalloc((void **)&d->h_cnt, 4 * 64 * sizeof(unsigned long long), hipHostMallocDefault);
+    hipError_t e = hipMalloc((void **)&d->d_cnt, 8 * 64 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipHostMalloc((void **)&d->h_cnt, 8 * 64 * sizeof(unsigned long long), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void **)&d->d_route_cnt, gk_dist::NROUTE * SKM_COUNT_WORDS * sizeof(unsigned long long));
     for (int i = 0; i < gk_dist::NROUTE && e == hipSuccess; i++) e = hipEventCreateWithFlags(&d->route_done[i], hipEventDisableTiming);
     for (int i = 0; i < gk_dist::NROUTE && e == hipSuccess; i++) e = hipEventCreateWithFlags(&d->exch_done[i], hipEventDisableTiming);
@@ -382,6 +411,8 @@ int gk_dist_create_loopback(gk_ctx *ctx, int rank, int world, const void *id128,
 void gk_dist_destroy(gk_dist *d) {
     if (!d) return;
     gk_ctx *ctx = d->ctx;
+    helper_stop(d);
+    if (ctx) { (void)hipSetDevice(ctx->device); drain_garbage(d); }
     if (d->ctx) { (void)hipSetDevice(d->ctx->device); (void)hipStreamSynchronize(d->ctx->stream); }
     if (d->comm_stream) (void)hipStreamSynchronize(d->comm_stream);
     if (d->comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(d->comm);
@@ -475,6 +506,7 @@ int gk_dist_route_begin(gk_dist *d, int k, const void *dev_records, uint64_t nre
     if (int rc = dist_check(d)) return rc;
     gk_ctx *ctx = d->ctx;
     constexpr int NR = gk_dist::NROUTE;
+    drain_garbage(d);
     if (d->npending >= NR) return fail(ctx, GK_E_STATE, "gk_dist_route_begin: three routes are already waiting (gk_dist_count_routed consumes one)");
     if (!dev_records && nreads) return fail(ctx, GK_E_INVALID, "gk_dist_route_begin: null records");
     if (read_len < 0 || read_len > 255) return fail(ctx, GK_E_FORMAT, "read_len must be 0..255 (one length byte per record)");
@@ -491,77 +523,149 @@ int gk_dist_route_begin(gk_dist *d, int k, const void *dev_records, uint64_t nre
     }
     const int b = (d->head + d->npending) % NR;
     // (the buffer's previous batch was counted before this slot could come round again: its records have left)
-    if (int rc = dist_grow(ctx, &d->d_sendbuf[b], &d->send_cap[b], std::max(route_want_records(k, P, nreads, read_len), d->send_cap[b]), slot)) return rc;
-    if (int rc = skm_route_launch(ctx, ctx->copy_stream, d->d_route_cnt + b * SKM_COUNT_WORDS, d->h_route_cnt + b * SKM_COUNT_WORDS, k, dev_records, nreads,
-                                  read_len, P, d->d_sendbuf[b], d->send_cap[b])) return rc;
-    GK_HIP(ctx, hipEventRecord(d->route_done[b], ctx->copy_stream));
+    u64 want = std::max(route_want_records(k, P, nreads, read_len), d->send_cap[b]);
+    if (ctx->hook_dist_small_send > 0) {      // test hook: THIS route gets a send buffer of so many records — the in-place re-route must repair it
+        GK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+        if (d->d_sendbuf[b]) { GK_HIP(ctx, hipFree(d->d_sendbuf[b])); d->d_sendbuf[b] = nullptr; d->send_cap[b] = 0; }
+        want = (u64)std::max(ctx->hook_dist_small_send, P);
+        ctx->hook_dist_small_send = 0;
+    }
     gk_dist::Route &rt = d->route[b];
     rt = gk_dist::Route();
     rt.k = k; rt.read_len = read_len; rt.records = dev_records; rt.nreads = nreads;
+    // A failure from here on is THIS RANK'S ALONE, and its peers are going to exchange this batch: the batch is begun all the
+    // same, carrying the failure, and gk_dist_count_routed tells everybody (status word of the counts exchange).
+    int rc = dist_grow(ctx, &d->d_sendbuf[b], &d->send_cap[b], want, slot);
+    if (!rc) rc = skm_route_launch(ctx, ctx->copy_stream, d->d_route_cnt + b * SKM_COUNT_WORDS, d->h_route_cnt + b * SKM_COUNT_WORDS, k, dev_records, nreads,
+                                   read_len, P, d->d_sendbuf[b], d->send_cap[b]);
+    if (rc) { rt.settled = true; rt.local_rc = rc; rt.local_err = ctx->err; (void)hipGetLastError(); }
+    GK_HIP(ctx, hipEventRecord(d->route_done[b], ctx->copy_stream));
     d->npending++;
     return GK_OK;
 }
 
-// Counts and records of route slot b over RCCL, on the communication stream: waits (host) for the route and for the
-// per-peer sizes, then posts the sends and receives and returns — the records are on the wire when this returns, and
-// exch_done[b] fires when they have arrived.  ms2 += {waiting for the route, the exchange's host time}.
-static int dist_exchange(gk_dist *d, int b, float *ms2) {
+// Owner thread: wait for route slot b's kernel, take the route again (bigger, in place) while a region was too small, and
+// fix this rank's verdict on its half of the batch.  ms += the wait.
+static void route_settle(gk_dist *d, int b, float *ms) {
     gk_ctx *ctx = d->ctx;
     gk_dist::Route &rt = d->route[b];
+    if (rt.settled) return;
+    const double t0 = now_ms();
     const int k = rt.k, P = d->world, slot = d->slot;
     unsigned long long *d_rc = d->d_route_cnt + b * SKM_COUNT_WORDS, *h_rc = d->h_route_cnt + b * SKM_COUNT_WORDS;
-    const double t0 = now_ms();
-    // ---- 1. the route's counters (it ran on the second stream, possibly long ago)
-    uint64_t recs[64], kmers[64];
-    GK_HIP(ctx, hipEventSynchronize(d->route_done[b]));        // this route only: later ones may already be queued behind it
-    int rrc = skm_route_finish(ctx, h_rc, rt.nreads && rt.read_len >= k, P, d->send_cap[b], recs, kmers);
+    int rrc = GK_OK;
+    hipError_t e = hipEventSynchronize(d->route_done[b]);            // this route only: later ones may already be queued behind it
+    if (e != hipSuccess) rrc = hip_fail(ctx, e, "gk_dist: waiting for the route");
+    if (!rrc) rrc = skm_route_finish(ctx, h_rc, rt.nreads && rt.read_len >= k, P, d->send_cap[b], rt.recs, rt.kmers);
     for (int attempt = 0; rrc == GK_E_CAPACITY && attempt < 4; attempt++) {       // a region was too small: route again, in place, bigger
         u64 worst = 0;
-        for (int p = 0; p < P; p++) worst = std::max<u64>(worst, recs[p]);
+        for (int p = 0; p < P; p++) worst = std::max<u64>(worst, rt.recs[p]);
         const u64 want = std::max<u64>(d->send_cap[b] * 2, (worst + worst / 8 + 1024) * P);
-        GK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));                       // (later routes share the stream: let them finish)
-        if (int rc = dist_grow(ctx, &d->d_sendbuf[b], &d->send_cap[b], want, slot)) return rc;
-        if (int rc = skm_route_launch(ctx, ctx->copy_stream, d_rc, h_rc, k, rt.records, rt.nreads, rt.read_len, P, d->d_sendbuf[b], d->send_cap[b])) return rc;
-        GK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
-        rrc = skm_route_finish(ctx, h_rc, true, P, d->send_cap[b], recs, kmers);
+        if ((e = hipStreamSynchronize(ctx->copy_stream)) != hipSuccess) { rrc = hip_fail(ctx, e, "gk_dist: re-route"); break; }   // (later routes share the stream)
+        if ((rrc = dist_grow(ctx, &d->d_sendbuf[b], &d->send_cap[b], want, slot)) != GK_OK) break;
+        if ((rrc = skm_route_launch(ctx, ctx->copy_stream, d_rc, h_rc, k, rt.records, rt.nreads, rt.read_len, P, d->d_sendbuf[b], d->send_cap[b])) != GK_OK) break;
+        if ((e = hipStreamSynchronize(ctx->copy_stream)) != hipSuccess) { rrc = hip_fail(ctx, e, "gk_dist: re-route"); break; }
+        rrc = skm_route_finish(ctx, h_rc, true, P, d->send_cap[b], rt.recs, rt.kmers);
     }
-    if (rrc) return rrc;
+    if (!rrc && ctx->hook_dist_fail) {        // test hook: this rank alone fails this batch, as an allocation or a hopeless route would
+        rrc = fail(ctx, ctx->hook_dist_fail, "injected failure (test_dist_fail_exchange)");
+        ctx->hook_dist_fail = 0;
+    }
+    rt.local_rc = rrc;
+    if (rrc) rt.local_err = ctx->err;
+    rt.settled = true;
+    *ms += (float)(now_ms() - t0);
+}
+
+// Counts and records of route slot b (settled) over RCCL, on the communication stream — on the owner thread or on the
+// helper.  Touches neither the context's error string nor its streams nor the pool's frees.  Three steps, and every rank
+// takes the same ones whatever happens to it locally:
+//   1. counts: (records, k-mers, STATUS) to every peer — a rank whose route failed says so here and sends nothing; if any
+//      status is set, every rank drops the batch after this step;
+//   2. room for what is coming, then one max-reduction of "I could not make room": any rank -> every rank drops the batch;
+//   3. payload: region p -> rank p straight out of the send buffer, arrivals back to back in the receive buffer that is not
+//      being counted.  exch_done[b] fires when they have arrived.
+// Returns 0 with rt.exchanged set, or the code the batch's count_routed will report (rt.error / rt.error_text).
+static int dist_exchange(gk_dist *d, int b, float *ms) {
+    gk_ctx *ctx = d->ctx;
+    gk_dist::Route &rt = d->route[b];
+    const int P = d->world, slot = d->slot;
     const double t1 = now_ms();
-    // ---- 2. counts: (records, k-mers) for every peer, one tiny all-to-all; the sizes then reach the host
-    const u64 region = d->send_cap[b] / (u64)P;
     hipStream_t cs = d->comm_stream;
+    auto give_up = [&](int code, const std::string &text) { rt.error = code; rt.error_text = text; *ms += (float)(now_ms() - t1); return code; };
+    auto hip_text = [](hipError_t e, const char *what) { (void)hipGetLastError(); return std::string(what) + ": " + hipGetErrorString(e); };
+    // ---- 1. counts + status
+    const u64 region = d->send_cap[b] / (u64)P;
     u64 sent = 0;
-    for (int p = 0; p < P; p++) { d->h_cnt[2 * p] = recs[p]; d->h_cnt[2 * p + 1] = kmers[p]; sent += kmers[p]; }
-    unsigned long long *d_in = d->d_cnt, *d_out = d->d_cnt + 2 * 64;
-    GK_HIP(ctx, hipMemcpyAsync(d_in, d->h_cnt, 2 * P * 8, hipMemcpyHostToDevice, cs));
-    GK_NCCL(ctx, xGroupStart(d));
+    unsigned long long *h_in = d->h_cnt, *h_out = d->h_cnt + 3 * 64, *d_in = d->d_cnt, *d_out = d->d_cnt + 3 * 64;
     for (int p = 0; p < P; p++) {
-        GK_NCCL(ctx, xSend(d, d_in + 2 * p, 2, ncclUint64, p, cs));
-        GK_NCCL(ctx, xRecv(d, d_out + 2 * p, 2, ncclUint64, p, cs));
+        h_in[3 * p] = rt.local_rc ? 0 : rt.recs[p];
+        h_in[3 * p + 1] = rt.local_rc ? 0 : rt.kmers[p];
+        h_in[3 * p + 2] = rt.local_rc ? (unsigned long long)(-rt.local_rc) : 0ull;
+        sent += h_in[3 * p + 1];
     }
-    GK_NCCL(ctx, xGroupEnd(d));
-    unsigned long long *h_out = d->h_cnt + 2 * 64;
-    GK_HIP(ctx, hipMemcpyAsync(h_out, d_out, 2 * P * 8, hipMemcpyDeviceToHost, cs));
-    GK_HIP(ctx, hipStreamSynchronize(cs));                     // (also: the previous batch's records have arrived)
+    hipError_t e = hipMemcpyAsync(d_in, h_in, 3 * P * 8, hipMemcpyHostToDevice, cs);
+    if (e != hipSuccess) return give_up(GK_E_HIP, hip_text(e, "gk_dist: counts upload") + " (before anything was posted: the peers will wait; destroy the communicator)");
+    int grc = xGroupStart(d);
+    for (int p = 0; p < P && grc == ncclSuccess; p++) {
+        grc = xSend(d, d_in + 3 * p, 3, ncclUint64, p, cs);
+        if (grc == ncclSuccess) grc = xRecv(d, d_out + 3 * p, 3, ncclUint64, p, cs);
+    }
+    { const int gend = xGroupEnd(d); if (grc == ncclSuccess) grc = gend; }          // (a group that was opened is always closed)
+    if (grc != ncclSuccess) return give_up(GK_E_COMM, "counts exchange: " + comm_error_text(grc));
+    e = hipMemcpyAsync(h_out, d_out, 3 * P * 8, hipMemcpyDeviceToHost, cs);
+    if (e == hipSuccess) e = hipStreamSynchronize(cs);                              // (also: the previous batch's records have arrived)
+    if (e != hipSuccess) return give_up(GK_E_HIP, hip_text(e, "gk_dist: counts download"));
     u64 nrec_in = 0, nkm_in = 0;
-    for (int p = 0; p < P; p++) { nrec_in += h_out[2 * p]; nkm_in += h_out[2 * p + 1]; }
-    // ---- 3. payload: region p -> rank p, straight out of the send buffer; arrivals land back to back in the receive buffer
-    //         that is NOT being counted (the batch counted two exchanges ago has returned)
-    const int rb = (int)(d->nexchanged & 1);
-    if (int rc = dist_grow(ctx, &d->d_recv[rb], &d->recv_records[rb], std::max<u64>(nrec_in, d->recv_records[rb]), slot)) return rc;
-    GK_NCCL(ctx, xGroupStart(d));
-    u64 roff = 0;
+    int bad_rank = -1;
     for (int p = 0; p < P; p++) {
-        if (recs[p]) GK_NCCL(ctx, xSend(d, d->d_sendbuf[b] + (u64)p * region * slot, (size_t)recs[p] * slot, ncclUint8, p, cs));
-        if (h_out[2 * p]) GK_NCCL(ctx, xRecv(d, d->d_recv[rb] + roff * slot, (size_t)h_out[2 * p] * slot, ncclUint8, p, cs));
-        roff += h_out[2 * p];
+        nrec_in += h_out[3 * p]; nkm_in += h_out[3 * p + 1];
+        if (h_out[3 * p + 2] && bad_rank < 0) bad_rank = p;
     }
-    GK_NCCL(ctx, xGroupEnd(d));
-    GK_HIP(ctx, hipEventRecord(d->exch_done[b], cs));
+    if (bad_rank >= 0) {
+        std::string text = "rank " + std::to_string(bad_rank) + " could not route its share of this batch (status " + std::to_string(-(long long)h_out[3 * bad_rank + 2]) +
+                           "): every rank dropped the batch";
+        if (rt.local_rc) text += "; this rank: " + rt.local_err;
+        return give_up(GK_E_COMM, text);
+    }
+    // ---- 2. room for the arrivals (the buffer that is NOT being counted: the batch counted two exchanges ago has returned)
+    const int rb = (int)(d->nexchanged & 1);
+    unsigned long long noroom = 0;
+    std::string noroom_text;
+    if (nrec_in > d->recv_records[rb] || !d->d_recv[rb]) {
+        const u64 want = std::max<u64>(nrec_in + nrec_in / 8, 1024);
+        uint8_t *nb = nullptr;
+        e = hipMalloc((void **)&nb, want * (u64)slot + 64);                         // (the pool: a mutex, no stream is waited for)
+        if (e == hipSuccess) {
+            if (d->d_recv[rb]) { std::lock_guard<std::mutex> lk(d->wmu); d->garbage.push_back(d->d_recv[rb]); }
+            d->d_recv[rb] = nb; d->recv_records[rb] = want;
+        } else { noroom = 1; noroom_text = hip_text(e, "gk_dist: receive buffer"); }
+    }
+    unsigned long long *d_flag = d->d_cnt + 6 * 64, *h_flag = d->h_cnt + 6 * 64;
+    h_flag[0] = noroom;
+    e = hipMemcpyAsync(d_flag, h_flag, 8, hipMemcpyHostToDevice, cs);
+    if (e != hipSuccess) return give_up(GK_E_HIP, hip_text(e, "gk_dist: ready flag"));
+    grc = xAllReduce(d, d_flag, d_flag + 1, 1, ncclUint64, ncclMax, cs);
+    if (grc != ncclSuccess) return give_up(GK_E_COMM, "ready reduction: " + comm_error_text(grc));
+    e = hipMemcpyAsync(h_flag + 1, d_flag + 1, 8, hipMemcpyDeviceToHost, cs);
+    if (e == hipSuccess) e = hipStreamSynchronize(cs);
+    if (e != hipSuccess) return give_up(GK_E_HIP, hip_text(e, "gk_dist: ready flag"));
+    if (h_flag[1]) return give_up(GK_E_COMM, "a rank had no room for the records addressed to it: every rank dropped the batch" + (noroom ? "; this rank: " + noroom_text : std::string()));
+    // ---- 3. payload
+    grc = xGroupStart(d);
+    u64 roff = 0;
+    for (int p = 0; p < P && grc == ncclSuccess; p++) {
+        if (rt.recs[p]) grc = xSend(d, d->d_sendbuf[b] + (u64)p * region * slot, (size_t)rt.recs[p] * slot, ncclUint8, p, cs);
+        if (h_out[3 * p] && grc == ncclSuccess) grc = xRecv(d, d->d_recv[rb] + roff * slot, (size_t)h_out[3 * p] * slot, ncclUint8, p, cs);
+        roff += h_out[3 * p];
+    }
+    { const int gend = xGroupEnd(d); if (grc == ncclSuccess) grc = gend; }
+    if (grc != ncclSuccess) return give_up(GK_E_COMM, "record exchange: " + comm_error_text(grc));
+    e = hipEventRecord(d->exch_done[b], cs);
+    if (e != hipSuccess) return give_up(GK_E_HIP, hip_text(e, "gk_dist: exchange event"));
     rt.exchanged = true; rt.rbuf = rb; rt.nrec_in = nrec_in; rt.nkm_in = nkm_in; rt.sent = sent;
     d->nexchanged++;
-    const double t2 = now_ms();
-    ms2[0] += (float)(t1 - t0); ms2[1] += (float)(t2 - t1);
+    *ms += (float)(now_ms() - t1);
     return GK_OK;
 }
 
@@ -575,39 +679,37 @@ int gk_dist_count_routed(gk_dist *d, gk_map *local, uint64_t *occurrences_sent, 
     constexpr int NR = gk_dist::NROUTE;
     if (occurrences_sent) *occurrences_sent = 0;
     if (occurrences_owned) *occurrences_owned = 0;
+    drain_garbage(d);
     if (!d->npending) return fail(ctx, GK_E_STATE, "gk_dist_count_routed: no route was begun (gk_dist_route_begin)");
     const int b = d->head;
     if (!local || local->ctx != ctx) return fail(ctx, GK_E_INVALID, "gk_dist_count_routed: the local map must live on the handle's context");
     if (local->k != d->route[b].k) return fail(ctx, GK_E_KLEN, "gk_dist_count_routed: the route was begun for another k");
     const double t0 = now_ms();
-    float ms2[2] = {0, 0};
+    float ms_route = 0, ms_exch = 0;
     auto drop_head = [&]() { d->head = (d->head + 1) % NR; d->npending--; };
-    if (d->route[b].error) {                 // found while this batch's exchange was attempted ahead of its turn
-        const int rc = d->route[b].error;
-        const std::string text = d->route[b].error_text;
-        drop_head();
-        return fail(ctx, rc, text);
+    // (whatever this batch's own fate, the collective steps below are taken: the peers take them too)
+    if (!d->route[b].exchanged && !d->route[b].error) {
+        route_settle(d, b, &ms_route);
+        (void)dist_exchange(d, b, &ms_exch);           // a failure is in route[b].error
     }
-    if (!d->route[b].exchanged) {
-        if (int rc = dist_exchange(d, b, ms2)) { drop_head(); return rc; }       // (a batch that cannot be exchanged is dropped)
-    }
-    // With three batches begun, the NEXT batch's exchange runs on a helper thread beside this batch's owner count: its host
-    // side alone (two RCCL group launches and the round trip for the sizes, 0.4-0.6 ms) would otherwise sit in front of
-    // the owner pipeline's launches.  The helper is the only thread that touches the communicator until it is joined below.
-    std::thread helper;
-    float hms[2] = {0, 0};
+    // With three batches begun, the NEXT batch's exchange runs on the helper thread beside this batch's owner count: its host
+    // side alone (RCCL group launches and two round trips for the sizes, 0.4-0.6 ms) would otherwise sit in front of the
+    // owner pipeline's launches.  Its route is settled HERE first (a re-route allocates and waits for the context's second
+    // stream: the owner thread's business).  The helper is the only thread that touches the communicator until it is waited for.
+    bool helping = false;
+    float hms = 0;
     if (d->npending >= NR && ctx->hook_dist_ahead != 0) {        // ("dist_exchange_ahead" = 0: the plain order, for A/B and as a fallback)
         const int b1 = (b + 1) % NR;
         if (!d->route[b1].exchanged && !d->route[b1].error) {
-            helper = std::thread([d, b1, &hms]() {
-                (void)hipSetDevice(d->ctx->device);
-                if (int rc = dist_exchange(d, b1, hms)) { d->route[b1].error = rc; d->route[b1].error_text = d->ctx->err; }
-            });
+            route_settle(d, b1, &ms_route);
+            helper_submit(d, [d, b1, &hms]() { (void)dist_exchange(d, b1, &hms); });
+            helping = true;
         }
     }
-    struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join_helper{helper};
+    struct Join { gk_dist *d; bool on; ~Join() { if (on) helper_wait(d); } } join_helper{d, helping};
     const gk_dist::Route rt = d->route[b];
     drop_head();
+    if (rt.error) return fail(ctx, rt.error, "gk_dist_count_routed: " + rt.error_text);     // (a batch that could not be exchanged is dropped — on every rank)
     const double t2 = now_ms();
     // ---- the owner counts what it received: the records ARE short reads (stream-ordered behind the receives)
     GK_HIP(ctx, hipStreamWaitEvent(ctx->stream, d->exch_done[b], 0));
@@ -615,12 +717,12 @@ int gk_dist_count_routed(gk_dist *d, gk_map *local, uint64_t *occurrences_sent, 
     if (rt.nrec_in) { if (int rc = gk_map_count_superkmers_dev(local, d->d_recv[rt.rbuf], rt.nrec_in, rt.nkm_in, &occ)) return rc; }
     else GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const double t3 = now_ms();
-    if (helper.joinable()) helper.join();
+    if (helping) { helper_wait(d); join_helper.on = false; }
     const double t4 = now_ms();
     // {waiting for routes, exchanges done in front of the count, owner count, total}; [1] also carries what the helper's
     // exchange took beyond the owner count (0 when it was hidden completely)
-    d->last_ms[0] = ms2[0]; d->last_ms[1] = ms2[1] + (float)(t4 - t3); d->last_ms[2] = (float)(t3 - t2); d->last_ms[3] = (float)(t4 - t0);
-    d->last_helper_ms = hms[0] + hms[1];
+    d->last_ms[0] = ms_route; d->last_ms[1] = ms_exch + (float)(t4 - t3); d->last_ms[2] = (float)(t3 - t2); d->last_ms[3] = (float)(t4 - t0);
+    d->last_helper_ms = hms;
     if (occurrences_sent) *occurrences_sent = rt.sent;
     if (occurrences_owned) *occurrences_owned = occ;
     return GK_OK;
@@ -642,6 +744,11 @@ int gk_dist_last_ms(gk_dist *d, float *ms4) {
     return GK_OK;
 }
 
+// The whole k-mer set on every rank.  CHUNKED: every rank exports the live (key, count) of 2^25 of its slots at a time, the
+// chunk's sizes go round (one word per rank — ~0 = "I failed": then EVERY rank gives up together, nobody is left waiting in a
+// receive), the parts are exchanged and inserted, and the staging is reused: 0.67 GB to send and P x that to receive whatever
+// the table's size (until round 3 the whole set was staged at 20 B per key — 62 GB at C5 — beside the table being built).
+// The new table is sized the way the graph phase wants it (graph_table_load).
 int gk_dist_gather_map(gk_dist *d, gk_map *local, gk_map **full) {
     if (int rc = dist_check(d)) return rc;
     gk_ctx *ctx = d->ctx;
@@ -650,65 +757,106 @@ int gk_dist_gather_map(gk_dist *d, gk_map *local, gk_map **full) {
     if (int rc = dist_quiesce(d)) return rc;
     if (int rc = map_materialize(local)) return rc;
     const int P = d->world, W = local->W;
-    // sizes
-    unsigned long long mine = local->size;
-    GK_HIP(ctx, hipMemcpyAsync(d->d_cnt + 64, &mine, 8, hipMemcpyHostToDevice, ctx->stream));
-    GK_NCCL(ctx, xAllGather(d, d->d_cnt + 64, d->d_cnt, 1, ncclUint64, ctx->stream));
-    GK_HIP(ctx, hipMemcpyAsync(d->h_cnt, d->d_cnt, P * 8, hipMemcpyDeviceToHost, ctx->stream));
+    constexpr u64 CHS = 1ull << 25;
+    // live keys of every rank, and the number of chunks of the rank with the largest table
+    unsigned long long mine[2] = {local->size, (local->capacity + CHS - 1) / CHS};
+    GK_HIP(ctx, hipMemcpyAsync(d->d_cnt + 2 * 64, mine, 16, hipMemcpyHostToDevice, ctx->stream));
+    GK_NCCL(ctx, xAllGather(d, d->d_cnt + 2 * 64, d->d_cnt, 1, ncclUint64, ctx->stream));
+    GK_NCCL(ctx, xAllReduce(d, d->d_cnt + 2 * 64 + 1, d->d_cnt + 64, 1, ncclUint64, ncclMax, ctx->stream));
+    GK_HIP(ctx, hipMemcpyAsync(d->h_cnt, d->d_cnt, (64 + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    u64 total = 0, my_off = 0;
-    for (int p = 0; p < P; p++) { if (p == d->rank) my_off = total; total += d->h_cnt[p]; }
-    if (d->h_cnt[d->rank] != mine) return fail(ctx, GK_E_COMM, "gk_dist_gather_map: size exchange is inconsistent");
-    // every rank's live (key, count) lands in one array, this rank's own part written in place by the export
-    u64 *d_keys = nullptr;
-    i32 *d_cnt = nullptr;
-    unsigned long long *d_cursor = nullptr;
+    u64 total = 0;
+    const u64 nchunks = d->h_cnt[64];
+    for (int p = 0; p < P; p++) total += d->h_cnt[p];
+    if (d->h_cnt[d->rank] != mine[0]) return fail(ctx, GK_E_COMM, "gk_dist_gather_map: size exchange is inconsistent");
+    gk_map *m = nullptr;
+    u64 *d_send_k = nullptr, *d_recv_k = nullptr;
+    i32 *d_send_c = nullptr, *d_recv_c = nullptr;
+    unsigned long long *d_cur = nullptr;
+    // every rank's chunk holds at most CHS keys: the receive staging is allocated ONCE, before anything is agreed — no allocation,
+    // hence no local failure, between a chunk's size exchange and its sends and receives
+    const u64 recv_cap = std::max<u64>(std::min<u64>(total, (u64)P * CHS), 1);
     auto done = [&](int code) {
-        if (d_keys) (void)hipFree(d_keys);
-        if (d_cnt) (void)hipFree(d_cnt);
-        if (d_cursor) (void)hipFree(d_cursor);
+        for (void *p : {(void *)d_send_k, (void *)d_send_c, (void *)d_recv_k, (void *)d_recv_c, (void *)d_cur}) if (p) (void)hipFree(p);
+        if (code != GK_OK && m) { gk_map_destroy(m); m = nullptr; }
         return code;
     };
-    hipError_t e = hipMalloc((void **)&d_keys, std::max<u64>(total, 1) * 8 * W);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_cnt, std::max<u64>(total, 1) * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_cursor, 8);
-    if (e == hipSuccess) e = hipMemsetAsync(d_cursor, 0, 8, ctx->stream);
-    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_dist_gather_map: alloc"));
-    if (mine) {
-        const int grid = (int)std::min<u64>(std::max<u64>((local->capacity + BLOCK - 1) / BLOCK, 1), (u64)ctx->cu_count * 8);
-        if (W == 1)
-            hipLaunchKernelGGL(k_export_packed<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)local->slots, local->capacity, 0u,
-                               d_keys + my_off, d_cnt + my_off, d_cursor);
-        else
-            hipLaunchKernelGGL(k_export_packed<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)local->slots, local->capacity,
-                               local->k == 64 ? 1u : 0u, d_keys + 2 * my_off, d_cnt + my_off, d_cursor);
-        e = hipGetLastError();
-        if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_dist_gather_map: export"));
+    // a local failure must not leave the peers in a receive: it is announced in the chunk's size word and everybody stops
+    int my_rc = map_create_for_graph(ctx, local->k, total, &m);
+    std::string my_err = my_rc ? ctx->err : std::string();
+    const u64 send_cap = std::min<u64>(CHS, local->capacity);
+    if (!my_rc) {
+        hipError_t e = hipMalloc((void **)&d_send_k, std::max<u64>(send_cap, 1) * 8 * W);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_send_c, std::max<u64>(send_cap, 1) * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_cur, 8);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_recv_k, recv_cap * 8 * W);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_recv_c, recv_cap * 4);
+        if (e != hipSuccess) { my_rc = hip_fail(ctx, e, "gk_dist_gather_map: staging"); my_err = ctx->err; }
     }
-    // all-gather-v: my part to every peer, every peer's part to its offset (device to device over xGMI)
-    int grc = xGroupStart(d);
-    u64 off = 0;
-    for (int p = 0; p < P && grc == ncclSuccess; p++) {
-        const u64 n = d->h_cnt[p];
-        if (p != d->rank) {
-            if (mine) grc = xSend(d, d_keys + my_off * W, (size_t)mine * W, ncclUint64, p, ctx->stream);
-            if (mine && grc == ncclSuccess) grc = xSend(d, d_cnt + my_off, (size_t)mine * 4, ncclUint8, p, ctx->stream);
-            if (n && grc == ncclSuccess) grc = xRecv(d, d_keys + off * W, (size_t)n * W, ncclUint64, p, ctx->stream);
-            if (n && grc == ncclSuccess) grc = xRecv(d, d_cnt + off, (size_t)n * 4, ncclUint8, p, ctx->stream);
+#define HIPD(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return done(hip_fail(ctx, e__, #call)); } while (0)
+    for (u64 c = 0; c < nchunks; c++) {
+        uint64_t n_mine = 0;
+        if (!my_rc && c * CHS < local->capacity) {
+            my_rc = map_export_range_dev(local, c * CHS, (c + 1) * CHS, d_send_k, d_send_c, d_cur, &n_mine);
+            if (my_rc) my_err = ctx->err;
         }
-        off += n;
+        unsigned long long word = my_rc ? ~0ull : n_mine;
+        HIPD(hipMemcpyAsync(d->d_cnt + 2 * 64, &word, 8, hipMemcpyHostToDevice, ctx->stream));
+        { const int g = xAllGather(d, d->d_cnt + 2 * 64, d->d_cnt, 1, ncclUint64, ctx->stream); if (g != ncclSuccess) return done(fail(ctx, GK_E_COMM, "gk_dist_gather_map: " + comm_error_text(g))); }
+        HIPD(hipMemcpyAsync(d->h_cnt, d->d_cnt, P * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPD(hipStreamSynchronize(ctx->stream));
+        u64 tot_c = 0, my_off = 0;
+        bool peer_failed = false;
+        for (int p = 0; p < P; p++) {
+            if (d->h_cnt[p] == ~0ull) { peer_failed = true; continue; }
+            if (p == d->rank) my_off = tot_c;
+            tot_c += d->h_cnt[p];
+        }
+        if (peer_failed) return done(my_rc ? fail(ctx, my_rc, my_err) : fail(ctx, GK_E_COMM, "gk_dist_gather_map: another rank failed; the gather was abandoned on every rank"));
+        if (tot_c == 0) continue;
+        if (tot_c > recv_cap) return done(fail(ctx, GK_E_STATE, "gk_dist_gather_map: a chunk holds more keys than its slots"));   // (cannot happen: <= CHS per rank)
+        if (n_mine) {
+            HIPD(hipMemcpyAsync(d_recv_k + my_off * W, d_send_k, n_mine * 8 * W, hipMemcpyDeviceToDevice, ctx->stream));
+            HIPD(hipMemcpyAsync(d_recv_c + my_off, d_send_c, n_mine * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        if (P > 1) {
+            int grc = xGroupStart(d);
+            u64 off = 0;
+            for (int p = 0; p < P; p++) {
+                const u64 n = d->h_cnt[p];
+                if (p != d->rank) {
+                    if (n_mine && grc == ncclSuccess) grc = xSend(d, d_send_k, (size_t)n_mine * W, ncclUint64, p, ctx->stream);
+                    if (n_mine && grc == ncclSuccess) grc = xSend(d, d_send_c, (size_t)n_mine * 4, ncclUint8, p, ctx->stream);
+                    if (n && grc == ncclSuccess) grc = xRecv(d, d_recv_k + off * W, (size_t)n * W, ncclUint64, p, ctx->stream);
+                    if (n && grc == ncclSuccess) grc = xRecv(d, d_recv_c + off, (size_t)n * 4, ncclUint8, p, ctx->stream);
+                }
+                off += n;
+            }
+            const int gend = xGroupEnd(d);                 // (the group is always closed, whatever was posted)
+            if (grc == ncclSuccess) grc = gend;
+            if (grc != ncclSuccess) return done(fail(ctx, GK_E_COMM, std::string("gk_dist_gather_map: ") + comm_error_text(grc)));
+        }
+        // one table holding every partition's keys (each key has exactly one owner: nothing merges)
+        my_rc = map_add_counted_keys_dev(m, d_recv_k, d_recv_c, tot_c);
+        if (my_rc) my_err = ctx->err;
     }
-    if (grc == ncclSuccess) grc = xGroupEnd(d);
-    if (grc != ncclSuccess) return done(fail(ctx, GK_E_COMM, std::string("gk_dist_gather_map: ") + comm_error_text(grc)));
-    // one table holding every partition's keys (each key has exactly one owner: nothing merges)
-    gk_map *m = nullptr;
-    if (int rc = gk_map_create(ctx, local->k, total, &m)) return done(rc);
-    int rc = total ? map_add_counted_keys_dev(m, d_keys, d_cnt, total) : GK_OK;
-    if (rc == GK_OK) rc = map_sync_counters(m);
-    if (rc != GK_OK) { gk_map_destroy(m); return done(rc); }
+    // the last chunk's insert may have failed after its word went out: agree on the outcome once more
+    {
+        unsigned long long word = my_rc ? ~0ull : 0ull;
+        HIPD(hipMemcpyAsync(d->d_cnt + 2 * 64, &word, 8, hipMemcpyHostToDevice, ctx->stream));
+        const int g = xAllReduce(d, d->d_cnt + 2 * 64, d->d_cnt + 2 * 64, 1, ncclUint64, ncclMax, ctx->stream);
+        if (g != ncclSuccess) return done(fail(ctx, GK_E_COMM, "gk_dist_gather_map: " + comm_error_text(g)));
+        HIPD(hipMemcpyAsync(&word, d->d_cnt + 2 * 64, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPD(hipStreamSynchronize(ctx->stream));
+        if (my_rc) return done(fail(ctx, my_rc, my_err));
+        if (word) return done(fail(ctx, GK_E_COMM, "gk_dist_gather_map: another rank failed; the gathered table is void on every rank"));
+    }
+    if (int rc = map_sync_counters(m)) return done(rc);
+    if (m->size != total) return done(fail(ctx, GK_E_STATE, "gk_dist_gather_map: gathered " + std::to_string(m->size) + " keys, the partitions hold " + std::to_string(total)));
     m->dirty = local->dirty;
     *full = m;
     return done(GK_OK);
 }
+#undef HIPD
 
 }  // extern "C"

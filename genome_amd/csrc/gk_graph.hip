@@ -43,6 +43,12 @@ gk_ctx *vmap_ctx(const gk_vmap *m);
 static constexpr u32 NONE = 0xFFFFFFFFu;
 static constexpr u32 AUX_TERMINAL = 1u << 8;
 static constexpr u32 AUX_SECONDARY = 1u << 9;
+// Once k_make_nodes has numbered the terminal k-mers, a terminal slot's annotation IS its node: AUX_NODE | j, where the stored
+// orientation is node 2j and its reverse complement node 2j + 1.  (Until round 3 a separate u32 per table SLOT held that
+// number: 4 bytes x capacity — 19 GB at C5 — and one more random read at every edge's end.)  Its degree masks are not
+// needed any more at that point: a walk stops at a terminal k-mer, it never leaves one through the table.
+static constexpr u32 AUX_NODE = 1u << 31;
+__device__ __forceinline__ u32 aux_node(u32 aux, bool fwd) { return 2u * (aux & 0x7fffffffu) + (fwd ? 0u : 1u); }
 
 // ---------------------------------------------------------------------------------------------
 // device-side view of a graph
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(BLOCK) void k_collect_terminals(Table<W> t, int k, 
 // complement (termKmers = set ++ set.map(revComplement), :330-333); plus the (node, base) stubs of
 // buildEdges (:351): one edge per outgoing base, in A,G,C,T order.
 template <int W>
-__global__ __launch_bounds__(BLOCK) void k_make_nodes(Table<W> t, int k, const u64 *tslots, u64 nT, GraphView g, u32 *slot_node,
+__global__ __launch_bounds__(BLOCK) void k_make_nodes(Table<W> t, int k, const u64 *tslots, u64 nT, GraphView g,
                                                       unsigned long long *ecursor) {
     __shared__ u32 lds4[BLOCK / 64];
     __shared__ unsigned long long s_base;
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(BLOCK) void k_make_nodes(Table<W> t, int k, const u
             pal = (y == rc);
             m0 = (aux >> 4) & 15u;                  // outcoming(y)
             m1 = pal ? 0u : rev4(aux & 15u);        // outcoming(rc y) = complemented incoming(y)
-            slot_node[slot] = (u32)(2 * j);
+            t.slots[slot].aux = AUX_NODE | (u32)j;          // (nT < 2^31 is checked by the host)
         }
         u64 e = block_reserve((u32)(__popc(m0) + __popc(m1)), ecursor, lds4, &s_base);
         if (j < nT) {
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(BLOCK) void k_make_nodes(Table<W> t, int k, const u
 // pass 1: only for edges longer than WALK_BUF: walk again and emit the bases 2 bits each at e_off (assigned in pass 0).
 static constexpr u32 WALK_BUF = 128;          // bases kept in four 64-bit registers
 template <int W>
-__global__ __launch_bounds__(BLOCK) void k_walk(Table<W> t, int k, GraphView g, const u32 *slot_node, int pass, u64 max_steps,
+__global__ __launch_bounds__(BLOCK) void k_walk(Table<W> t, int k, GraphView g, int pass, u64 max_steps,
                                                 unsigned long long *pool_cursor, unsigned long long *n_long, u32 *err) {
     __shared__ u32 lds4[BLOCK / 64];
     __shared__ unsigned long long s_base;
@@ -367,8 +373,8 @@ __global__ __launch_bounds__(BLOCK) void k_walk(Table<W> t, int k, GraphView g, 
                 i64 slot = table_find_either(t, cur, k, &fwd);
                 if (slot < 0) { *err = 1; break; }
                 const u32 aux = t.slots[slot].aux;
-                if (aux & AUX_TERMINAL) {                                   // nodeMap.contains(seq)  :355
-                    end = slot_node[slot] + (fwd ? 0u : 1u);
+                if (aux & AUX_NODE) {                                       // nodeMap.contains(seq)  :355
+                    end = aux_node(aux, fwd);
                     break;
                 }
                 const u32 om = fwd ? ((aux >> 4) & 15u) : rev4(aux & 15u);  // outcoming(seq)         :356
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(BLOCK) void k_walk(Table<W> t, int k, GraphView g, 
 // slot per edge, and k_place_edges afterwards assigns the pool offsets (one atomic per 2048 edges) and copies the staged
 // bases.  Edges longer than WALK_BUF are emitted by k_walk's pass 1 as before.
 template <int W>
-__global__ __launch_bounds__(BLOCK) void k_walk_q(Table<W> t, int k, GraphView g, const u32 *slot_node, u64 max_steps,
+__global__ __launch_bounds__(BLOCK) void k_walk_q(Table<W> t, int k, GraphView g, u64 max_steps,
                                                   unsigned long long *queue, ulonglong2 *stage, unsigned long long *n_long, u32 *err) {
     constexpr u64 CHUNK = 1024;
     const int lane = threadIdx.x & 63;
@@ -466,8 +472,8 @@ __global__ __launch_bounds__(BLOCK) void k_walk_q(Table<W> t, int k, GraphView g
             if (slot < 0) { *err = 1; finished = true; }
             else {
                 const u32 aux = t.slots[slot].aux;
-                if (aux & AUX_TERMINAL) {                                   // nodeMap.contains(seq)  :355
-                    end = slot_node[slot] + (fwd ? 0u : 1u);
+                if (aux & AUX_NODE) {                                       // nodeMap.contains(seq)  :355
+                    end = aux_node(aux, fwd);
                     finished = true;
                 } else {
                     const u32 om = fwd ? ((aux >> 4) & 15u) : rev4(aux & 15u);  // outcoming(seq)     :356
@@ -544,7 +550,7 @@ __global__ __launch_bounds__(BLOCK) void k_place_edges(GraphView g, const ulongl
 // Unitigs by POINTER JUMPING (list ranking) instead of one lane walking each edge base by base:
 // k_walk is one dependent probe per base, so a single 4.6 Mbp unitig (an error-free bacterial
 // genome) costs 2 x 4.6M x ~1 us = 10 s on one lane.  Here every ORIENTED interior k-mer
-// (id = 2*slot + orientation; interior = non-terminal with exactly one successor) starts with a
+// (id = 2 * rank of its slot among the live slots + orientation; interior = non-terminal with exactly one successor) starts with a
 // pointer to its successor and distance 1, pre-terminals (successor is a terminal k-mer) absorb,
 // and log2(longest unitig) rounds of  d[u] += d[next[u]]; next[u] = next[next[u]]  give every
 // interior k-mer its pre-terminal and its distance to it.  From that:
@@ -555,89 +561,131 @@ __global__ __launch_bounds__(BLOCK) void k_place_edges(GraphView g, const ulongl
 // Members of all-(1,1) cycles never absorb and are skipped (Graph.scala:375 "perfect cycles are
 // ignored").  Same results as k_walk (tests run both).
 // ---------------------------------------------------------------------------------------------
-template <int W> __device__ __forceinline__ Kmer<W> oriented_kmer(const Table<W> &t, u64 id, int k) {
-    Kmer<W> y = slot_key(t.slots, id >> 1, t.tagged);
-    return (id & 1) ? revcomp(y, k) : y;
-}
 // unique outgoing base of an interior oriented k-mer (from the slot's masks), -1 if not exactly one
 __device__ __forceinline__ int single_out_base(u32 aux, int ori) {
     const u32 om = ori ? rev4(aux & 15u) : ((aux >> 4) & 15u);
     return __popc(om) == 1 ? __ffs(om) - 1 : -1;
 }
 
-// pointer-jumping state of one oriented k-mer: successor id (itself once absorbed, ~0 if unregistered) and the
-// distance covered so far, side by side so that a jump is ONE 16-byte random read
-struct alignas(16) PjState { u64 nxt; u64 dist; };
-
+// ---- rank of a live slot --------------------------------------------------------------------------------------------
+// The pointer-jumping state is indexed by LIVE KEY, not by slot: one (live mask, live slots before) pair per 64 slots — 0.25
+// bytes per slot — turns a slot index into its rank with one 16-byte read.  (Until round 3 two arrays of 2 x capacity x 16
+// bytes were indexed by slot: 64 B per SLOT, 305 GB for C5's table.)
+struct alignas(16) RankBlk { u64 mask; u64 base; };
+static constexpr u32 RANK_CHUNK = 256;              // 64-slot blocks per chunk (16384 slots): one workgroup, one thread per block
+__device__ __forceinline__ u64 rank_of(const RankBlk *rb, u64 slot) {
+    const RankBlk b = rb[slot >> 6];
+    return b.base + (u64)__popcll(b.mask & ((1ull << (slot & 63)) - 1ull));
+}
 template <int W>
-__global__ __launch_bounds__(BLOCK) void k_pj_init(Table<W> t, int k, PjState *st, u64 *active, unsigned long long *n_active) {
-    __shared__ u32 lds4[BLOCK / 64];
-    __shared__ unsigned long long s_base;
+__global__ __launch_bounds__(BLOCK) void k_rank_masks(Table<W> t, RankBlk *rb, u64 nblk, u32 *chunk_tot, u64 nchunks) {
+    __shared__ u32 s_tot;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u64 ncap = t.capacity();
-    const u64 ngroups = (ncap + BLOCK - 1) / BLOCK;
-    for (u64 grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const u64 i = grp * BLOCK + threadIdx.x;
-        u32 nact = 0;
-        u64 nx[2] = {0, 0};
-        u32 dd[2] = {0, 0};
-        bool act[2] = {false, false};
-        if (i < ncap && slot_live(&t.slots[i])) {
-            const u32 aux = t.slots[i].aux;
-            if (!(aux & (AUX_TERMINAL | AUX_SECONDARY))) {
-                const Kmer<W> y = slot_key(t.slots, i, t.tagged);
-                for (int ori = 0; ori < 2; ori++) {
-                    const int nb = single_out_base(aux, ori);
-                    if (nb < 0) continue;                              // (0,0) k-mers are in no unitig
-                    const Kmer<W> u = ori ? revcomp(y, k) : y;
-                    bool fwd;
-                    const i64 ws = table_find_either(t, append_base(u, nb, k), k, &fwd);
-                    if (ws < 0) continue;
-                    const u64 self = 2 * i + ori;
-                    if (t.slots[ws].aux & AUX_TERMINAL) { nx[ori] = self; dd[ori] = 0; }     // pre-terminal: absorbs
-                    else { nx[ori] = 2 * (u64)ws + (fwd ? 0 : 1); dd[ori] = 1; }
-                    act[ori] = true;
-                    nact++;
-                }
-            }
+    for (u64 c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_tot = 0;
+        __syncthreads();
+        u32 tot = 0;
+        for (u32 j = wave; j < RANK_CHUNK; j += BLOCK / 64) {
+            const u64 blk = c * RANK_CHUNK + j;
+            if (blk >= nblk) break;
+            const u64 i = blk * 64 + lane;
+            const unsigned long long m = __ballot(i < ncap && slot_live(&t.slots[i]));
+            if (lane == 0) rb[blk].mask = m;
+            tot += (u32)__popcll(m);
         }
-        u64 o = block_reserve(nact, n_active, lds4, &s_base);
-        for (int ori = 0; ori < 2; ori++)
-            if (act[ori]) {
-                const u64 self = 2 * i + ori;
-                st[self] = PjState{nx[ori], (u64)dd[ori]};
-                active[o++] = self;
-            }
+        if (lane == 0 && tot) atomicAdd(&s_tot, tot);
+        __syncthreads();
+        if (threadIdx.x == 0) chunk_tot[c] = s_tot;
+    }
+}
+// exclusive scan of the chunk totals: ONE workgroup, every thread a contiguous share (3e5 chunks at C5: ~300 per thread)
+__global__ __launch_bounds__(1024) void k_rank_scan(const u32 *chunk_tot, u64 *chunk_base, u64 nchunks) {
+    __shared__ u64 s_sum[1024];
+    const u64 per = (nchunks + 1023) / 1024, c0 = threadIdx.x * per, c1 = min(c0 + per, nchunks);
+    u64 sum = 0;
+    for (u64 c = c0; c < c1; c++) sum += chunk_tot[c];
+    s_sum[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) { u64 run = 0; for (int i = 0; i < 1024; i++) { const u64 v = s_sum[i]; s_sum[i] = run; run += v; } chunk_base[nchunks] = run; }
+    __syncthreads();
+    u64 run = s_sum[threadIdx.x];
+    for (u64 c = c0; c < c1; c++) { chunk_base[c] = run; run += chunk_tot[c]; }
+}
+__global__ __launch_bounds__(RANK_CHUNK) void k_rank_fill(RankBlk *rb, u64 nblk, const u64 *chunk_base, u64 nchunks) {
+    __shared__ u32 wsum[RANK_CHUNK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (u64 c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const u64 blk = c * RANK_CHUNK + threadIdx.x;
+        const u32 v = blk < nblk ? (u32)__popcll(rb[blk].mask) : 0u;
+        u32 inc = wave_incl_scan(v);
+        __syncthreads();
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        u32 pre = 0;
+        for (int w = 0; w < wave; w++) pre += wsum[w];
+        if (blk < nblk) rb[blk].base = chunk_base[c] + pre + inc - v;
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_pj_round(const u64 *__restrict__ active, u64 n, const PjState *__restrict__ A, PjState *__restrict__ B,
-                                                    u32 *changed) {
+// ---- pointer-jumping state: ONE 64-bit word per oriented live k-mer (index 2 x rank + orientation), updated IN PLACE -------
+//   absorbed (the successor is a terminal k-mer):  PJ_ABS | first base of this oriented k-mer << 32 | node id of that terminal
+//   on its way:                                    successor index << 29 | distance covered so far (saturating)
+//   not registered (terminal, secondary, (0,0)):   ~0
+// A jump reads the successor's word and writes the own one; a reader that meets a word in mid-round sees either the old or
+// the new state of that k-mer — both are true statements "my pointer is d steps ahead of me" — so no second buffer is needed
+// (stale lines in another XCD's L2 are old states too, and kernel boundaries bring everybody up to date).
+static constexpr u64 PJ_ABS = 1ull << 63, PJ_UNREG = ~0ull;
+static constexpr u32 PJ_DBITS = 29;
+static constexpr u64 PJ_DMAX = (1ull << PJ_DBITS) - 1ull;          // 5.4e8 bases: longer unitigs are refused (GK_E_CAPACITY)
+static constexpr u64 PJ_MAX_STATES = 1ull << (63 - PJ_DBITS);      // 2^34 oriented k-mers
+__device__ __forceinline__ u64 pj_pack(u64 nxt, u64 dist) { return (nxt << PJ_DBITS) | min(dist, PJ_DMAX); }
+__device__ __forceinline__ u64 pj_nxt(u64 s) { return s >> PJ_DBITS; }
+__device__ __forceinline__ u64 pj_dist(u64 s) { return s & PJ_DMAX; }
+__device__ __forceinline__ bool pj_absorbed(u64 s) { return (s & PJ_ABS) && s != PJ_UNREG; }
+__device__ __forceinline__ u32 pj_node(u64 s) { return (u32)s; }
+__device__ __forceinline__ int pj_first(u64 s) { return (int)((s >> 32) & 3u); }
+
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_pj_init(Table<W> t, int k, const RankBlk *__restrict__ rb, u64 *st) {
+    const u64 ncap = t.capacity();
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < ncap; i += (u64)gridDim.x * BLOCK) {
+        if (!slot_live(&t.slots[i])) continue;
+        const u32 aux = t.slots[i].aux;
+        if (aux & (AUX_NODE | AUX_TERMINAL | AUX_SECONDARY)) continue;
+        const Kmer<W> y = slot_key(t.slots, i, t.tagged);
+        const u64 r = rank_of(rb, i);
+        for (int ori = 0; ori < 2; ori++) {
+            const int nb = single_out_base(aux, ori);
+            if (nb < 0) continue;                              // (0,0) k-mers are in no unitig
+            const Kmer<W> u = ori ? revcomp(y, k) : y;
+            bool fwd;
+            const i64 ws = table_find_either(t, append_base(u, nb, k), k, &fwd);
+            if (ws < 0) continue;
+            const u32 wa = t.slots[ws].aux;
+            if (wa & AUX_NODE) st[2 * r + ori] = PJ_ABS | ((u64)first_base(u) << 32) | (u64)aux_node(wa, fwd);     // pre-terminal: absorbs
+            else st[2 * r + ori] = pj_pack(2 * rank_of(rb, (u64)ws) + (fwd ? 0u : 1u), 1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_pj_round(u64 *st, u64 n, u32 *changed /* [0] a pointer moved, [1] error */) {
     bool ch = false;
-    for (u64 a = (u64)blockIdx.x * BLOCK + threadIdx.x; a < n; a += (u64)gridDim.x * BLOCK) {
-        const u64 u = active[a];
-        const PjState su = A[u];
-        if (su.nxt == u) { B[u] = su; continue; }           // absorbed
-        const PjState sv = A[su.nxt];                       // the one random read of the round
-        B[u] = PjState{sv.nxt, su.dist + sv.dist};
-        if (sv.nxt != su.nxt) ch = true;                    // the pointer moved: not done yet
+    for (u64 u = (u64)blockIdx.x * BLOCK + threadIdx.x; u < n; u += (u64)gridDim.x * BLOCK) {
+        const u64 su = st[u];
+        if (su & PJ_ABS) continue;                          // absorbed, or not registered
+        const u64 sv = st[pj_nxt(su)];                      // the one random read of the round
+        if (sv == PJ_UNREG) { changed[1] = 8; continue; }   // an interior k-mer's successor is interior or terminal: cannot happen
+        if (sv & PJ_ABS) continue;                          // the pointer is at the chain's pre-terminal: done
+        st[u] = pj_pack(pj_nxt(sv), pj_dist(su) + pj_dist(sv));
+        ch = true;
     }
-    if (ch) *changed = 1;
-}
-
-// terminal reached from a pre-terminal oriented k-mer: node id, or NONE
-template <int W>
-__device__ __forceinline__ u32 pj_end_node(const Table<W> &t, int k, u64 pt, const u32 *slot_node) {
-    const u32 aux = t.slots[pt >> 1].aux;
-    const int nb = single_out_base(aux, (int)(pt & 1));
-    if (nb < 0) return NONE;
-    bool fwd;
-    const i64 ws = table_find_either(t, append_base(oriented_kmer(t, pt, k), nb, k), k, &fwd);
-    if (ws < 0 || !(t.slots[ws].aux & AUX_TERMINAL)) return NONE;
-    return slot_node[ws] + (fwd ? 0u : 1u);
+    if (ch) changed[0] = 1;
 }
 
 template <int W>
-__global__ __launch_bounds__(BLOCK) void k_pj_edges(Table<W> t, int k, GraphView g, const u32 *slot_node, const PjState *st, u32 *err) {
+__global__ __launch_bounds__(BLOCK) void k_pj_edges(Table<W> t, int k, GraphView g, const RankBlk *__restrict__ rb, const u64 *__restrict__ st, u32 *err) {
     for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < g.n_edges; e += (u64)gridDim.x * BLOCK) {
         const u32 n = g.e_start[e];
         const Kmer<W> u0 = append_base(node_kmer<W>(g, n), g.e_first[e], k);
@@ -646,15 +694,16 @@ __global__ __launch_bounds__(BLOCK) void k_pj_edges(Table<W> t, int k, GraphView
         if (s0 < 0) { *err = 1; continue; }
         u32 end = NONE;
         u64 len = 1;
-        if (t.slots[s0].aux & AUX_TERMINAL) {
-            end = slot_node[s0] + (fwd ? 0u : 1u);
+        const u32 a0 = t.slots[s0].aux;
+        if (a0 & AUX_NODE) {
+            end = aux_node(a0, fwd);
         } else {
-            const u64 id0 = 2 * (u64)s0 + (fwd ? 0 : 1);
-            const PjState s_id0 = st[id0];
-            const u64 pt = s_id0.nxt;
-            if (pt >= 2 * t.capacity() || st[pt].nxt != pt) { *err = 4; continue; }   // unregistered / not absorbed: cannot happen from a terminal
-            len = s_id0.dist + 2;
-            end = pj_end_node(t, k, pt, slot_node);
+            const u64 s = st[2 * rank_of(rb, (u64)s0) + (fwd ? 0u : 1u)];
+            u64 sp = s;                                     // the chain's pre-terminal
+            if (!(s & PJ_ABS)) { sp = st[pj_nxt(s)]; len = pj_dist(s) + 2; if (pj_dist(s) == PJ_DMAX) { *err = 9; continue; } }
+            else len = 2;
+            if (!pj_absorbed(sp)) { *err = 4; continue; }   // unregistered / not absorbed: cannot happen on a chain that leaves a node
+            end = pj_node(sp);
         }
         g.e_end[e] = end;
         g.e_len[e] = len;
@@ -669,26 +718,36 @@ __device__ __forceinline__ void pool_or(uint8_t *pool, u64 off, u64 pos, int bas
     atomicOr(w, (u32)base << (((byte & 3) * 8) + (pos & 3) * 2));
 }
 
+// every interior oriented k-mer u places the base that follows it (see the derivation above): a scan over the table's slots
 template <int W>
-__global__ __launch_bounds__(BLOCK) void k_pj_emit(Table<W> t, int k, GraphView g, const u32 *slot_node, const u64 *active, u64 n_active,
-                                                   const PjState *st, u32 *err) {
+__global__ __launch_bounds__(BLOCK) void k_pj_emit(Table<W> t, int k, GraphView g, const RankBlk *__restrict__ rb, const u64 *__restrict__ st, u32 *err) {
     const u64 tid = (u64)blockIdx.x * BLOCK + threadIdx.x, stride = (u64)gridDim.x * BLOCK;
     for (u64 e = tid; e < g.n_edges; e += stride) pool_or(g.pool, g.e_off[e], 0, g.e_first[e]);       // builder += base  :352
-    for (u64 a = tid; a < n_active; a += stride) {
-        const u64 u = active[a], v = u ^ 1;                     // v = rc(u): same slot, other orientation
-        const PjState s_v = st[v];
-        const u64 pt = s_v.nxt, ptu = st[u].nxt, nid = 2 * t.capacity();
-        if (pt >= nid || ptu >= nid) { *err = 7; continue; }    // the partner orientation must have been registered too
-        if (st[pt].nxt != pt || st[ptu].nxt != ptu) continue;   // member of an all-(1,1) cycle
-        const int nb = single_out_base(t.slots[u >> 1].aux, (int)(u & 1));
-        const u32 rs_node = pj_end_node(t, k, pt, slot_node);   // node of rc(s)
-        if (nb < 0 || rs_node == NONE) { *err = 5; continue; }
-        const u32 partner = rs_node ^ 1u;
-        const u32 s_node = g.node_alive[partner] ? partner : rs_node;      // palindromic node: s == rc(s)
-        const int b = 3 - first_base(oriented_kmer(t, pt, k));            // last base of u0 = complement of first base of rc(u0)
-        const u32 e = g.out_edge[(u64)s_node * 4 + b];
-        if (e == NONE) { *err = 6; continue; }
-        pool_or(g.pool, g.e_off[e], s_v.dist + 1, nb);
+    const u64 ncap = t.capacity();
+    for (u64 i = tid; i < ncap; i += stride) {
+        if (!slot_live(&t.slots[i])) continue;
+        const u32 aux = t.slots[i].aux;
+        if (aux & (AUX_NODE | AUX_TERMINAL | AUX_SECONDARY)) continue;
+        const u64 r = rank_of(rb, i);
+        for (int ori = 0; ori < 2; ori++) {
+            const u64 su = st[2 * r + ori];
+            if (su == PJ_UNREG) continue;
+            const u64 sv = st[2 * r + (ori ^ 1)];               // v = rc(u): same slot, other orientation
+            if (sv == PJ_UNREG) { *err = 7; continue; }         // the partner orientation must have been registered too
+            const u64 pu = (su & PJ_ABS) ? su : st[pj_nxt(su)], pv = (sv & PJ_ABS) ? sv : st[pj_nxt(sv)];
+            if (!pj_absorbed(pu) || !pj_absorbed(pv)) continue; // member of an all-(1,1) cycle
+            const u64 dv = (sv & PJ_ABS) ? 0ull : pj_dist(sv);
+            if (dv == PJ_DMAX) { *err = 9; continue; }
+            const int nb = single_out_base(aux, ori);
+            const u32 rs_node = pj_node(pv);                    // node of rc(s)
+            if (nb < 0 || rs_node == NONE) { *err = 5; continue; }
+            const u32 partner = rs_node ^ 1u;
+            const u32 s_node = g.node_alive[partner] ? partner : rs_node;      // palindromic node: s == rc(s)
+            const int b = 3 - pj_first(pv);                     // last base of u0 = complement of the first base of rc(u0)
+            const u32 e = g.out_edge[(u64)s_node * 4 + b];
+            if (e == NONE) { *err = 6; continue; }
+            pool_or(g.pool, g.e_off[e], dv + 1, nb);
+        }
     }
 }
 
@@ -1469,22 +1528,21 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
     gk_ctx *ctx = m->ctx;
     // (m->dirty: keys were inserted verbatim and at least one was not its k-mer's hash-rule orientation — the reference's
     //  `contains` probes both strands unconditionally, Graph.scala:270; so does every lookup below then)
-    Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u, m->dirty ? 1u : 0u, m->aligned ? 1u : 0u};
+    Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u, m->dirty ? 1u : 0u};
     const int k = m->k;
     unsigned long long *d_cnt = nullptr;     // [0] terminals [1] cursor [2] edges [3] ecursor [4] pool cursor
-    u32 *d_err = nullptr, *slot_node = nullptr;
+    u32 *d_err = nullptr;
     u64 *tslots = nullptr;
     int rc = GK_OK;
     hipError_t e = hipMalloc((void **)&d_cnt, 8 * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_err, 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_err, 16);
     if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, 64, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_err, 0, 8, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_err, 0, 16, ctx->stream);
     unsigned long long h_cnt[8] = {0};
     u32 h_err = 0;
     auto done = [&](int code) {
         if (d_cnt) (void)hipFree(d_cnt);
         if (d_err) (void)hipFree(d_err);
-        if (slot_node) (void)hipFree(slot_node);
         if (tslots) (void)hipFree(tslots);
         return code;
     };
@@ -1503,11 +1561,9 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
     if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: classify"));
     lap(0);
     const u64 nT = h_cnt[0];
-    if (2 * nT >= (u64)NONE) return done(fail(ctx, GK_E_CAPACITY, "more than 2^32 graph nodes"));
+    if (2 * nT >= (u64)NONE) return done(fail(ctx, GK_E_CAPACITY, "more than 2^32 graph nodes"));        // (also: j < 2^31 fits AUX_NODE | j)
     // 2. terminal slots -> nodes (both strands) and edge stubs
     e = hipMalloc((void **)&tslots, std::max<u64>(nT, 1) * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&slot_node, m->capacity * 4);
-    if (e == hipSuccess) e = hipMemsetAsync(slot_node, 0xff, m->capacity * 4, ctx->stream);
     if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: alloc nodes"));
     hipLaunchKernelGGL(k_collect_terminals<W>, dim3(ggrid(ctx, m->capacity / 16 + 1)), dim3(BLOCK), 0, ctx->stream, t, k, tslots, &d_cnt[1], &d_cnt[2]);
     e = hipGetLastError();
@@ -1521,7 +1577,7 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
     if ((rc = graph_alloc_edges(g, nE)) != GK_OK) return done(rc);
     g->v.k = k;
     if (nT) {
-        hipLaunchKernelGGL(k_make_nodes<W>, dim3(ggrid(ctx, nT)), dim3(BLOCK), 0, ctx->stream, t, k, tslots, nT, g->v, slot_node, &d_cnt[3]);
+        hipLaunchKernelGGL(k_make_nodes<W>, dim3(ggrid(ctx, nT)), dim3(BLOCK), 0, ctx->stream, t, k, tslots, nT, g->v, &d_cnt[3]);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 32, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1534,39 +1590,51 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
     //    (k_walk) when edges are short; pointer jumping when they are long (see k_pj_* above).
     if (nE) {
         const bool use_pj = ctx->hook_unitigs ? ctx->hook_unitigs == 2 : (m->size / std::max<u64>(nE, 1) >= 16);   // (hook: gk_ctx_set_option "graph_unitigs")
-        PjState *stA = nullptr, *stB = nullptr;
-        u64 *active = nullptr;
+        u64 *st = nullptr;                     // pointer jumping: one word per oriented live k-mer
+        RankBlk *rb = nullptr;                 // ... and the slot -> rank structure
+        u32 *chunk_tot = nullptr;
+        u64 *chunk_base = nullptr;
         ulonglong2 *stage = nullptr;           // queue-fed walk: the first WALK_BUF bases of every edge, 32 bytes each
-        u64 n_active = 0;
         auto pj_free = [&]() {
-            for (void *p : {(void *)stA, (void *)stB, (void *)active, (void *)stage}) if (p) (void)hipFree(p);
-            stA = stB = nullptr; active = nullptr; stage = nullptr;
+            for (void *p : {(void *)st, (void *)rb, (void *)chunk_tot, (void *)chunk_base, (void *)stage}) if (p) (void)hipFree(p);
+            st = nullptr; rb = nullptr; chunk_tot = nullptr; chunk_base = nullptr; stage = nullptr;
         };
         if (use_pj) {
-            const u64 nid = 2 * m->capacity;
-            e = hipMalloc((void **)&stA, nid * sizeof(PjState));
-            if (e == hipSuccess) e = hipMalloc((void **)&stB, nid * sizeof(PjState));
-            if (e == hipSuccess) e = hipMalloc((void **)&active, std::max<u64>(2 * m->size, 1) * 8);
-            if (e == hipSuccess) e = hipMemsetAsync(stA, 0xff, nid * sizeof(PjState), ctx->stream);       // unregistered ids are out of range
+            // what is alive here besides the table: 16 B per live key (st) + 0.25 B per slot (rb) — DESIGN.md section 6
+            const u64 nstates = 2 * m->size, nblk = (m->capacity + 63) / 64, nchunks = (nblk + RANK_CHUNK - 1) / RANK_CHUNK;
+            if (nstates >= PJ_MAX_STATES) return done(fail(ctx, GK_E_CAPACITY, "more than 2^33 k-mers: beyond the pointer-jumping state's index"));
+            e = hipMalloc((void **)&rb, nblk * sizeof(RankBlk));
+            if (e == hipSuccess) e = hipMalloc((void **)&chunk_tot, nchunks * 4);
+            if (e == hipSuccess) e = hipMalloc((void **)&chunk_base, (nchunks + 1) * 8);
+            if (e == hipSuccess) e = hipMalloc((void **)&st, std::max<u64>(nstates, 1) * 8);
+            if (e == hipSuccess) e = hipMemsetAsync(st, 0xff, std::max<u64>(nstates, 1) * 8, ctx->stream);         // PJ_UNREG
             if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: pointer-jumping arrays")); }
-            hipLaunchKernelGGL(k_pj_init<W>, dim3(ggrid(ctx, m->capacity)), dim3(BLOCK), 0, ctx->stream, t, k, stA, active, &d_cnt[5]);
+            hipLaunchKernelGGL(k_rank_masks<W>, dim3((int)std::min<u64>(nchunks, (u64)ctx->cu_count * 8)), dim3(BLOCK), 0, ctx->stream, t, rb, nblk, chunk_tot, nchunks);
+            hipLaunchKernelGGL(k_rank_scan, dim3(1), dim3(1024), 0, ctx->stream, chunk_tot, chunk_base, nchunks);
+            hipLaunchKernelGGL(k_rank_fill, dim3((int)std::min<u64>(nchunks, (u64)ctx->cu_count * 8)), dim3(RANK_CHUNK), 0, ctx->stream, rb, nblk, chunk_base, nchunks);
+            unsigned long long ranked = 0;
             e = hipGetLastError();
-            if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 48, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&ranked, chunk_base + nchunks, 8, hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: pj init")); }
-            n_active = h_cnt[5];
-            for (int round = 0; round < 64 && n_active; round++) {
-                u32 changed = 0;
-                e = hipMemsetAsync(d_err + 1, 0, 4, ctx->stream);
+            if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: slot ranks")); }
+            if (ranked != m->size) { pj_free(); return done(fail(ctx, GK_E_STATE, "live slots (" + std::to_string(ranked) + ") differ from the map's size (" + std::to_string(m->size) + ")")); }
+            hipLaunchKernelGGL(k_pj_init<W>, dim3(ggrid(ctx, m->capacity)), dim3(BLOCK), 0, ctx->stream, t, k, rb, st);
+            e = hipGetLastError();
+            // a chain of n k-mers is resolved after ceil(log2 n) rounds; what still moves then is an all-(1,1) cycle (Graph.scala:375)
+            int max_rounds = 2;
+            while ((1ull << (max_rounds - 2)) < std::max<u64>(nstates, 2)) max_rounds++;
+            for (int round = 0; round < max_rounds && nstates && e == hipSuccess; round++) {
+                u32 flags[2] = {0, 0};
+                e = hipMemsetAsync(d_err + 1, 0, 8, ctx->stream);      // (d_err has 4 words: [0] the build's error, [1] moved, [2] round error)
                 if (e != hipSuccess) break;
-                hipLaunchKernelGGL(k_pj_round, dim3(ggrid(ctx, n_active)), dim3(BLOCK), 0, ctx->stream, active, n_active, stA, stB, d_err + 1);
-                e = hipMemcpyAsync(&changed, d_err + 1, 4, hipMemcpyDeviceToHost, ctx->stream);
+                hipLaunchKernelGGL(k_pj_round, dim3(ggrid(ctx, nstates)), dim3(BLOCK), 0, ctx->stream, st, nstates, d_err + 1);
+                e = hipMemcpyAsync(flags, d_err + 1, 8, hipMemcpyDeviceToHost, ctx->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-                std::swap(stA, stB);
-                if (e != hipSuccess || !changed) break;
+                if (e == hipSuccess && flags[1]) { pj_free(); return done(fail(ctx, GK_E_STATE, "pointer jumping met an unregistered successor (code " + std::to_string(flags[1]) + ")")); }
+                if (!flags[0]) break;
             }
             if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: pj rounds")); }
-            hipLaunchKernelGGL(k_pj_edges<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node, stA, d_err);
+            hipLaunchKernelGGL(k_pj_edges<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, rb, st, d_err);
         } else {
             // every oriented interior k-mer lies on exactly one edge: sum of lengths <= edges + 2 x live keys, and every edge
             // rounds up to a byte — the pool can be allocated before the walk, so the walk can write as it goes
@@ -1574,12 +1642,12 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
             e = hipMalloc((void **)&g->v.pool, g->pool_cap);
             if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: pool")); }
             if (ctx->hook_walk_queue == 0)        // ("graph_walk_queue": 0 = one edge per lane, the round-1 form; A/B)
-                hipLaunchKernelGGL(k_walk<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node, 0, m->capacity + 1, &d_cnt[4], &d_cnt[6], d_err);
+                hipLaunchKernelGGL(k_walk<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, 0, m->capacity + 1, &d_cnt[4], &d_cnt[6], d_err);
             else {
                 e = hipMalloc((void **)&stage, std::max<u64>(nE, 1) * 32);
                 if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: edge staging")); }
                 const int gq = (int)std::min<u64>((nE + 4 * BLOCK - 1) / (4 * BLOCK), (u64)ctx->cu_count * 8);
-                hipLaunchKernelGGL(k_walk_q<W>, dim3(std::max(gq, 1)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node, m->capacity + 1, &d_cnt[7], stage, &d_cnt[6], d_err);
+                hipLaunchKernelGGL(k_walk_q<W>, dim3(std::max(gq, 1)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, m->capacity + 1, &d_cnt[7], stage, &d_cnt[6], d_err);
                 hipLaunchKernelGGL(k_place_edges, dim3(ggrid(ctx, nE / 8 + 1)), dim3(BLOCK), 0, ctx->stream, g->v, stage, &d_cnt[4]);
             }
         }
@@ -1610,13 +1678,12 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
         if (use_pj) {
             e = hipMemsetAsync(g->v.pool, 0, g->pool_cap, ctx->stream);
             if (e == hipSuccess) {
-                hipLaunchKernelGGL(k_pj_emit<W>, dim3(ggrid(ctx, std::max<u64>(n_active, nE))), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node,
-                                   active, n_active, stA, d_err);
+                hipLaunchKernelGGL(k_pj_emit<W>, dim3(ggrid(ctx, std::max<u64>(m->capacity, nE))), dim3(BLOCK), 0, ctx->stream, t, k, g->v, rb, st, d_err);
                 e = hipGetLastError();
             }
             if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream);
         } else if (h_cnt[6]) {       // edges longer than the walk's register buffer: second walk, emitting
-            hipLaunchKernelGGL(k_walk<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, slot_node, 1, m->capacity + 1, &d_cnt[4], &d_cnt[6], d_err);
+            hipLaunchKernelGGL(k_walk<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, 1, m->capacity + 1, &d_cnt[4], &d_cnt[6], d_err);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

@@ -34,13 +34,13 @@ struct gk_ctx {
     int hook_max_nb2 = 0;            // test hook: the partitioned path refuses tables of more fine buckets per L1 bucket than this (0: MAX_NB2), so that
                                      // a batch that outgrows the fan-out between its levels can be staged with a small table
     int hook_min_lnb1 = 0;           // test hook: tables of enough segments get at least 2^this L1 buckets (9, 10: the fan-out of tables beyond 34 GB)
+    int hook_dist_small_send = 0;    // test hook: the next gk_dist_route_begin on this context gets a send buffer of so many records (forces the in-place re-route)
+    int hook_dist_fail = 0;          // test hook: this context's next exchange fails locally with this code before anything is posted (the peers must drop the batch too)
     int hook_dist_ahead = -1;        // gk_dist_count_routed with three batches begun: 0 = do not post the next batch's exchange ahead (every rank alike)
     int hook_p24_pieces = -1;        // pipelined batch (both levels over-provisioned): pieces whose P4 overlaps the next piece's scatter (-1: default, 0/1: off)
     int hook_p45_stripes = -1;       // over-provisioned fine level: stripes of L1 buckets whose P5 overlaps the next stripe's P4 (-1/1: none)
     int hook_graph_load_pct = -1;    // load factor (percent) of the table map_compact builds for the graph phase (-1: 40, 30 at k = 64)
     int hook_filter_classic = -1;    // deleteAll: 1 = tombstones + k_rehash (the older path), else the one-pass segment-wise filter + compaction
-    int hook_graph_aligned = -1;     // compacted table: 1 = probes start at the first slot of a 128-byte line (A/B; loses), else anywhere
-    int hook_graph_mem = -1;         // memory kind of the compacted table the graph phase reads: 0 ordinary, 1 uncached, 2 fine-grained (A/B)
     int hook_walk_queue = -1;        // unitig walk: 0 = one edge per lane (k_walk pass 0), else lanes fed from a queue (k_walk_q)
     int hook_p4_grid = -1;           // over-provisioned fine level: P4 workgroups per CU (-1: 4, or 2 of the 1024-thread form)
     int hook_p4_wide = -1;           // exact fine level, 8-byte keys: -1 auto (by nb2), 0 sort 4096 keys at a time, 1 sort 8192 (1024 threads)
@@ -52,6 +52,8 @@ struct gk_ctx {
     std::multimap<size_t, void *> pool_free_blocks;          // by size
     std::unordered_map<void *, size_t> pool_sizes;           // every block the pool has handed out or holds
     size_t pool_held = 0, pool_limit = 0;                    // bytes parked; cap (a third of the device's memory)
+    size_t pool_live = 0, pool_peak = 0;                     // bytes handed out (blocks of 1 MiB and more) and their high-water mark (gk_ctx_mem_stats)
+    size_t mem_budget = 0;                                   // gk_ctx_set_mem_budget: plan as if the device had this much memory (0: all of it)
     uint64_t pool_hits = 0, pool_misses = 0;
     std::recursive_mutex pool_mu;                            // (gk_dist's helper thread grows its buffers beside the owner pipeline)
     std::string err;
@@ -88,6 +90,8 @@ struct PartScratch;
 hipError_t pool_malloc(gk_ctx *ctx, void **p, size_t bytes);
 hipError_t pool_free(gk_ctx *ctx, void *p);
 void pool_release(gk_ctx *ctx);                              // hipFree everything parked
+size_t mem_available(gk_ctx *ctx);                           // free + parked, or what the caller's budget leaves
+double graph_table_load(gk_ctx *ctx, int k, uint64_t keys);  // load factor of a table the graph phase will read
 }
 
 struct gk_map {
@@ -107,8 +111,6 @@ struct gk_map {
     uint64_t total_occurrences = 0;
     uint64_t grows = 0;
     bool skewed = false;         // a batch overflowed the pipeline's L1 regions and spill list (pathological skew): auto mode stays on the direct path
-    bool aligned = false;        // this table's probes start at the first slot of a 128-byte line (Table::aligned; set by map_compact,
-                                 // dropped when the contents are cleared)
     bool dirty = false;          // the table may hold keys that are not the hash-rule orientation of their k-mer (verbatim inserts):
                                  // Graph.buildGraph's `contains` then probes both strands, as the reference does (Graph.scala:270)
     bool sample_dirty = false;   // the distinct-key sample holds keys: gk_map_clear must reset it
@@ -152,7 +154,7 @@ int hip_fail(const gk_ctx *ctx, hipError_t e, const char *what);
 
 inline bool k_supported(int k) { return (k >= 2 && k <= 31) || (k >= 34 && k <= 64); }
 inline int words_for_k(int k) { return k <= 32 ? 1 : 2; }
-inline size_t slot_bytes(int W) { return W == 1 ? 16 : 32; }
+inline size_t slot_bytes(int W) { return W == 1 ? 16 : 24; }      // sizeof(gk::Slot<W>)
 inline uint32_t seg_bits_for(int W) { return W == 1 ? gk::SegBits<1>::value : gk::SegBits<2>::value; }
 // segment geometry for at least `want_slots` slots: nb1 = 2^lnb1 L1 buckets x nb2 fine buckets.  256 L1 buckets at most
 // — unless that would take more fine buckets per L1 bucket than the partitioned insert pipeline handles (PLAN_MAX_NB2):
@@ -186,6 +188,8 @@ int map_materialize(gk_map *m);                      // run a deferred clear so 
 int map_add_keys_direct(gk_map *m, const uint64_t *d_keys, uint64_t n);   // k_add_keys on device keys (W words each)
 int map_insert_keys_dev(gk_map *m, const uint64_t *d_keys, uint64_t n, bool verbatim);
 int map_add_counted_keys_dev(gk_map *m, const uint64_t *d_keys, const int32_t *d_counts, uint64_t n);   // update(key, c, _ + c), canonical device keys   // update(key, 1, _+1) for device keys, either path
+int map_export_range_dev(gk_map *m, uint64_t s0, uint64_t s1, uint64_t *d_keys, int32_t *d_cnt, unsigned long long *d_cursor, uint64_t *n_out);
+int map_create_for_graph(gk_ctx *ctx, int k, uint64_t keys, gk_map **out);      // a new map sized the way the graph phase wants it
 void *map_scratch(gk_map *m, size_t bytes);          // pooled scratch (grown, never shrunk); nullptr + error set on failure
 // partitioned path (part_count may return PART_RETRY_DIRECT: take the direct path for this batch)
 constexpr int PART_RETRY_DIRECT = 1;

@@ -1035,27 +1035,21 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W> t, const u64 
         if (cnt == 0) {
             if (from_empty) {       // materialise the pending clear of a segment that gets no key
 #pragma unroll
-                for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) {
-                    if constexpr (W == 1) gseg[i] = make_uint4(~0u, ~0u, 0u, 0u);
-                    else gseg[i] = (i & 1) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
-                }
+                for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) gseg[i] = empty_vec<W>(i);
             }
         } else {
             __syncthreads();
             if (threadIdx.x < 3) flags[threadIdx.x] = 0;
             if (from_empty) {
 #pragma unroll
-                for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) {
-                    if constexpr (W == 1) lds_raw[i] = make_uint4(~0u, ~0u, 0u, 0u);
-                    else lds_raw[i] = (i & 1) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
-                }
+                for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) lds_raw[i] = empty_vec<W>(i);
             } else {
                 u32 nfree = 0;                                  // a slot is free iff its first key word is EMPTY
 #pragma unroll
                 for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) {
                     const uint4 v = gseg[i];
                     lds_raw[i] = v;
-                    if ((W == 1 || !(i & 1)) && (v.x & v.y) == ~0u) nfree++;
+                    nfree += empty_w0_in_vec<W>(i, v);
                 }
                 __syncthreads();                                // flags[2] = 0 is visible
                 for (int d = 32; d; d >>= 1) nfree += __shfl_down(nfree, d);
@@ -1098,10 +1092,7 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W> t, const u64 
                 // segment full: leave the HBM copy as it was (or EMPTY) and hand the bucket to the host,
                 // which grows the table and replays these keys through the direct path
                 if (from_empty)
-                    for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) {
-                        if constexpr (W == 1) gseg[i] = make_uint4(~0u, ~0u, 0u, 0u);
-                        else gseg[i] = (i & 1) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
-                    }
+                    for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) gseg[i] = empty_vec<W>(i);
                 if (threadIdx.x == 0) a.failed[atomicAdd(a.n_failed, 1u)] = (u32)s;
             } else {
 #pragma unroll
@@ -1277,7 +1268,7 @@ template <int W>
 static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d_keys, u64 nkeys_in, u64 nkeys_bound, bool from_empty,
                     const PartPlan &plan) {
     gk_ctx *ctx = m->ctx;
-    Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u, 0u, m->aligned ? 1u : 0u};
+    Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u, 0u};
     PartArrays a;
     const uint8_t *d_rec = src.rec;
     const u32 *d_off = src.off;
@@ -1559,7 +1550,7 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
                 const u64 ahead = (u64)((double)est_new * (1.0 + 0.6 * (std::max(plan.grow_ahead, 1.0) - 1.0)));
                 if (int rc = map_make_room(m, est_new, ahead, from_empty, true)) return rc;     // may replace the table (same lnb1: P2 has cut the batch by L1 bucket)
             }
-            t = Table<W>{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u, 0u, m->aligned ? 1u : 0u};
+            t = Table<W>{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u, 0u};
             // many repeats: segment sizes are far from binomial -> exact fine level
             fine_exact = !op1 || plan.fine_exact || (double)est_new < 0.5 * (double)nkeys_bound;
         }

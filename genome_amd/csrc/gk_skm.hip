@@ -252,12 +252,14 @@ int skm_route_launch(gk_ctx *ctx, hipStream_t st, unsigned long long *d_counts, 
     const u64 ntiles = (nreads + TILE_READS - 1) / TILE_READS;
     const int grid = (int)std::min<u64>(ntiles, (u64)ctx->cu_count * 6);
     const uint8_t *rec = (const uint8_t *)dev_records;
+    // the last counter word: [0] a region overflowed, [1] a record's length byte exceeded read_len (clamped).  Both travel back
+    // with the counts, so whoever finishes the route — on any thread — needs no other stream and no shared flag word.
     u32 *d_overflow = reinterpret_cast<u32 *>(d_counts + 2 * MAX_PARTS);
     if (skm_slot_bytes(k) == 16)
-        hipLaunchKernelGGL(k_skm_route<16>, dim3(grid), dim3(BLOCK), 0, st, rec, nreads, stride, k, P, WindowLimits{read_len, ctx->d_flags}, region_cap, d_counts,
+        hipLaunchKernelGGL(k_skm_route<16>, dim3(grid), dim3(BLOCK), 0, st, rec, nreads, stride, k, P, WindowLimits{read_len, d_overflow + 1}, region_cap, d_counts,
                            d_counts + MAX_PARTS, d_overflow, (uint8_t *)dev_out);
     else
-        hipLaunchKernelGGL(k_skm_route<32>, dim3(grid), dim3(BLOCK), 0, st, rec, nreads, stride, k, P, WindowLimits{read_len, ctx->d_flags}, region_cap, d_counts,
+        hipLaunchKernelGGL(k_skm_route<32>, dim3(grid), dim3(BLOCK), 0, st, rec, nreads, stride, k, P, WindowLimits{read_len, d_overflow + 1}, region_cap, d_counts,
                            d_counts + MAX_PARTS, d_overflow, (uint8_t *)dev_out);
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipMemcpyAsync(h_counts, d_counts, SKM_COUNT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
@@ -273,10 +275,11 @@ int skm_route_finish(gk_ctx *ctx, const unsigned long long *h, bool launched, in
         worst = std::max(worst, h[p]);
     }
     if (!launched) return GK_OK;
+    if ((u32)(h[2 * MAX_PARTS] >> 32)) return fail(ctx, GK_E_FORMAT, "a device record's length byte exceeds the declared read length");
     if ((u32)h[2 * MAX_PARTS] || worst > region_cap)
         return fail(ctx, GK_E_CAPACITY, "record buffer too small: the fullest owner region needs " + std::to_string(worst) +
                                             " records, out_cap_records / P = " + std::to_string(region_cap));
-    return ctx_check_format(ctx);
+    return GK_OK;
 }
 }  // namespace gk
 

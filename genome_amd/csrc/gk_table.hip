@@ -54,7 +54,7 @@ template <int W> __global__ __launch_bounds__(BLOCK) void k_clear(Slot<W> *slots
         if constexpr (W == 1) {
             slots[i] = Slot<1>{KEY_EMPTY, 0u, 0u};
         } else {
-            slots[i] = Slot<2>{KEY_EMPTY, KEY_EMPTY, 0u, 0u, 0ull};
+            slots[i] = Slot<2>{KEY_EMPTY, KEY_EMPTY, 0u, 0u};
         }
     }
 }
@@ -191,10 +191,7 @@ __global__ __launch_bounds__(CBLOCK) void k_compact_seg(Table<W> old, Table<W> n
         const u32 b1 = (u32)(sn / nw.nb2), fn = (u32)(sn % nw.nb2);
         __syncthreads();
         if (threadIdx.x == 0) { s_kept = 0; s_err = 0; }
-        for (u32 i = threadIdx.x; i < NVEC; i += CBLOCK) {
-            if constexpr (W == 1) cseg_raw[i] = make_uint4(~0u, ~0u, 0u, 0u);
-            else cseg_raw[i] = (i & 1) ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
-        }
+        for (u32 i = threadIdx.x; i < NVEC; i += CBLOCK) cseg_raw[i] = empty_vec<W>(i);
         // the 32 hash bits x with seg_fine(nw, .) == fn: [xlo, xhi); the old fine buckets they fall into: f0 .. f1
         const u64 xlo = (((u64)fn << 32) + nw.nb2 - 1) / nw.nb2, xhi = ((((u64)fn + 1) << 32) + nw.nb2 - 1) / nw.nb2;
         const u32 f0 = (u32)((xlo * old.nb2) >> 32), f1 = (u32)(((xhi - 1) * old.nb2) >> 32);
@@ -330,6 +327,37 @@ __global__ __launch_bounds__(BLOCK) void k_export(const Slot<W> *__restrict__ sl
     }
 }
 
+// live (key, count) of a RANGE of slots, packed: keys interleaved W words each (what k_add_keys takes), counts apart.
+// `first` = index of slots[0] in its table (a multiple of the segment size: a tagged slot's last base is its index mod 4).
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_export_packed(const Slot<W> *__restrict__ slots, u64 n, u64 first, u32 tagged, u64 *keys, i32 *cnt,
+                                                         unsigned long long *cursor) {
+    __shared__ unsigned long long s_base;
+    __shared__ u32 wsum[BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 ngroups = (n + BLOCK - 1) / BLOCK;
+    for (u64 g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const u64 i = g * BLOCK + threadIdx.x;
+        const bool live = i < n && slot_live(&slots[i]);
+        const unsigned long long b = __ballot(live);
+        const u32 wprefix = (u32)__popcll(b & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (lane == 0) wsum[wave] = (u32)__popcll(b);
+        __syncthreads();
+        u32 base = 0, tot = 0;
+        for (int w = 0; w < BLOCK / 64; ++w) { if (w < wave) base += wsum[w]; tot += wsum[w]; }
+        if (threadIdx.x == 0 && tot) s_base = atomicAdd(cursor, (unsigned long long)tot);
+        __syncthreads();
+        if (live) {
+            const Kmer<W> key = from_stored(load_stored(&slots[i]), tagged ? (u32)((first + i) & 3u) : 0u);
+            const u64 o = s_base + base + wprefix;
+            if constexpr (W == 1) keys[o] = key.lo;
+            else { keys[2 * o] = key.lo; keys[2 * o + 1] = key.hi; }
+            cnt[o] = (i32)slot_count(&slots[i]);
+        }
+    }
+}
+
 // ============================================================================================
 // host side
 // ============================================================================================
@@ -341,15 +369,12 @@ static inline int grid_for(const gk_ctx *ctx, u64 work_items, int per_block) {
 }
 
 template <int W> static Table<W> table_of(const gk_map *m) {
-    return Table<W>{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u, 0u, m->aligned ? 1u : 0u};
+    return Table<W>{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u, 0u};
 }
 
-// mem_kind: 0 = ordinary device memory (pooled); 1 = hipDeviceMallocUncached, 2 = hipDeviceMallocFinegrained (A/B of the
-// table the graph phase reads: every read request of ordinary memory is a 128-byte line, whatever the lane asked for)
 static int streaming_rebuild(gk_map *m, uint32_t nnb2, uint32_t nlnb1, uint64_t ncap, int32_t rounds, bool *done);     // (defined next to its kernel's host code)
-static int alloc_table(gk_ctx *ctx, int W, uint64_t cap, void **out, int mem_kind = 0) {
-    if (mem_kind == 0) GK_HIP(ctx, hipMalloc(out, cap * slot_bytes(W)));
-    else GK_HIP(ctx, hipExtMallocWithFlags(out, cap * slot_bytes(W), mem_kind == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained));
+static int alloc_table(gk_ctx *ctx, int W, uint64_t cap, void **out) {
+    GK_HIP(ctx, hipMalloc(out, cap * slot_bytes(W)));
     int grid = grid_for(ctx, cap, BLOCK * 4);
     if (W == 1) hipLaunchKernelGGL(k_clear<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (Slot<1> *)*out, cap);
     else hipLaunchKernelGGL(k_clear<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (Slot<2> *)*out, cap);
@@ -369,6 +394,8 @@ hipError_t pool_malloc(gk_ctx *ctx, void **p, size_t bytes) {
     if (it != ctx->pool_free_blocks.end() && it->first <= bytes + bytes / 2) {
         *p = it->second;
         ctx->pool_held -= it->first;
+        ctx->pool_live += it->first;
+        ctx->pool_peak = std::max(ctx->pool_peak, ctx->pool_live);
         ctx->pool_free_blocks.erase(it);
         ctx->pool_hits++;
         return hipSuccess;
@@ -379,7 +406,12 @@ hipError_t pool_malloc(gk_ctx *ctx, void **p, size_t bytes) {
         pool_release(ctx);
         e = (hipMalloc)(p, bytes);
     }
-    if (e == hipSuccess) { ctx->pool_sizes[*p] = bytes; ctx->pool_misses++; }
+    if (e == hipSuccess) {
+        ctx->pool_sizes[*p] = bytes;
+        ctx->pool_misses++;
+        ctx->pool_live += bytes;
+        ctx->pool_peak = std::max(ctx->pool_peak, ctx->pool_live);
+    }
     return e;
 }
 hipError_t pool_free(gk_ctx *ctx, void *p) {
@@ -388,9 +420,12 @@ hipError_t pool_free(gk_ctx *ctx, void *p) {
     auto it = ctx->pool_sizes.find(p);
     if (it == ctx->pool_sizes.end()) return (hipFree)(p);
     const size_t bytes = it->second;
-    // (hipFree waits for the device; a parked block may be handed out again at once, so wait for this context's work here)
+    ctx->pool_live -= std::min(ctx->pool_live, bytes);
+    // (hipFree waits for the device; a parked block may be handed out again at once, so wait for this context's work here:
+    //  all three of its streams — the pipelined pieces of a batch run on the auxiliary one)
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess && ctx->copy_stream) e = hipStreamSynchronize(ctx->copy_stream);
+    if (e == hipSuccess && ctx->aux_stream) e = hipStreamSynchronize(ctx->aux_stream);
     if (e != hipSuccess || ctx->pool_held + bytes > ctx->pool_limit) {
         ctx->pool_sizes.erase(it);
         const hipError_t e2 = (hipFree)(p);
@@ -399,6 +434,33 @@ hipError_t pool_free(gk_ctx *ctx, void *p) {
     ctx->pool_free_blocks.emplace(bytes, p);
     ctx->pool_held += bytes;
     return hipSuccess;
+}
+// what sizing decisions may count on: free device memory plus what the pool has parked, or what a caller-set budget leaves
+size_t mem_available(gk_ctx *ctx) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+    std::lock_guard<std::recursive_mutex> lock(ctx->pool_mu);
+    size_t avail = free_b + ctx->pool_held;
+    if (ctx->mem_budget) avail = std::min(avail, ctx->mem_budget > ctx->pool_live ? ctx->mem_budget - ctx->pool_live : (size_t)0);
+    return avail;
+}
+// Load factor of a table the graph phase will read.  What follows deleteAll / the gather is read-only: 8 lookups per key of
+// which ~6 MISS, and a miss in a linearly probed table walks (1 + 1/(1-load)^2)/2 slots; measured at C3 (1.28e8 keys),
+// classify / unitig walk / buildGraph in ms: load 0.25 35 / 17 / 59, 0.40 44 / 21 / 70, 0.60 75 / 29 / 109, 0.75 171 / 44 / 219.
+// So: as sparse as 0.25 while the table stays under a third of what is available, denser in steps when it would not — the
+// table PLUS what gk_graph_build puts beside it (16.3 bytes per key in the pointer-jumping form) must fit 80 % of it.  C5's
+// replica (3.1e9 63-mers in 288 GB) lands at 0.55, C4's (1.5e9 55-mers) at 0.4: DESIGN.md section 6 has the byte table.
+double graph_table_load(gk_ctx *ctx, int k, uint64_t keys) {
+    if (ctx->hook_graph_load_pct > 0) return ctx->hook_graph_load_pct / 100.0;       // ("graph_load_pct": A/B)
+    const double avail = (double)mem_available(ctx), sb = (double)slot_bytes(words_for_k(k)), beside = 17.0 * (double)keys;
+    const double steps64[] = {0.2, 0.3, 0.45}, steps[] = {0.25, 0.4, 0.55, 0.7};
+    const double *st = k == 64 ? steps64 : steps;
+    const int n = k == 64 ? 3 : 4;
+    for (int i = 0; i < n; i++) {
+        const double tb = (double)keys * sb / st[i];
+        if (i == 0 ? (tb <= avail / 3.0 && tb + beside <= 0.8 * avail) : (tb + beside <= 0.8 * avail)) return st[i];
+    }
+    return st[n - 1];
 }
 void pool_release(gk_ctx *ctx) {
     std::lock_guard<std::recursive_mutex> lock(ctx->pool_mu);
@@ -470,10 +532,10 @@ static int map_grow_to(gk_map *m, uint64_t want_slots, bool rehash, bool keep_ln
         int grid = grid_for(ctx, m->capacity, BLOCK);
         if (m->W == 1)
             hipLaunchKernelGGL(k_rehash<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, m->capacity,
-                               Table<1>{(Slot<1> *)nslots, nnb2, nlnb1, 0u, 0u, m->aligned ? 1u : 0u}, m->d_ctr);
+                               Table<1>{(Slot<1> *)nslots, nnb2, nlnb1, 0u, 0u}, m->d_ctr);
         else
             hipLaunchKernelGGL(k_rehash<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots, m->capacity,
-                               Table<2>{(Slot<2> *)nslots, nnb2, nlnb1, m->k == 64 ? 1u : 0u, 0u, m->aligned ? 1u : 0u}, m->d_ctr);
+                               Table<2>{(Slot<2> *)nslots, nnb2, nlnb1, m->k == 64 ? 1u : 0u, 0u}, m->d_ctr);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { (void)hipFree(nslots); return hip_fail(ctx, e, "table rehash"); }
@@ -620,7 +682,25 @@ int gk_ctx_trim(gk_ctx *ctx) {
     GK_HIP(ctx, hipSetDevice(ctx->device));
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     GK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    if (ctx->aux_stream) GK_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
     gk::pool_release(ctx);
+    return GK_OK;
+}
+
+int gk_ctx_mem_stats(gk_ctx *ctx, uint64_t *live, uint64_t *peak, uint64_t *parked, int reset_peak) {
+    if (!ctx) return fail(nullptr, GK_E_INVALID, "gk_ctx_mem_stats: null context");
+    std::lock_guard<std::recursive_mutex> lock(ctx->pool_mu);
+    if (live) *live = ctx->pool_live;
+    if (peak) *peak = ctx->pool_peak;
+    if (parked) *parked = ctx->pool_held;
+    if (reset_peak) ctx->pool_peak = ctx->pool_live;
+    return GK_OK;
+}
+
+int gk_ctx_set_mem_budget(gk_ctx *ctx, uint64_t bytes) {
+    if (!ctx) return fail(nullptr, GK_E_INVALID, "gk_ctx_set_mem_budget: null context");
+    std::lock_guard<std::recursive_mutex> lock(ctx->pool_mu);
+    ctx->mem_budget = (size_t)bytes;
     return GK_OK;
 }
 
@@ -643,6 +723,8 @@ int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value) {
     else if (n == "p45_stripes") ctx->hook_p45_stripes = (int)value;
     else if (n == "p24_pieces") ctx->hook_p24_pieces = (int)value;
     else if (n == "dist_exchange_ahead") ctx->hook_dist_ahead = (int)value;
+    else if (n == "test_dist_small_send") ctx->hook_dist_small_send = (int)std::max<int64_t>(0, value);
+    else if (n == "test_dist_fail_exchange") ctx->hook_dist_fail = value > 0 ? -(int)value : (int)value;
     else if (n == "test_max_nb2") ctx->hook_max_nb2 = (int)std::max<int64_t>(0, value);
     else if (n == "min_lnb1") {
         if (value < 0 || value > (int64_t)gk::MAX_LNB1) return fail(ctx, GK_E_INVALID, "min_lnb1: 0..10");
@@ -650,8 +732,6 @@ int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value) {
     }
     else if (n == "p4_grid") ctx->hook_p4_grid = (int)value;
     else if (n == "graph_walk_queue") ctx->hook_walk_queue = (int)value;
-    else if (n == "graph_mem") ctx->hook_graph_mem = (int)value;
-    else if (n == "graph_aligned") ctx->hook_graph_aligned = (int)value;
     else if (n == "filter_classic") ctx->hook_filter_classic = (int)value;
     else if (n == "graph_load_pct") ctx->hook_graph_load_pct = (int)value;
     else if (n == "fine_exact") ctx->hook_fine_exact = value < 0 ? -1 : value != 0;
@@ -815,6 +895,14 @@ int gk_map_create(gk_ctx *ctx, int k, uint64_t capacity_hint, gk_map **out) {
     return GK_OK;
 }
 
+int gk_map_create_for_graph(gk_ctx *ctx, int k, uint64_t keys, gk_map **out) {
+    if (!ctx || !out) return fail(ctx, GK_E_INVALID, "gk_map_create_for_graph: null argument");
+    *out = nullptr;
+    if (!k_supported(k)) return fail(ctx, GK_E_UNSUPPORTED_K, "k=" + std::to_string(k) + " unsupported (2..31 and 34..64)");
+    GK_HIP(ctx, hipSetDevice(ctx->device));
+    return map_create_for_graph(ctx, k, keys, out);
+}
+
 void gk_map_destroy(gk_map *m) {
     if (!m) return;
     gk_ctx *ctx = m->ctx;
@@ -856,7 +944,6 @@ int gk_map_clear(gk_map *m) {
     m->tombstones = 0;
     m->total_occurrences = 0;
     m->dirty = false;
-    m->aligned = false;          // (the contents are void: the next build uses the count table's rule again)
     return GK_OK;
 }
 
@@ -997,11 +1084,11 @@ static u64 part_batch_keys(gk_map *m) {
     u64 cap = m->max_batch_keys ? m->max_batch_keys : (1ull << 31) / (u64)m->W;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-        const gk::PartScratch *ps = m->part;
-        (void)ps;
         const double per_key = 8.0 * m->W * (1.125 + 1.0 + 1.0 / 16) + 1.0;      // bufA + bufB + spill (+ range matrix, bounded above)
         // the scratch a previous batch left allocated is reused, so it counts as available: approximate by a share of the whole card
-        const double avail = std::max((double)free_b + (double)m->ctx->pool_held, 0.35 * (double)total_b);
+        // (a caller-set memory budget replaces the card's size)
+        const double whole = m->ctx->mem_budget ? (double)m->ctx->mem_budget : (double)total_b;
+        const double avail = std::max((double)mem_available(m->ctx), 0.35 * whole);
         cap = std::min<u64>(cap, (u64)(0.5 * avail / per_key));
     }
     return std::max<u64>(cap, 1ull << 20);
@@ -1280,6 +1367,34 @@ int map_add_counted_keys_dev(gk_map *m, const uint64_t *d_keys, const int32_t *d
     if (int rc = map_materialize(m)) return rc;
     return n ? add_keys_dev(m, d_keys, d_counts, n) : GK_OK;
 }
+// the live (key, count) of slots [s0, s1) of m, packed into d_keys (W words per key) / d_cnt; d_cursor: 8 bytes of device scratch
+int map_export_range_dev(gk_map *m, uint64_t s0, uint64_t s1, uint64_t *d_keys, int32_t *d_cnt, unsigned long long *d_cursor, uint64_t *n_out) {
+    gk_ctx *ctx = m->ctx;
+    *n_out = 0;
+    if (s1 > m->capacity) s1 = m->capacity;
+    if (s0 >= s1) return GK_OK;
+    if (int rc = map_materialize(m)) return rc;
+    GK_HIP(ctx, hipMemsetAsync(d_cursor, 0, 8, ctx->stream));
+    const int grid = grid_for(ctx, s1 - s0, BLOCK);
+    if (m->W == 1)
+        hipLaunchKernelGGL(k_export_packed<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots + s0, s1 - s0, s0, 0u, d_keys, d_cnt, d_cursor);
+    else
+        hipLaunchKernelGGL(k_export_packed<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots + s0, s1 - s0, s0, m->k == 64 ? 1u : 0u, d_keys, d_cnt, d_cursor);
+    GK_HIP(ctx, hipGetLastError());
+    unsigned long long n = 0;
+    GK_HIP(ctx, hipMemcpyAsync(&n, d_cursor, 8, hipMemcpyDeviceToHost, ctx->stream));
+    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = n;
+    return GK_OK;
+}
+// a new, empty map whose table is sized for `keys` keys the way the graph phase wants it (graph_table_load)
+int map_create_for_graph(gk_ctx *ctx, int k, uint64_t keys, gk_map **out) {
+    const double load = graph_table_load(ctx, k, keys);
+    // gk_map_create sizes for its own target load: hand it the key count that gives the wanted number of slots
+    gk_map probe; probe.k = k;
+    const uint64_t hint = (uint64_t)((double)std::max<uint64_t>(keys, 1) / load * target_load(&probe)) + 1;
+    return gk_map_create(ctx, k, hint, out);
+}
 }
 extern "C" {
 
@@ -1367,41 +1482,55 @@ int gk_map_update_inc(gk_map *m, const uint64_t *lo, const uint64_t *hi, uint64_
     return gk_map_add_counts(m, lo, hi, nullptr, n);
 }
 
+// update(key, c, _ + c) for every (key, c) of `src`, device to device, in chunks of the source's slots: how the partitions of a
+// PartitionedDNAMap that share a device are merged (the counterpart of gk_dist_gather_map, which does the same per chunk with
+// an exchange in between).  Staging: 2^25 slots' worth of packed entries at most (0.4 / 0.67 GB).
+int gk_map_add_map(gk_map *dst, gk_map *src) {
+    if (int rc = check_map(dst)) return rc;
+    gk_ctx *ctx = dst->ctx;
+    if (!src || src->ctx != ctx || src == dst) return fail(ctx, GK_E_INVALID, "gk_map_add_map: the source must be another map of the same context");
+    if (src->k != dst->k) return fail(ctx, GK_E_KLEN, "gk_map_add_map: the maps' k differ");
+    if (int rc = map_materialize(src)) return rc;
+    if (src->size == 0) return GK_OK;
+    if (int rc = map_reserve(dst, src->size)) return rc;
+    constexpr u64 CHS = 1ull << 25;
+    const u64 cap = std::min<u64>(CHS, src->capacity);
+    u64 *d_keys = nullptr;
+    i32 *d_cnt = nullptr;
+    unsigned long long *d_cur = nullptr;
+    auto done = [&](int code) { for (void *p : {(void *)d_keys, (void *)d_cnt, (void *)d_cur}) if (p) (void)hipFree(p); return code; };
+    hipError_t e = hipMalloc((void **)&d_keys, cap * 8 * dst->W);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_cnt, cap * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_cur, 8);
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_map_add_map: staging"));
+    for (u64 s0 = 0; s0 < src->capacity; s0 += CHS) {
+        uint64_t n = 0;
+        if (int rc = map_export_range_dev(src, s0, s0 + CHS, d_keys, d_cnt, d_cur, &n)) return done(rc);
+        if (n) { if (int rc = add_keys_dev(dst, d_keys, d_cnt, n, src->dirty)) return done(rc); }
+    }
+    if (src->dirty) dst->dirty = true;
+    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return done(GK_OK);
+}
+
 // replace the table by one sized for its live keys (after deleteAll: the reference rescales too, ArrayDNAMap.scala:214)
 static int map_compact(gk_map *m) {
     gk_ctx *ctx = m->ctx;
     uint32_t nnb2, nlnb1;
     uint64_t ncap;
-    // What follows deleteAll is the read-only graph phase: 8 lookups per key of which ~6 MISS, and a miss in a linearly
-    // probed table walks (1 + 1/(1-load)^2)/2 slots — 4.6 at load 0.65, i.e. a second, DEPENDENT 64-byte sector for most
-    // misses.  HBM is not what is scarce here: the compacted table is sized for load 0.25 (1.4 slots per miss) when that
-    // takes less than a third of the free memory, else for 0.4.  Measured at C3 (1.28e8 keys), classify / unitig walk /
-    // buildGraph in ms: load 0.25 35 / 17 / 59, 0.40 44 / 21 / 70, 0.60 75 / 29 / 109, 0.75 171 / 44 / 219 — the footprint
-    // (8.2 GB at 0.25, 5.1 GB at 0.4) costs nothing, the probe length everything.
-    // ("graph_load_pct": A/B of the compacted table's load factor)
-    double graph_load = ctx->hook_graph_load_pct > 0 ? ctx->hook_graph_load_pct / 100.0 : (m->k == 64 ? 0.2 : 0.25);
-    if (ctx->hook_graph_load_pct <= 0) {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
-        free_b += ctx->pool_held;               // (what the context's pool has parked is as good as free)
-        if ((double)m->size / graph_load * (double)slot_bytes(m->W) > (double)free_b / 3.0) graph_load = m->k == 64 ? 0.3 : 0.4;
-    }
+    // the read-only graph phase follows: a sparse table (graph_table_load has the measurements and the memory rule)
+    const double graph_load = graph_table_load(ctx, m->k, m->size);
     plan_segments(m->W, (uint64_t)((double)m->size / graph_load) + 1, &nnb2, &nlnb1, &ncap, (uint32_t)ctx->hook_min_lnb1);
     if (ncap > m->capacity) { nnb2 = m->nb2; nlnb1 = m->lnb1; ncap = m->capacity; }
     void *nslots = nullptr;
-    if (alloc_table(ctx, m->W, ncap, &nslots, ctx->hook_graph_mem > 0 ? ctx->hook_graph_mem : 0) != GK_OK) { if (nslots) (void)hipFree(nslots); return GK_OK; }   // keep tombstones if memory is short
-    // A/B option "graph_aligned" = 1: probes of the compacted table start at the first slot of a 128-byte line (Table::aligned),
-    // so that a lookup — hit or miss — stays inside one line.  Measured at C3 it LOSES (classify 35.3 -> 41.4 ms, walk 12.9 ->
-    // 13.9): the key is then rarely in the first slot probed, and classify's second look at a line comes after the line has
-    // left the caches (16 waves x 64 lanes x 8 lookups in flight per CU), i.e. it is fetched from HBM again.  Off by default.
-    const bool aligned = m->k != 64 && ctx->hook_graph_aligned > 0;
+    if (alloc_table(ctx, m->W, ncap, &nslots) != GK_OK) { if (nslots) (void)hipFree(nslots); return GK_OK; }   // keep tombstones if memory is short
     int g2 = grid_for(ctx, m->capacity, BLOCK);
     if (m->W == 1)
         hipLaunchKernelGGL(k_rehash<1>, dim3(g2), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, m->capacity,
-                           Table<1>{(Slot<1> *)nslots, nnb2, nlnb1, 0u, 0u, aligned ? 1u : 0u}, m->d_ctr);
+                           Table<1>{(Slot<1> *)nslots, nnb2, nlnb1, 0u, 0u}, m->d_ctr);
     else
         hipLaunchKernelGGL(k_rehash<2>, dim3(g2), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots, m->capacity,
-                           Table<2>{(Slot<2> *)nslots, nnb2, nlnb1, m->k == 64 ? 1u : 0u, 0u, aligned ? 1u : 0u}, m->d_ctr);
+                           Table<2>{(Slot<2> *)nslots, nnb2, nlnb1, m->k == 64 ? 1u : 0u, 0u}, m->d_ctr);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { (void)hipFree(nslots); return hip_fail(ctx, e, "table compaction"); }
@@ -1412,7 +1541,6 @@ static int map_compact(gk_map *m) {
     m->nb2 = nnb2;
     m->lnb1 = nlnb1;
     m->tombstones = 0;
-    m->aligned = aligned;
     return GK_OK;
 }
 
@@ -1455,7 +1583,6 @@ static int streaming_rebuild(gk_map *m, uint32_t nnb2, uint32_t nlnb1, uint64_t 
     m->lnb1 = nlnb1;
     m->tombstones = 0;
     m->size = kept;
-    m->aligned = false;
     *done = true;
     return GK_OK;
 }
@@ -1466,7 +1593,7 @@ static int streaming_rebuild(gk_map *m, uint32_t nnb2, uint32_t nlnb1, uint64_t 
 static int filter_compact_streaming(gk_map *m, int32_t rounds, bool *done) {
     gk_ctx *ctx = m->ctx;
     *done = false;
-    if (m->k == 64 || ctx->hook_filter_classic > 0 || m->aligned || ctx->hook_graph_aligned > 0 || ctx->hook_graph_mem > 0) return GK_OK;
+    if (m->k == 64 || ctx->hook_filter_classic > 0) return GK_OK;
     const u64 nseg = (u64)m->nb2 << m->lnb1;
     unsigned long long *d2 = &m->d_ctr->rebuild_sample;
     unsigned long long h2[1] = {0};
@@ -1481,13 +1608,7 @@ static int filter_compact_streaming(gk_map *m, int32_t rounds, bool *done) {
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const u64 est = (u64)((double)h2[0] * every * 1.03) + 1024;
     // 2. the new table's geometry (same rule as map_compact)
-    double graph_load = ctx->hook_graph_load_pct > 0 ? ctx->hook_graph_load_pct / 100.0 : 0.25;
-    if (ctx->hook_graph_load_pct <= 0) {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
-        free_b += ctx->pool_held;
-        if ((double)est / graph_load * (double)slot_bytes(m->W) > (double)free_b / 3.0) graph_load = 0.4;
-    }
+    const double graph_load = graph_table_load(ctx, m->k, est);
     uint32_t nnb2, nlnb1;
     uint64_t ncap;
     plan_segments(m->W, (uint64_t)((double)est / graph_load) + 1, &nnb2, &nlnb1, &ncap, (uint32_t)ctx->hook_min_lnb1);

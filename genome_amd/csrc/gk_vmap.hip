@@ -40,7 +40,7 @@ template <int W> __device__ __forceinline__ u64 slot_value(const Slot<W> *s) { r
 template <int W> __global__ __launch_bounds__(BLOCK) void k_vm_clear(Slot<W> *slots, u64 n) {
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
         if constexpr (W == 1) slots[i] = Slot<1>{KEY_EMPTY, 0u, 0u};
-        else slots[i] = Slot<2>{KEY_EMPTY, KEY_EMPTY, 0u, 0u, 0ull};
+        else slots[i] = Slot<2>{KEY_EMPTY, KEY_EMPTY, 0u, 0u};
     }
 }
 

@@ -21,6 +21,23 @@ def unique_id() -> bytes:
     return buf.raw
 
 
+def share_id(rank: int, world: int, make_id=unique_id, backend: str = "gloo") -> bytes:
+    """Bootstrap over torch.distributed (what bench.py does; a JVM host uses its own channel): rank 0 makes the 128-byte id,
+    everybody gets it.  RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT come from the launcher; the process group is created
+    here if there is none.  Only the id travels this way — the data path is RCCL inside the library."""
+    import torch
+    import torch.distributed as td
+    if not td.is_initialized():
+        td.init_process_group(backend, rank=rank, world_size=world)
+    idt = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        raw = make_id()
+        assert len(raw) == 128
+        idt = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone()
+    td.broadcast(idt, 0)
+    return bytes(idt.numpy().tobytes())
+
+
 class HipDist:
     """One rank of the communicator (gk_dist_create is collective: every rank calls it with the same id)."""
 
@@ -34,7 +51,8 @@ class HipDist:
 
     def close(self):
         if self.h:
-            L.lib().gk_dist_destroy(self.h)
+            if self.ctx.h:               # (a handle that outlived its context is dropped, not followed: gk_dist_destroy uses the context)
+                L.lib().gk_dist_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -99,6 +117,4 @@ class DistDNAMap:
         """every partition's survivors in one table on this rank (what Graph.buildGraph needs)"""
         h = L.vp()
         L.check(L.lib().gk_dist_gather_map(self.dist.h, self.local.h, C.byref(h)), self.ctx.h)
-        m = HipDNAMap.__new__(HipDNAMap)
-        m.ctx, m.k, m.h = self.ctx, self.k, h
-        return m
+        return HipDNAMap.adopt(self.ctx, self.k, h)

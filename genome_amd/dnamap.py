@@ -49,6 +49,16 @@ class Context:
         """Give the device buffers parked in the context's pool back to the device (gk_ctx_trim)."""
         L.check(L.lib().gk_ctx_trim(self.h), self.h)
 
+    def mem_stats(self, reset_peak: bool = False) -> dict:
+        """Device bytes this context holds in blocks of 1 MiB and more: live, their high-water mark, parked in the pool."""
+        live, peak, parked = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        L.check(L.lib().gk_ctx_mem_stats(self.h, C.byref(live), C.byref(peak), C.byref(parked), 1 if reset_peak else 0), self.h)
+        return {"live": live.value, "peak": peak.value, "parked": parked.value}
+
+    def set_mem_budget(self, nbytes: int):
+        """Plan as if the device had `nbytes` of memory (0: all of it)."""
+        L.check(L.lib().gk_ctx_set_mem_budget(self.h, int(nbytes)), self.h)
+
     def host_alloc(self, nbytes: int) -> np.ndarray:
         """Page-locked host buffer as a uint8 array (gk_host_alloc); give it back with host_free(array)."""
         p = L.vp()
@@ -124,10 +134,23 @@ def _keys(k: int, keys):
 class HipDNAMap:
     """`ArrayDNAMap[Int]` resident in HBM (one partition)."""
 
-    def __init__(self, ctx: Context, k: int, capacity_hint: int = 0):
+    def __init__(self, ctx: Context, k: int, capacity_hint: int = 0, for_graph: bool = False):
+        """for_graph: the map is filled once with `capacity_hint` keys and then read by buildGraph (gk_map_create_for_graph)."""
         self.ctx, self.k = ctx, k
         self.h = L.vp()
-        L.check(L.lib().gk_map_create(ctx.h, k, capacity_hint, C.byref(self.h)), ctx.h)
+        create = L.lib().gk_map_create_for_graph if for_graph else L.lib().gk_map_create
+        L.check(create(ctx.h, k, capacity_hint, C.byref(self.h)), ctx.h)
+        self._apply_env()
+
+    @classmethod
+    def adopt(cls, ctx: "Context", k: int, handle) -> "HipDNAMap":
+        """wrap a gk_map the library created (gk_dist_gather_map): the wrapper owns it from here on"""
+        m = cls.__new__(cls)
+        m.ctx, m.k, m.h = ctx, k, handle
+        m._apply_env()
+        return m
+
+    def _apply_env(self):
         forced = os.environ.get("GENOME_AMD_INSERT_PATH")     # test hook: "direct" | "partitioned"
         if forced:
             self.set_insert_path(forced)
@@ -180,6 +203,9 @@ class HipDNAMap:
         counts = np.ascontiguousarray(counts, np.int32)
         L.check(L.lib().gk_map_add_counts(self.h, L.ptr(lo, C.c_uint64), L.ptr(hi, C.c_uint64),
                                           L.ptr(counts, C.c_int32), len(lo)), self.ctx.h)
+
+    def add_map(self, other: "HipDNAMap"):                   # update(key, c, _ + c) for every entry of `other`, device to device
+        L.check(L.lib().gk_map_add_map(self.h, other.h), self.ctx.h)
 
     def update_inc_dev(self, d_keys: int, n: int):
         L.check(L.lib().gk_map_update_inc_dev(self.h, d_keys, n), self.ctx.h)

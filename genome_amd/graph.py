@@ -234,10 +234,13 @@ class Support:
 
     def close(self):
         if self.h:
-            L.lib().gk_support_destroy(self.h)
+            if self.ctx.h:               # (see HipDNAMap.close)
+                L.lib().gk_support_destroy(self.h)
             self.h = None
 
     def __del__(self):
+        if sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

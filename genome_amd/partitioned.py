@@ -1,9 +1,7 @@
 """PartitionedDNAMap[Int] (S/ds/PartitionedDNAMap.scala:15-64): P partitions, each a HipDNAMap.
 
-Two deployments of the same routing code:
-  * logical partitions on ONE device (this class) — the only form `gpurun`'s 1-GPU box can run;
-  * one partition per rank/GPU (`RankPartition` + `exchange_and_insert`), the all-to-all carried by
-    RCCL through torch.distributed (backend "nccl"), or by gloo on CPU tensors in the CPU tests.
+Logical partitions on ONE device: the form a 1-GPU box can run, and the rehearsal of what one rank of the N-GPU run
+(genome_amd.dist.DistDNAMap over gk_dist_*: RCCL inside the library) does with the records it owns.
 Owner = strand-symmetric minimizer hash mod P (gk_owner_of) instead of `hashCode mod P`
 (PartitionedDNAMap.scala:60-63): unobservable in results, keeps x and rc(x) together.
 """
@@ -221,57 +219,9 @@ class PartitionedDNAMap:
         return lo[order], hi[order], cnt[order]
 
     def merged(self) -> HipDNAMap:
-        """Gather every partition into one table (what Graph.buildGraph needs; SURVEY.md §8e
-        "all-gather the survivors")."""
-        lo, hi, cnt = self.items()
-        m = HipDNAMap(self.ctx, self.k, len(lo))
-        if len(lo):
-            m.add_counts(lo, hi, cnt)
+        """Gather every partition into one table (what Graph.buildGraph needs; SURVEY.md §8e "all-gather the survivors"):
+        device to device, partition by partition (gk_map_add_map — the one-device form of gk_dist_gather_map)."""
+        m = HipDNAMap(self.ctx, self.k, self.size(), for_graph=True)
+        for p in self.parts:
+            m.add_map(p)
         return m
-
-
-def exchange_keys(dist, send, send_counts, W: int, recv=None, group=None):
-    """The ONE exchange step of the sharded path: route every canonical key to its owner rank.
-
-    send: 1-D int64 tensor holding this rank's keys grouped by owner (W words per key, as
-    gk_shard_reads_dev writes them); send_counts[p] = keys destined to rank p.  Two collectives:
-    all_to_all_single of the P counts, then all_to_all_single of the keys with split sizes — RCCL
-    over xGMI when the tensors are on GPUs (backend "nccl"), gloo on CPU tensors in the CPU tests.
-    Returns (recv tensor view holding sum(recv_counts)*W words, recv_counts)."""
-    import torch
-    sc = torch.as_tensor(np.asarray(send_counts, dtype=np.int64), device=send.device)
-    rc = torch.empty_like(sc)
-    dist.all_to_all_single(rc, sc, group=group)
-    recv_counts = rc.cpu().numpy().astype(np.int64)
-    nrecv = int(recv_counts.sum())
-    if recv is None or recv.numel() < nrecv * W:
-        recv = torch.empty(max(nrecv * W, 1), dtype=torch.int64, device=send.device)
-    nsend = int(np.asarray(send_counts, dtype=np.int64).sum())
-    dist.all_to_all_single(recv[:nrecv * W], send[:nsend * W],
-                           output_split_sizes=[int(c) * W for c in recv_counts],
-                           input_split_sizes=[int(c) * W for c in send_counts], group=group)
-    return recv, recv_counts
-
-
-def exchange_records(dist, send, rec_counts, kmer_counts, slot: int, region_records: int, recv=None, group=None):
-    """The exchange step for super-k-mer records (gk_shard_superkmers_dev): `send` is a uint8 tensor
-    cut into P regions of `region_records` slots, region p holding rec_counts[p] records for rank p.
-    One all-to-all of (records, k-mers) per peer, one of the record bytes (RCCL over xGMI on GPU
-    tensors, gloo on CPU tensors).  Returns (recv uint8 tensor with the records packed back to back,
-    records received, k-mers received)."""
-    import torch
-    P = len(rec_counts)
-    sc = torch.as_tensor(np.stack([np.asarray(rec_counts, np.int64), np.asarray(kmer_counts, np.int64)], axis=1).reshape(-1),
-                         device=send.device)
-    rc = torch.empty_like(sc)
-    dist.all_to_all_single(rc, sc, group=group)
-    rcn = rc.cpu().numpy().reshape(P, 2)
-    nrec, nkm = int(rcn[:, 0].sum()), int(rcn[:, 1].sum())
-    if recv is None or recv.numel() < nrec * slot:
-        recv = torch.empty(max(nrec * slot, slot), dtype=torch.uint8, device=send.device)
-    # pack the P region prefixes back to back (one device copy), then ONE all_to_all_single with split sizes
-    packed = torch.cat([send[p * region_records * slot: (p * region_records + int(rec_counts[p])) * slot] for p in range(P)])
-    dist.all_to_all_single(recv[:nrec * slot], packed,
-                           output_split_sizes=[int(c) * slot for c in rcn[:, 0]],
-                           input_split_sizes=[int(c) * slot for c in rec_counts], group=group)
-    return recv, nrec, nkm

@@ -66,12 +66,20 @@ int gk_ctx_sync(gk_ctx *ctx);                    /* hipStreamSynchronize on the 
  * milliseconds to seconds, and freshly freed memory is scrubbed on the copy engines while the next upload wants them.
  * gk_ctx_trim gives everything parked back to the device (gk_map_trim does so too); gk_ctx_destroy always does. */
 int gk_ctx_trim(gk_ctx *ctx);
+/* Device memory this context holds in blocks of 1 MiB and more (tables, key scratch, graph arrays, gk_dev_alloc): *live = bytes
+ * handed out now, *peak = their high-water mark since the last reset, *parked = bytes waiting in the block pool; any may be
+ * NULL.  reset_peak != 0 restarts the high-water mark at the current value.  (What DESIGN.md's bytes-per-key tables are
+ * checked against; the reference's counterpart is the JVM heap it logs, -Xmx in project/Build.scala:44.) */
+int gk_ctx_mem_stats(gk_ctx *ctx, uint64_t *live, uint64_t *peak, uint64_t *parked, int reset_peak);
+/* Plan as if the device had `bytes` of memory (0 = all of it, the default): the sizing decisions that look at free memory — the
+ * load factor of the table the graph phase reads, the key scratch of an insert batch — then use min(free, bytes - live).  For a
+ * GPU shared with other work, and for rehearsing an 8-GPU replica's budget at an eighth of its size. */
+int gk_ctx_set_mem_budget(gk_ctx *ctx, uint64_t bytes);
 /* Test / A-B switches (never needed in production).  Their defaults are read from the environment ONCE, in
  * gk_ctx_create (GK_TEST_NO_RESERVE, GK_HOST_RAGGED, GK_PART_EXACT, GK_GRAPH_UNITIGS=walk|pj); no entry point
  * consults the environment afterwards.  Names: "test_no_reserve", "host_ragged", "part_exact" (0/1),
  * "graph_unitigs" (0 auto, 1 walk, 2 pointer jumping), "graph_walk_queue" (0: one edge per lane), "graph_load_pct" (load factor
- * of the compacted table, percent), "graph_mem" (1 uncached / 2 fine-grained memory for it), "graph_aligned" (1: probes start at
- * the first slot of a 128-byte line), "p4_direct" / "fine_exact" / "p2_wide" / "p2_sorted" (-1 auto, 0, 1), "p4_wide" (-1 auto, 0: 4096-key sorts, 1: 8192, 2: 12288),
+ * of the compacted table, percent), "p4_direct" / "fine_exact" / "p2_wide" / "p2_sorted" (-1 auto, 0, 1), "p4_wide" (-1 auto, 0: 4096-key sorts, 1: 8192, 2: 12288),
  * "p45_stripes" (P5 of one stripe of L1 buckets beside P4 of the next), "p24_pieces" (P4 of one piece of a batch beside the L1
  * scatter of the next), "p4_grid" (P4 workgroups per CU), "filter_classic" (1: tombstones + rehash instead of the streaming
  * rebuild), "dist_exchange_ahead" (0: gk_dist_count_routed does not post the next batch's exchange ahead; every rank alike):
@@ -102,6 +110,10 @@ int gk_dev_stream_bench(gk_ctx *ctx, size_t nbytes, int reps, double *gbps3);
  * keys (0 = default); the table is pre-sized from it and grows by rehashing when a batch could
  * push the load factor past 0.75 (the reference's 0.3/0.7 rescale, :217-230, is unobservable). */
 int gk_map_create(gk_ctx *ctx, int k, uint64_t capacity_hint, gk_map **out);
+/* The same for a map that is FILLED ONCE with `keys` keys (a merge of partitions, a load from a file) and then read by
+ * gk_graph_build: its table is sized the way the graph phase wants it — as sparse as memory allows, load 0.25 down to 0.7
+ *  — which is also how gk_dist_gather_map sizes the table it returns and gk_map_filter_lt the one it leaves. */
+int gk_map_create_for_graph(gk_ctx *ctx, int k, uint64_t keys, gk_map **out);
 void gk_map_destroy(gk_map *m);
 int gk_map_k(const gk_map *m);
 int gk_map_clear(gk_map *m);                               /* back to an empty table of the same capacity */
@@ -149,6 +161,10 @@ int gk_map_update_inc(gk_map *m, const uint64_t *lo, const uint64_t *hi, uint64_
 int gk_map_update_inc_dev(gk_map *m, const void *dev_keys, uint64_t n);
 /* update(key, v0=c, f=_+c): adds counts of pre-aggregated keys (merging exported partitions) */
 int gk_map_add_counts(gk_map *m, const uint64_t *lo, const uint64_t *hi, const int32_t *counts, uint64_t n);
+
+/* update(key, c, _ + c) for every (key, c) of `src` (same context, same k), device to device in bounded chunks: merges the
+ * partitions of a PartitionedDNAMap that share a device (the one-device counterpart of gk_dist_gather_map).  `src` is unchanged. */
+int gk_map_add_map(gk_map *dst, gk_map *src);
 
 /* DNAMap.deleteAll((k, v) => v < rounds)  (FreqFilter.scala:55; ArrayDNAMap.scala:164-173, 212-215) */
 int gk_map_filter_lt(gk_map *m, int32_t rounds);
@@ -275,7 +291,9 @@ int gk_dist_last_ms(gk_dist *d, float *ms4);
 int gk_dist_size(gk_dist *d, gk_map *local, uint64_t *total);         /* PartitionedDNAMap.size (:31): sum over the partitions */
 /* deleteAll / filter_lt, stats, export are LOCAL: call gk_map_filter_lt etc. on `local` on every rank (:49-51 scatter, no data moves). */
 /* The whole k-mer set on every rank, for Graph.buildGraph (the unitig walk crosses partitions arbitrarily):
- * all-gather of every partition's live (key, count), device to device, into a NEW map (*full, caller destroys it). */
+ * all-gather of every partition's live (key, count), device to device and in bounded chunks (staging <= 0.7 GB to send, world x
+ * that to receive), into a NEW map (*full, caller destroys it) sized the way the graph phase wants it.  A rank that fails
+ * says so in the chunk's size word: every rank then returns an error for the same chunk and nobody waits in a receive. */
 int gk_dist_gather_map(gk_dist *d, gk_map *local, gk_map **full);
 
 /* ---- Graph: S/data/graph/Graph.scala ------------------------------------------------------- */

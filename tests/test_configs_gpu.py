@@ -132,7 +132,97 @@ def test_c2_full_size_properties(ctx, mode):
     m.close(); ctx.free(d)
 
 
-def _share(ctx, k, n, G, e, cfg, chunk, with_plain):
+def _graph_stage(ctx, pm, k, budget, tag):
+    """The graph stage of an 8-GPU configuration as ONE rank sees it, at an eighth of the size: the 8 logical partitions stand
+    for the 8 ranks' tables (partition 0 = "this rank's", the other seven live on other GPUs in the real run), the merged table
+    for the replica every rank gathers (gk_dist_gather_map; here gk_map_add_map, partition by partition — the same export /
+    insert chunks without the exchange), then Graph.buildGraph in both unitig constructions, removeBubbles, simplifyGraph and
+    GraphBuilder's retain (Graph.scala:269-382, 125-149, 211-230; GraphBuilder.scala:32-54).  `budget` = an eighth of a
+    288 GB GPU: the library plans against it (gk_ctx_set_mem_budget) and the high-water mark of what this rank would hold
+    must stay inside it, i.e. 8 x peak < 288 GB at full size."""
+    import json, os, time
+    from genome_amd.dist import DistDNAMap, HipDist, unique_id
+    W = 2 if k > 32 else 1
+    slot = 16 if W == 1 else 24
+    total = pm.size()
+    want = pm.verify()
+    ctx.trim()
+    elsewhere = sum(p.slots() * slot for p in pm.parts[1:])           # tables that are on other GPUs in the real run
+    base0 = ctx.mem_stats(reset_peak=True)["live"] - pm.parts[0].slots() * slot   # reads etc.: not this stage's
+    ctx.set_mem_budget(budget + base0)
+    report = {"config": tag, "k": k, "keys": total, "budget_bytes": budget}
+    try:
+        # ---- this rank's own partition through the real collective (a communicator of one rank): chunked export + insert
+        dist = HipDist(ctx, 0, 1, unique_id())
+        dm = DistDNAMap.__new__(DistDNAMap)
+        dm.dist, dm.ctx, dm.k, dm.local = dist, ctx, k, pm.parts[0]
+        own = dm.gathered()
+        assert own.verify_checksum() == pm.parts[0].verify_checksum()
+        own.close(); dist.close(); ctx.trim()
+        ctx.mem_stats(reset_peak=True)
+        # ---- the replica: every partition's survivors in one table sized for the graph phase
+        t0 = time.perf_counter()
+        full = pm.merged()
+        report["gather_s"] = time.perf_counter() - t0
+        assert full.size() == total and full.verify_checksum() == want
+        peak_gather = ctx.mem_stats()["peak"] - base0 - elsewhere
+        report["gather_peak_bytes"] = peak_gather
+        report["replica_slots"], report["replica_load"] = full.slots(), total / full.slots()
+        pm.close()
+        ctx.trim()
+        ctx.mem_stats(reset_peak=True)
+        base1 = ctx.mem_stats()["live"] - full.slots() * slot
+        # ---- buildGraph, both constructions: the same graph
+        out = {}
+        for mode, name in ((1, "walk"), (2, "pj")):
+            ctx.set_option("graph_unitigs", mode)
+            t0 = time.perf_counter()
+            g = buildGraph(k, full)
+            out[name] = (g.counts(), g.checksum())
+            report[name + "_build_s"] = time.perf_counter() - t0
+            report[name + "_build_peak_bytes"] = ctx.mem_stats(reset_peak=True)["peak"] - base1
+            if mode == 1:
+                g.close()
+                ctx.mem_stats(reset_peak=True)
+        ctx.set_option("graph_unitigs", 0)
+        assert out["walk"] == out["pj"], out
+        (nodes, edges, total_len), _ = out["pj"]
+        report.update(nodes=nodes, edges=edges, edge_bases=total_len)
+        assert nodes > 0 and nodes % 2 == 0 and edges >= nodes // 2
+        assert total_len >= total - nodes // 2                      # every interior k-mer lies on an edge (both strands walk it)
+        # the reference's own invariants on a sample (SURVEY.md section 4)
+        e = g.getEdges()
+        rnd = np.random.default_rng(5)
+        for i in rnd.choice(edges, min(edges, 200), replace=False):
+            o, ln = int(e["off"][i]), int(e["len"][i])
+            seq = dna.unpack_2bit(e["seq"][o:o + (ln + 3) // 4], ln)
+            s_, t_ = dna.unpack(int(e["slo"][i]), int(e["shi"][i]), k), dna.unpack(int(e["elo"][i]), int(e["ehi"][i]), k)
+            assert (s_ + seq).endswith(t_)
+            assert g.nodeId(dna.rev_complement(s_))[0] is not None     # termKmers = T ++ T.map(revComplement)
+        del e
+        g.removeBubbles()
+        assert g.counts()[0] == nodes and g.counts()[1] <= edges
+        g.simplifyGraph()
+        h1, h2 = g.componentHistograms()
+        kept, comps = g.retainLargest()
+        assert sum(c for _, c in h1) == comps == sum(c for _, c in h2)
+        assert kept == h1[-1][0] and g.counts()[0] == kept
+        report["final"] = g.counts()
+        report["simplify_retain_peak_bytes"] = ctx.mem_stats()["peak"] - base1
+        g.close()
+        peak = max(peak_gather, report["walk_build_peak_bytes"], report["pj_build_peak_bytes"], report["simplify_retain_peak_bytes"])
+        report["stage_peak_bytes"], report["times_8_GB"] = peak, 8 * peak / 1e9
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(f"gpurun_out/graph_stage_{tag}.json", "w") as f:
+            json.dump(report, f, indent=1)
+        assert 8 * peak < 288e9, report
+        full.close()
+    finally:
+        ctx.set_mem_budget(0)
+        ctx.set_option("graph_unitigs", 0)
+
+
+def _share(ctx, k, n, G, e, cfg, chunk, with_plain, graph_stage=None):
     """One rank's share of an 8-GPU configuration on P = 8 logical partitions, pre-filtered."""
     L_, P = 150, 8
     stride = synth.record_stride(L_)
@@ -161,7 +251,10 @@ def _share(ctx, k, n, G, e, cfg, chunk, with_plain):
     filtered = pm.verify()
     assert filtered[0] == pm.size() and filtered[1] == 0
     assert 0.5 * solid < filtered[0] < 1.6 * solid          # what survives is the genome's k-mers (plus errors seen 3 times)
-    pm.close()
+    if graph_stage:
+        _graph_stage(ctx, pm, k, 36_000_000_000, graph_stage)     # (closes pm)
+    else:
+        pm.close()
     if with_plain:
         plain = PartitionedDNAMap(ctx, k, P, capacity_hint=int((solid + errors) * 1.05))
         occ = 0
@@ -183,8 +276,9 @@ def test_c4_one_rank_share_k55_partitioned_prefiltered(ctx):
 
 def test_c5_one_rank_share_k63_partitioned_prefiltered(ctx):
     """configs[4] / 8: 250 M x 150 bp over 387.5 Mbp (~97x), k = 63, e = 0.2 %; 2.2e10 windows.  The unfiltered table
-    (~5e9 16-byte keys) does not fit one GPU — which is what the pre-filter is for — so no with/without comparison here."""
-    _share(ctx, k=63, n=250_000_000, G=387_500_000, e=0.002, cfg=5, chunk=25_000_000, with_plain=False)
+    (~5e9 16-byte keys) does not fit one GPU — which is what the pre-filter is for — so no with/without comparison here.
+    Then the graph stage of configs[4] ("full build + simplify, HBM-resident graph") as one rank holds it: _graph_stage."""
+    _share(ctx, k=63, n=250_000_000, G=387_500_000, e=0.002, cfg=5, chunk=25_000_000, with_plain=False, graph_stage="c5_share_k63")
 
 
 @pytest.mark.parametrize("k,L_,hint", [(31, 150, 1_500_000_000), (55, 150, 720_000_000)])

@@ -173,3 +173,113 @@ def test_several_ranks_over_the_loopback_transport(world, k, L_):
         assert size == len(want[0])
         for a, b in zip(items, want):
             assert np.array_equal(a, b)
+
+
+def _run_ranks(world, body, timeout=240):
+    """`body(rank, ctx, hd)` on one thread per rank over the loopback transport; returns the ranks' results, fails on a stuck rank."""
+    import threading
+    id128 = bytes(random.Random(world * 7919 + 13).getrandbits(8) for _ in range(128))
+    out, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            c = Context(0)
+            hd = HipDist(c, rank, world, id128, loopback=True)
+            out[rank] = body(rank, c, hd)
+            hd.barrier()
+            hd.close(); c.close()
+        except BaseException as e:          # noqa: BLE001 — reported by the main thread
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=timeout)
+    assert not any(t.is_alive() for t in threads), "a rank is stuck"
+    assert not errors, errors
+    return out
+
+
+@pytest.mark.parametrize("world,k,L_", [(3, 31, 150), (2, 55, 150)])
+def test_one_rank_fails_its_route_and_every_rank_drops_that_batch(world, k, L_):
+    """A failure that only ONE rank has — its route cannot be completed, an allocation fails (injected: test_dist_fail_exchange
+    on rank 1's context) — must not leave the peers waiting in a receive: the failing rank says so in the status word of the
+    counts exchange, EVERY rank drops that batch and reports GK_E_COMM from the same count_routed, nobody hangs, and the batches
+    after it are counted as if nothing had happened: the gathered table is the oracle's over the reads of all OTHER batches."""
+    n, nb, bad = 24000, 5, 2
+    per = n // nb
+    rec = synth.reads_mode_g(n * world, L_, 40000 * world, 0.01, config_id=900 + k)
+    stride = rec.shape[1]
+    keep = np.concatenate([rec[r * n + i * per: r * n + (i + 1) * per] for r in range(world) for i in range(nb) if i != bad])
+    ref = O.PMap(k, 1)
+    occ = ref.count_reads(keep.tobytes(), len(keep))
+    want = ref.export_sorted()
+
+    def body(rank, c, hd):
+        pm = DistDNAMap(hd, k, 1 << 10)
+        d = c.alloc(n * stride + 64)
+        c.upload(d, rec[rank * n:(rank + 1) * n])
+        begun = sent = owned = 0
+        failed = []
+        for i in range(nb):
+            while begun < min(i + 3, nb):
+                pm.route_begin(d + begun * per * stride, per, L_)
+                begun += 1
+            if rank == 1 and i == bad - 1:
+                c.set_option("test_dist_fail_exchange", 4)      # batch `bad` is settled inside this call (its exchange goes ahead)
+            try:
+                s_, o_ = pm.count_routed()
+                sent += s_; owned += o_
+            except L.GkError as e:
+                assert e.code == L.GK_E_COMM, e
+                failed.append((i, str(e)))
+        tot = hd.allreduce([float(sent), float(owned)], "sum")
+        full = pm.gathered()
+        res = (failed, tot.tolist(), full.sorted_items(), pm.local.verify()[1])
+        full.close(); pm.close(); c.free(d)
+        return res
+
+    for rank, (failed, tot, items, badslots) in enumerate(_run_ranks(world, body)):
+        assert [i for i, _ in failed] == [bad], (rank, failed)
+        assert "rank 1" in failed[0][1]
+        assert ("injected" in failed[0][1]) == (rank == 1)          # only the failing rank knows why
+        assert tot == [float(occ), float(occ)] and badslots == 0
+        for a, b in zip(items, want):
+            assert np.array_equal(a, b)
+
+
+def test_a_send_region_that_is_too_small_is_routed_again_in_place():
+    """One rank's send buffer is far too small for a batch (injected: test_dist_small_send): the route overflows its regions, the
+    owner thread routes the batch again into a bigger buffer before its exchange is posted, and nothing is lost or counted twice."""
+    world, k, L_, n, nb = 2, 31, 120, 20000, 4
+    per = n // nb
+    rec = synth.reads_mode_g(n * world, L_, 60000, 0.01, config_id=950)
+    stride = rec.shape[1]
+    ref = O.PMap(k, 1)
+    occ = ref.count_reads(rec.tobytes(), n * world)
+    want = ref.export_sorted()
+
+    def body(rank, c, hd):
+        pm = DistDNAMap(hd, k, 1 << 10)
+        d = c.alloc(n * stride + 64)
+        c.upload(d, rec[rank * n:(rank + 1) * n])
+        begun = sent = owned = 0
+        for i in range(nb):
+            while begun < min(i + 3, nb):
+                if rank == 0 and begun in (1, 3):
+                    c.set_option("test_dist_small_send", 8)
+                pm.route_begin(d + begun * per * stride, per, L_)
+                begun += 1
+            s_, o_ = pm.count_routed()
+            sent += s_; owned += o_
+        tot = hd.allreduce([float(sent), float(owned)], "sum")
+        full = pm.gathered()
+        res = (tot.tolist(), full.sorted_items())
+        full.close(); pm.close(); c.free(d)
+        return res
+
+    for tot, items in _run_ranks(world, body):
+        assert tot == [float(occ), float(occ)]
+        for a, b in zip(items, want):
+            assert np.array_equal(a, b)
