@@ -33,73 +33,7 @@
 
 using namespace gk;
 
-struct gk_vmap;
-namespace gk {
-int vmap_put_new_dev(gk_vmap *m, const uint64_t *d_lo, const uint64_t *d_hi, const uint64_t *d_val, uint64_t n);
-int vmap_k(const gk_vmap *m);
-gk_ctx *vmap_ctx(const gk_vmap *m);
-}
-
-static constexpr u32 NONE = 0xFFFFFFFFu;
-static constexpr u32 AUX_TERMINAL = 1u << 8;
-static constexpr u32 AUX_SECONDARY = 1u << 9;
-// Once k_make_nodes has numbered the terminal k-mers, a terminal slot's annotation IS its node: AUX_NODE | j, where the stored
-// orientation is node 2j and its reverse complement node 2j + 1.  (Until round 3 a separate u32 per table SLOT held that
-// number: 4 bytes x capacity — 19 GB at C5 — and one more random read at every edge's end.)  Its degree masks are not
-// needed any more at that point: a walk stops at a terminal k-mer, it never leaves one through the table.
-static constexpr u32 AUX_NODE = 1u << 31;
-__device__ __forceinline__ u32 aux_node(u32 aux, bool fwd) { return 2u * (aux & 0x7fffffffu) + (fwd ? 0u : 1u); }
-
-// ---------------------------------------------------------------------------------------------
-// device-side view of a graph
-// ---------------------------------------------------------------------------------------------
-struct GraphView {
-    int k;
-    u64 n_nodes, n_edges;
-    u64 *node_lo, *node_hi;
-    uint8_t *node_alive;
-    u32 *out_edge;      // [n_nodes*4], by first base
-    u32 *out_order;     // count in bits 0..2, i-th base in bits 4+2i..5+2i
-    u32 *in_deg;
-    u32 *e_start, *e_end;
-    u64 *e_len, *e_off;
-    uint8_t *e_alive, *e_first;
-    uint8_t *pool;
-    u32 *nidx;          // open-addressed k-mer -> node id index
-    u64 nidx_mask;
-};
-
-struct gk_graph {
-    gk_ctx *ctx = nullptr;
-    int k = 0, W = 1;
-    GraphView v{};
-    void *node_blob = nullptr, *edge_blob = nullptr;      // the node / edge arrays of `v` are carved out of these two allocations
-    u64 node_cap = 0, edge_cap = 0, pool_cap = 0, pool_used = 0;
-    u64 live_nodes = 0, live_edges = 0, live_len = 0;
-    // wall time of the phases of gk_graph_build (every phase ends in a stream sync): classify, terminals -> nodes + edge
-    // stubs, unitig measure (k_walk pass 0 / pointer jumping), pool reservation, unitig emit, node index + counts
-    float build_ms[6] = {0, 0, 0, 0, 0, 0};
-    u64 walked_bases = 0;        // bases emitted by the unitig construction (= total edge length at build time)
-    int used_pj = 0;
-    // host snapshot of the edge arrays for the paired-end walks, valid while `epoch` (bumped by every edit) has not moved:
-    // a stream of gk_graph_walk_pairs batches downloads the graph once
-    u64 epoch = 0, snap_epoch = ~0ull;
-    std::shared_ptr<void> snap;
-};
-
-__device__ __forceinline__ int order_count(u32 o) { return (int)(o & 7u); }
-__device__ __forceinline__ int order_base(u32 o, int i) { return (int)((o >> (4 + 2 * i)) & 3u); }
-__device__ __forceinline__ u32 order_append(u32 o, int b) {
-    int c = order_count(o);
-    return ((o & ~7u) | (u32)(c + 1)) | ((u32)b << (4 + 2 * c));
-}
-__device__ __forceinline__ u32 order_remove(u32 o, int b) {
-    u32 r = 0;
-    for (int i = 0; i < order_count(o); i++) if (order_base(o, i) != b) r = order_append(r, order_base(o, i));
-    return r;
-}
-__device__ __forceinline__ u32 rev4(u32 m) { return ((m & 1) << 3) | ((m & 2) << 1) | ((m & 4) >> 1) | ((m & 8) >> 3); }
-__device__ __forceinline__ int pool_get(const uint8_t *pool, u64 off, u64 i) { return (pool[off + (i >> 2)] >> ((i & 3) * 2)) & 3; }
+#include "gk_graph.h"
 
 template <int W> __device__ __forceinline__ Kmer<W> node_kmer(const GraphView &g, u64 n);
 template <> __device__ __forceinline__ Kmer<1> node_kmer<1>(const GraphView &g, u64 n) { return Kmer<1>{g.node_lo[n]}; }
@@ -1372,7 +1306,7 @@ __global__ void k_nidx_insert(GraphView g, u32 n, u64 h) {
 // =============================================================================================
 // host side
 // =============================================================================================
-static inline int ggrid(const gk_ctx *ctx, u64 items) {
+int ggrid(const gk_ctx *ctx, u64 items) {
     u64 blocks = (items + BLOCK - 1) / BLOCK;
     if (blocks < 1) blocks = 1;
     return (int)std::min<u64>(blocks, (u64)ctx->cu_count * 8);
@@ -1489,7 +1423,7 @@ static int graph_grow_edges(gk_graph *g, u64 new_n) {
     return GK_OK;
 }
 
-static int graph_refresh_counts(gk_graph *g) {
+int graph_refresh_counts(gk_graph *g) {
     gk_ctx *ctx = g->ctx;
     g->epoch++;                  // (every edit of the graph ends here or in a point edit)
     unsigned long long *d = nullptr, h[3] = {0, 0, 0};
@@ -1507,7 +1441,7 @@ static int graph_refresh_counts(gk_graph *g) {
     return GK_OK;
 }
 
-static int graph_build_index(gk_graph *g) {
+int graph_build_index(gk_graph *g) {
     gk_ctx *ctx = g->ctx;
     GraphView &v = g->v;
     if (v.nidx) { GK_HIP(ctx, hipFree(v.nidx)); v.nidx = nullptr; }
@@ -1703,7 +1637,7 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
     return done(rc);
 }
 
-static int check_graph(const gk_graph *g) {
+int check_graph(const gk_graph *g) {
     if (!g || !g->ctx) return fail(nullptr, GK_E_INVALID, "null graph handle");
     hipError_t e = hipSetDevice(g->ctx->device);
     if (e != hipSuccess) return hip_fail(g->ctx, e, "hipSetDevice");
@@ -2096,7 +2030,8 @@ int gk_graph_out_order(gk_graph *g, uint64_t lo, uint64_t hi, int *bases4, int *
     return GK_OK;
 }
 
-static int graph_grow_nodes(gk_graph *g, u64 new_cap) {
+}  // extern "C"
+int graph_grow_nodes(gk_graph *g, u64 new_cap) {
     gk_ctx *ctx = g->ctx;
     GraphView &v = g->v;
     if (new_cap <= g->node_cap) return GK_OK;
@@ -2123,6 +2058,8 @@ static int graph_grow_nodes(gk_graph *g, u64 new_cap) {
     g->node_cap = new_cap;
     return GK_OK;
 }
+
+extern "C" {
 
 // Graph.getGraphMap (Graph.scala:90-119): putNew of every node k-mer and of every interior k-mer of every edge into `vm`
 int gk_graph_position_map(gk_graph *g, gk_vmap *vm, uint64_t *entries) {
@@ -2294,538 +2231,6 @@ int gk_graph_edges_by_id(gk_graph *g, const uint32_t *ids, uint64_t n, uint32_t 
     for (void *p : {(void *)d_ids, (void *)d_s, (void *)d_e, (void *)d_len, (void *)d_f, (void *)d_al}) if (p) (void)hipFree(p);
     if (e != hipSuccess) return hip_fail(ctx, e, "gk_graph_edges_by_id");
     return GK_OK;
-}
-
-}  // extern "C"
-
-// =============================================================================================
-// Paired-end walking (S/scripts/GraphSimplifier.scala:33-127, 188-318).
-// The data-parallel part — four getAll per read pair on the position multimap (:214-217) — is one batched lookup on the
-// device (gk_vmap_get_all_batch).  The walks themselves are what the reference runs in its WalkingActors: bounded searches
-// (range.last = 250 bases) over the contig graph, a few dozen states each; they run on host threads over a snapshot of the
-// graph's edge arrays.  The result is applied on the device again (node split, edge removal) with batch kernels.
-// The walk is NOT the reference's recursion: states (previous edge, distance) are expanded in order of distance and
-// resolved in reverse — same set of supported edge pairs (tests compare against the oracle's literal dfs + memo).
-// =============================================================================================
-#include <mutex>
-#include <thread>
-#include <unordered_map>
-
-struct gk_support {
-    gk_ctx *ctx = nullptr;
-    std::unordered_map<u64, u32> paths;        // (e1 << 32 | e2) -> count          pathsMap :209
-    u64 bad_pairs = 0, walked = 0;             // badPairs :211; pair orientations that reached the walk
-    float last_ms[5] = {0, 0, 0, 0, 0};        // last gk_graph_walk_pairs: keys from the stream, getAll batch, snapshot + checks, walks, merge
-};
-
-namespace {
-
-struct HostGraph {
-    u64 n_nodes = 0, n_edges = 0;
-    std::vector<u32> e_start, e_end, out_edge, in_off, in_list;
-    std::vector<u64> e_len;
-    std::vector<uint8_t> e_alive, node_alive;
-};
-
-int graph_snapshot(gk_graph *g, HostGraph &H) {
-    gk_ctx *ctx = g->ctx;
-    const GraphView &v = g->v;
-    H.n_nodes = v.n_nodes; H.n_edges = v.n_edges;
-    H.e_start.resize(H.n_edges); H.e_end.resize(H.n_edges); H.e_len.resize(H.n_edges); H.e_alive.resize(H.n_edges);
-    H.out_edge.resize(H.n_nodes * 4); H.node_alive.resize(H.n_nodes);
-    GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (H.n_edges) {
-        GK_HIP(ctx, hipMemcpy(H.e_start.data(), v.e_start, H.n_edges * 4, hipMemcpyDeviceToHost));
-        GK_HIP(ctx, hipMemcpy(H.e_end.data(), v.e_end, H.n_edges * 4, hipMemcpyDeviceToHost));
-        GK_HIP(ctx, hipMemcpy(H.e_len.data(), v.e_len, H.n_edges * 8, hipMemcpyDeviceToHost));
-        GK_HIP(ctx, hipMemcpy(H.e_alive.data(), v.e_alive, H.n_edges, hipMemcpyDeviceToHost));
-    }
-    if (H.n_nodes) {
-        GK_HIP(ctx, hipMemcpy(H.out_edge.data(), v.out_edge, H.n_nodes * 16, hipMemcpyDeviceToHost));
-        GK_HIP(ctx, hipMemcpy(H.node_alive.data(), v.node_alive, H.n_nodes, hipMemcpyDeviceToHost));
-    }
-    // in-edge lists (Node.inEdgeIds), CSR by end node
-    H.in_off.assign(H.n_nodes + 1, 0);
-    for (u64 e = 0; e < H.n_edges; e++) if (H.e_alive[e]) H.in_off[H.e_end[e] + 1]++;
-    for (u64 n = 0; n < H.n_nodes; n++) H.in_off[n + 1] += H.in_off[n];
-    H.in_list.resize(H.in_off[H.n_nodes]);
-    std::vector<u32> cur(H.in_off.begin(), H.in_off.end() - 1);
-    for (u64 e = 0; e < H.n_edges; e++) if (H.e_alive[e]) H.in_list[cur[H.e_end[e]]++] = (u32)e;
-    return GK_OK;
-}
-
-int graph_snapshot_cached(gk_graph *g, const HostGraph **out) {
-    if (!g->snap || g->snap_epoch != g->epoch) {
-        auto h = std::make_shared<HostGraph>();
-        if (int rc = graph_snapshot(g, *h)) return rc;
-        g->snap = h;
-        g->snap_epoch = g->epoch;
-    }
-    *out = static_cast<const HostGraph *>(g->snap.get());
-    return GK_OK;
-}
-
-struct Pos { bool is_edge; u32 id; u32 dist; };
-inline Pos decode_pos(u64 v) { return Pos{GK_POS_IS_EDGE(v), GK_POS_ID(v), GK_POS_IS_EDGE(v) ? GK_POS_DIST(v) : 0u}; }
-
-// one (pos1, pos2) of WalkingActor.receive (:78-125): appends the supported (edge, edge) pairs, returns `good`
-struct Walker {
-    const HostGraph &G;
-    const int lo, hi;
-    // scratch reused between walks
-    std::unordered_map<u32, int> reach;
-    std::vector<std::vector<u32>> rq;                       // reach: nodes by distance
-    struct State { u32 pe; u32 d; bool pruned, res; };
-    std::vector<State> states;                              // in order of d
-    std::unordered_map<u64, u32> index;                     // (pe, d) -> position in `states`
-    std::vector<std::vector<u32>> sq;                       // states by distance
-    std::vector<u32> rq_touched, sq_touched;                // the distances whose buckets the last walk filled
-    Walker(const HostGraph &g, int lo_, int hi_) : G(g), lo(lo_), hi(hi_), rq(hi_ + 1), sq(hi_ + 1) {}
-
-    bool walk(Pos p1, Pos p2, std::vector<u64> &pairs) {
-        const u32 node2 = p2.is_edge ? G.e_start[p2.id] : p2.id;
-        const u32 dist2 = p2.is_edge ? p2.dist : 0u;
-        const u32 end_edge = p2.is_edge ? p2.id : NONE;
-        const u32 start_edge = p1.is_edge ? p1.id : NONE;
-        const u32 node0 = p1.is_edge ? G.e_end[p1.id] : p1.id;
-        const u64 dist0 = p1.is_edge ? G.e_len[p1.id] - p1.dist : 0;
-        if (dist0 > (u64)hi) return false;                  // (the reference finds this out after `reachable`; nothing is recorded either way)
-        // ---- reachable(node2) :43-72: shortest distance back along in-edges, <= hi (edge lengths >= 1: buckets by distance)
-        reach.clear();
-        for (u32 d : rq_touched) rq[d].clear();
-        rq_touched.clear();
-        rq[0].push_back(node2);
-        rq_touched.push_back(0);
-        for (int d = 0; d <= hi; d++)
-            for (size_t i = 0; i < rq[d].size(); i++) {
-                const u32 u = rq[d][i];
-                if (!reach.emplace(u, d).second) continue;
-                for (u32 j = G.in_off[u]; j < G.in_off[u + 1]; j++) {
-                    const u32 e = G.in_list[j];
-                    const u64 d2 = (u64)d + G.e_len[e];
-                    if (d2 <= (u64)hi) { if (rq[d2].empty()) rq_touched.push_back((u32)d2); rq[d2].push_back(G.e_start[e]); }
-                }
-            }
-        // ---- forward: states (previous edge, distance) in order of distance
-        states.clear(); index.clear();
-        for (u32 d : sq_touched) sq[d].clear();
-        sq_touched.clear();
-        auto node_of = [&](u32 pe) { return pe == NONE ? node0 : G.e_end[pe]; };
-        auto add_state = [&](u32 pe, u32 d) {
-            const u64 key = ((u64)pe << 32) | d;
-            if (index.count(key)) return;
-            index.emplace(key, 0u);
-            if (sq[d].empty()) sq_touched.push_back(d);
-            sq[d].push_back(pe);
-        };
-        add_state(start_edge, (u32)dist0);
-        for (int d = (int)dist0; d <= hi; d++)
-            for (size_t i = 0; i < sq[d].size(); i++) {
-                const u32 pe = sq[d][i], n1 = node_of(pe);
-                auto r = reach.find(n1);
-                const bool pruned = r == reach.end() || (u64)d + dist2 + (u64)r->second > (u64)hi;
-                index[((u64)pe << 32) | (u32)d] = (u32)states.size();
-                states.push_back(State{pe, (u32)d, pruned, false});
-                if (pruned) continue;
-                for (int b = 0; b < 4; b++) {
-                    const u32 e = G.out_edge[(u64)n1 * 4 + b];
-                    if (e == NONE) continue;
-                    const u64 d2 = (u64)d + G.e_len[e];
-                    if (d2 <= (u64)hi) add_state(e, (u32)d2);       // (beyond hi the child is pruned: res false, nothing to record)
-                }
-            }
-        // ---- backward: res(state) = arrival in range, or a child that succeeds (children have larger d)
-        for (size_t si = states.size(); si-- > 0;) {
-            State &s = states[si];
-            if (s.pruned) continue;
-            const u32 n1 = node_of(s.pe);
-            bool cur = false;
-            if (n1 == node2 && (int)(s.d + dist2) >= lo && (int)(s.d + dist2) <= hi) {
-                if (s.pe != NONE && end_edge != NONE) pairs.push_back(((u64)s.pe << 32) | end_edge);
-                cur = true;
-            }
-            for (int b = 0; b < 4; b++) {
-                const u32 e = G.out_edge[(u64)n1 * 4 + b];
-                if (e == NONE) continue;
-                const u64 d2 = (u64)s.d + G.e_len[e];
-                if (d2 > (u64)hi) continue;
-                const State &c = states[index[((u64)e << 32) | (u32)d2]];
-                if (c.res) {
-                    if (s.pe != NONE) pairs.push_back(((u64)s.pe << 32) | e);
-                    cur = true;
-                }
-            }
-            s.res = cur;
-        }
-        return states.empty() ? false : states[index[((u64)start_edge << 32) | (u32)dist0]].res;
-    }
-};
-
-// the first k bases of a `.bin` record as (lo, hi) — the first 2k bits of its payload, LSB first (DNASeq.scala:285-303) —
-// and its reverse complement.  `avail` = payload bytes that may be read (>= ceil(k / 4)).
-inline void first_kmer(const uint8_t *payload, size_t avail, int k, u64 &lo, u64 &hi) {
-    u64 w[2] = {0, 0};
-    memcpy(w, payload, std::min<size_t>(16, avail));
-    if (k <= 32) { lo = k == 32 ? w[0] : w[0] & ((1ull << (2 * k)) - 1ull); hi = 0; }
-    else { lo = w[0]; hi = k == 64 ? w[1] : w[1] & ((1ull << (2 * (k - 32))) - 1ull); }
-}
-// the 32 two-bit groups of a word in reverse order
-inline u64 reverse_groups(u64 x) {
-    x = __builtin_bswap64(x);
-    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
-    return ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
-}
-// complement (A<->T, G<->C = b ^ 3, Base.scala:6-23), then reverse; the complemented padding ends up below bit 0 and is shifted out
-inline void revcomp_host(u64 lo, u64 hi, int k, u64 &rlo, u64 &rhi) {
-    if (k <= 32) { rlo = reverse_groups(~lo) >> (64 - 2 * k); rhi = 0; return; }
-    const u64 nhi = reverse_groups(~lo), nlo = reverse_groups(~hi);       // the 128-bit value reversed: words swapped
-    const int s = 128 - 2 * k;                                             // 0 <= s < 64
-    rlo = s ? (nlo >> s) | (nhi << (64 - s)) : nlo;
-    rhi = nhi >> s;
-}
-
-}  // namespace
-
-extern "C" {
-
-int gk_support_create(gk_ctx *ctx, gk_support **out) {
-    if (!ctx || !out) return fail(ctx, GK_E_INVALID, "gk_support_create: null argument");
-    *out = new gk_support();
-    (*out)->ctx = ctx;
-    return GK_OK;
-}
-void gk_support_destroy(gk_support *s) { delete s; }
-int gk_support_size(const gk_support *s, uint64_t *pairs, uint64_t *bad_pairs, uint64_t *walked) {
-    if (!s) return fail(nullptr, GK_E_INVALID, "null support handle");
-    if (pairs) *pairs = s->paths.size();
-    if (bad_pairs) *bad_pairs = s->bad_pairs;
-    if (walked) *walked = s->walked;
-    return GK_OK;
-}
-int gk_support_last_ms(const gk_support *s, float *ms5) {
-    if (!s || !ms5) return fail(nullptr, GK_E_INVALID, "gk_support_last_ms: null argument");
-    for (int i = 0; i < 5; i++) ms5[i] = s->last_ms[i];
-    return GK_OK;
-}
-int gk_support_export(const gk_support *s, uint32_t *e1, uint32_t *e2, uint32_t *count, uint64_t cap, uint64_t *n) {
-    if (!s) return fail(nullptr, GK_E_INVALID, "null support handle");
-    if (n) *n = s->paths.size();
-    if (s->paths.size() > cap) return fail(s->ctx, GK_E_CAPACITY, "gk_support_export: need room for " + std::to_string(s->paths.size()) + " pairs");
-    u64 i = 0;
-    for (const auto &kv : s->paths) { e1[i] = (u32)(kv.first >> 32); e2[i] = (u32)kv.first; count[i] = kv.second; i++; }
-    return GK_OK;
-}
-
-int gk_graph_id_bounds(gk_graph *g, uint64_t *node_ids, uint64_t *edge_ids) {
-    if (int rc = check_graph(g)) return rc;
-    if (node_ids) *node_ids = g->v.n_nodes;
-    if (edge_ids) *edge_ids = g->v.n_edges;
-    return GK_OK;
-}
-
-// GraphSimplifier.scala:188-247 over the first `npairs` pairs of a `.bin` stream (two records per pair)
-int gk_graph_walk_pairs(gk_graph *g, gk_vmap *positions, gk_support *sup, const uint8_t *bin, size_t nbytes, uint64_t npairs, int range_lo,
-                        int range_hi) {
-    if (int rc = check_graph(g)) return rc;
-    gk_ctx *ctx = g->ctx;
-    if (!positions || !sup || (!bin && nbytes)) return fail(ctx, GK_E_INVALID, "gk_graph_walk_pairs: null argument");
-    if (gk_vmap_k(positions) != g->k) return fail(ctx, GK_E_KLEN, "gk_graph_walk_pairs: the position map has another k");
-    if (range_lo < 0 || range_hi < range_lo || range_hi > 65535) return fail(ctx, GK_E_INVALID, "gk_graph_walk_pairs: range must satisfy 0 <= lo <= hi <= 65535");
-    const int k = g->k;
-    auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
-    const double t_begin = now();
-    // ---- the pairs whose mates both hold k bases (:213), their four keys
-    std::vector<u64> klo, khi;
-    auto four_keys = [k](const uint8_t *r1, int l1, const uint8_t *r2, int l2, u64 *lo4, u64 *hi4) {
-        u64 alo, ahi, blo, bhi, ralo, rahi, rblo, rbhi;
-        first_kmer(r1 + 1, (size_t)(l1 + 3) / 4, k, alo, ahi); first_kmer(r2 + 1, (size_t)(l2 + 3) / 4, k, blo, bhi);
-        revcomp_host(alo, ahi, k, ralo, rahi); revcomp_host(blo, bhi, k, rblo, rbhi);
-        // f1 = getAll(p1.take(k)), f2 = getAll(p2.take(k).revComplement), f3 = getAll(p2.take(k)), f4 = getAll(p1.take(k).revComplement)
-        lo4[0] = alo; lo4[1] = rblo; lo4[2] = blo; lo4[3] = ralo;
-        hi4[0] = ahi; hi4[1] = rbhi; hi4[2] = bhi; hi4[3] = rahi;
-    };
-    // A stream of equal-length records (what a sequencer's run is) is cut by several threads, each checking the length bytes
-    // of its share; one that turns out ragged is walked serially.
-    bool cut = false;
-    if (npairs >= 65536 && nbytes && bin[0] >= k) {
-        const int l0 = bin[0];
-        const size_t rb = 1 + (size_t)(l0 + 3) / 4;
-        if (nbytes >= 2 * npairs * rb) {
-            klo.resize((size_t)npairs * 4); khi.resize((size_t)npairs * 4);
-            const unsigned nt = (unsigned)std::max<u64>(1, std::min<u64>({(u64)std::thread::hardware_concurrency(), 16, npairs / 32768}));
-            std::vector<uint8_t> ragged(nt, 0);
-            auto share = [&](unsigned t) {
-                const uint64_t p0 = npairs * t / nt, p1 = npairs * (t + 1) / nt;
-                for (uint64_t p = p0; p < p1; p++) {
-                    const uint8_t *r1 = bin + 2 * p * rb, *r2 = r1 + rb;
-                    if (r1[0] != l0 || r2[0] != l0) { ragged[t] = 1; return; }
-                    four_keys(r1, l0, r2, l0, &klo[4 * p], &khi[4 * p]);
-                }
-            };
-            std::vector<std::thread> th;
-            for (unsigned t = 1; t < nt; t++) th.emplace_back(share, t);
-            share(0);
-            for (auto &x : th) x.join();
-            cut = true;
-            for (unsigned t = 0; t < nt; t++) if (ragged[t]) cut = false;
-            if (!cut) { klo.clear(); khi.clear(); }
-        }
-    }
-    if (!cut) {
-        klo.reserve((size_t)std::min<uint64_t>(npairs, nbytes / 2) * 4); khi.reserve(klo.capacity());
-        size_t pos = 0;
-        for (uint64_t p = 0; p < npairs && pos < nbytes; p++) {
-            const uint8_t *r1 = bin + pos;
-            const int l1 = r1[0];
-            pos += 1 + (size_t)(l1 + 3) / 4;
-            if (pos >= nbytes) return fail(ctx, GK_E_FORMAT, "gk_graph_walk_pairs: the stream ends inside a pair");
-            const uint8_t *r2 = bin + pos;
-            const int l2 = r2[0];
-            pos += 1 + (size_t)(l2 + 3) / 4;
-            if (pos > nbytes) return fail(ctx, GK_E_FORMAT, "gk_graph_walk_pairs: the stream ends inside a record");
-            if (l1 < k || l2 < k) continue;
-            u64 lo4[4], hi4[4];
-            four_keys(r1, l1, r2, l2, lo4, hi4);
-            klo.insert(klo.end(), lo4, lo4 + 4);
-            khi.insert(khi.end(), hi4, hi4 + 4);
-        }
-    }
-    const u64 nq = klo.size();
-    if (nq == 0) return GK_OK;
-    const double t_keys = now();
-    std::vector<u64> off(nq + 1), vals(std::max<u64>(nq * 2, 16));
-    u64 total = 0;
-    int rc = gk_vmap_get_all_batch(positions, klo.data(), khi.data(), nq, off.data(), vals.data(), vals.size(), &total);
-    if (rc == GK_E_CAPACITY) { vals.resize(total); rc = gk_vmap_get_all_batch(positions, klo.data(), khi.data(), nq, off.data(), vals.data(), vals.size(), &total); }
-    if (rc) return rc;
-    const double t_lookup = now();
-    const HostGraph *Hp = nullptr;
-    if (int rc2 = graph_snapshot_cached(g, &Hp)) return rc2;
-    const HostGraph &H = *Hp;
-    for (u64 i = 0; i < total; i++) {                       // a position must name something of THIS graph
-        const Pos p = decode_pos(vals[i]);
-        if (p.is_edge ? (p.id >= H.n_edges || !H.e_alive[p.id] || p.dist >= H.e_len[p.id]) : (p.id >= H.n_nodes || !H.node_alive[p.id]))
-            return fail(ctx, GK_E_STATE, "gk_graph_walk_pairs: the position map does not belong to this graph (rebuild it after edits)");
-    }
-    const double t_snap = now();
-    // ---- the walks, on host threads; every thread keeps its own counts
-    const u64 norient = nq / 2;                              // two orientations per pair: (f1, f2) and (f3, f4)  :219
-    const unsigned nthreads = (unsigned)std::max<u64>(1, std::min<u64>({(u64)std::thread::hardware_concurrency(), 16, norient / 64 + 1}));
-    std::vector<std::unordered_map<u64, u32>> local(nthreads);
-    std::vector<u64> bad(nthreads, 0), walked(nthreads, 0);
-    auto work = [&](unsigned t) {
-        Walker w(H, range_lo, range_hi);
-        std::vector<u64> pairs;
-        for (u64 o = t; o < norient; o += nthreads) {
-            const u64 *p1 = vals.data() + off[2 * o], *p2 = vals.data() + off[2 * o + 1];
-            const u64 n1 = off[2 * o + 1] - off[2 * o], n2 = off[2 * o + 2] - off[2 * o + 1];
-            bool same_edge = false;                          // annotate :192-206
-            for (u64 i = 0; i < n1 && !same_edge; i++) {
-                const Pos a = decode_pos(p1[i]);
-                if (!a.is_edge) continue;
-                for (u64 j = 0; j < n2; j++) {
-                    const Pos b = decode_pos(p2[j]);
-                    const long d = (long)b.dist - (long)a.dist + k;
-                    if (b.is_edge && a.id == b.id && d >= range_lo && d <= range_hi) { same_edge = true; break; }
-                }
-            }
-            if (same_edge || n1 == 0 || n2 == 0) continue;   // (`if !list.isEmpty` :231)
-            pairs.clear();
-            bool good = false;
-            for (u64 i = 0; i < n1; i++)
-                for (u64 j = 0; j < n2; j++) good |= w.walk(decode_pos(p1[i]), decode_pos(p2[j]), pairs);
-            std::sort(pairs.begin(), pairs.end());
-            pairs.erase(std::unique(pairs.begin(), pairs.end()), pairs.end());
-            for (u64 pr : pairs) local[t][pr]++;             // counter.incrementAndGet() once per pair orientation  :235-241
-            if (!good) bad[t]++;
-            walked[t]++;
-        }
-    };
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nthreads; t++) pool.emplace_back(work, t);
-    work(0);
-    for (auto &th : pool) th.join();
-    const double t_walks = now();
-    for (unsigned t = 0; t < nthreads; t++) {
-        for (const auto &kv : local[t]) sup->paths[kv.first] += kv.second;
-        sup->bad_pairs += bad[t];
-        sup->walked += walked[t];
-    }
-    const double t_end = now();
-    sup->last_ms[0] = (float)(t_keys - t_begin); sup->last_ms[1] = (float)(t_lookup - t_keys); sup->last_ms[2] = (float)(t_snap - t_lookup);
-    sup->last_ms[3] = (float)(t_walks - t_snap); sup->last_ms[4] = (float)(t_end - t_walks);
-    return GK_OK;
-}
-
-}  // extern "C"
-
-// ---- batch edits of the split (device)
-__global__ __launch_bounds__(BLOCK) void k_add_nodes(GraphView g, u32 first, const u32 *src, u64 n) {
-    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
-        const u32 v = first + (u32)i, s = src[i];            // graph.addNode(node.seq)  :306
-        g.node_lo[v] = g.node_lo[s]; g.node_hi[v] = g.node_hi[s];
-        g.node_alive[v] = 1;
-        g.out_order[v] = 0; g.in_deg[v] = 0;
-        for (int b = 0; b < 4; b++) g.out_edge[(u64)v * 4 + b] = NONE;
-    }
-}
-__global__ __launch_bounds__(BLOCK) void k_move_ends(GraphView g, const u32 *edge, const u32 *node, u64 n) {
-    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
-        const u32 e = edge[i], nn = node[i];                 // graph.replaceEnd(e, newNode)  :307, Graph.scala:204-209
-        atomicSub(&g.in_deg[g.e_end[e]], 1u);
-        atomicAdd(&g.in_deg[nn], 1u);
-        g.e_end[e] = nn;
-    }
-}
-__global__ __launch_bounds__(BLOCK) void k_move_starts(GraphView g, const u32 *edge, const u32 *node, u64 n) {
-    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
-        const u32 e = edge[i], nn = node[i];                 // graph.replaceStart(e, newNode)  :308, Graph.scala:197-202
-        const u32 old = g.e_start[e];
-        const int b = g.e_first[e];
-        if (atomicCAS(&g.out_edge[(u64)old * 4 + b], e, NONE) == e) {
-            u32 seen = g.out_order[old], prev;
-            do { prev = seen; seen = atomicCAS(&g.out_order[old], prev, order_remove(prev, b)); } while (seen != prev);
-        }
-        g.out_edge[(u64)nn * 4 + b] = e;                     // (a fresh node: no two of its edges share a first base)
-        u32 seen = g.out_order[nn], prev;
-        do { prev = seen; seen = atomicCAS(&g.out_order[nn], prev, order_append(prev, b)); } while (seen != prev);
-        g.e_start[e] = nn;
-    }
-}
-__global__ __launch_bounds__(BLOCK) void k_remove_edges_by_id(GraphView g, const u32 *edge, u64 n, unsigned long long *removed) {
-    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
-        const u32 e = edge[i];                               // MapGraph.removeEdge :191-195
-        if (e >= g.n_edges || !g.e_alive[e]) continue;
-        const u32 v = g.e_start[e];
-        const int b = g.e_first[e];
-        if (atomicCAS(&g.out_edge[(u64)v * 4 + b], e, NONE) == e) {
-            u32 seen = g.out_order[v], prev;
-            do { prev = seen; seen = atomicCAS(&g.out_order[v], prev, order_remove(prev, b)); } while (seen != prev);
-        }
-        g.e_alive[e] = 0;
-        atomicSub(&g.in_deg[g.e_end[e]], 1u);
-        atomicAdd(removed, 1ull);
-    }
-}
-
-extern "C" {
-
-int gk_graph_remove_edges_by_id(gk_graph *g, const uint32_t *edge_ids, uint64_t n, uint64_t *removed) {
-    if (int rc = check_graph(g)) return rc;
-    gk_ctx *ctx = g->ctx;
-    if (removed) *removed = 0;
-    if (n == 0) return GK_OK;
-    if (!edge_ids) return fail(ctx, GK_E_INVALID, "gk_graph_remove_edges_by_id: null argument");
-    std::vector<u32> ids(edge_ids, edge_ids + n);            // (a Set in the reference: each id once)
-    std::sort(ids.begin(), ids.end());
-    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
-    u32 *d_e = nullptr;
-    unsigned long long *d_rm = nullptr, h_rm = 0;
-    hipError_t e = hipMalloc((void **)&d_e, ids.size() * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_rm, 8);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_e, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(d_rm, 0, 8, ctx->stream);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_remove_edges_by_id, dim3(ggrid(ctx, ids.size())), dim3(BLOCK), 0, ctx->stream, g->v, d_e, (u64)ids.size(), d_rm);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(&h_rm, d_rm, 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_e); (void)hipFree(d_rm);
-    if (e != hipSuccess) return hip_fail(ctx, e, "gk_graph_remove_edges_by_id");
-    if (removed) *removed = h_rm;
-    return graph_refresh_counts(g);
-}
-
-// GraphSimplifier.scala:272-316: per node with in- and out-edges the support matrix, its connected groups at `cutoff`; a
-// group without an out-edge loses its in-edge, every other group moves to a copy of the node; out-edges no group reached
-// are removed.  (simplifyGraph :318 is the caller's next call.)  Nodes that exist when the call starts are visited.
-int gk_graph_split_by_support(gk_graph *g, const gk_support *sup, int cutoff, uint64_t *removed_edges, uint64_t *new_nodes) {
-    if (int rc = check_graph(g)) return rc;
-    gk_ctx *ctx = g->ctx;
-    if (removed_edges) *removed_edges = 0;
-    if (new_nodes) *new_nodes = 0;
-    if (!sup) return fail(ctx, GK_E_INVALID, "gk_graph_split_by_support: null support handle");
-    const HostGraph *Hp = nullptr;
-    if (int rc = graph_snapshot_cached(g, &Hp)) return rc;
-    const HostGraph &H = *Hp;
-    std::vector<u32> to_remove, new_src, end_edge, end_node, start_edge, start_node;
-    const u32 first_new = (u32)H.n_nodes;
-    for (u64 v = 0; v < H.n_nodes; v++) {
-        if (!H.node_alive[v]) continue;
-        const u32 *in = H.in_list.data() + H.in_off[v];
-        const int nin = (int)(H.in_off[v + 1] - H.in_off[v]);
-        u32 out[4];
-        int nout = 0;
-        for (int b = 0; b < 4; b++) if (H.out_edge[v * 4 + b] != NONE) out[nout++] = H.out_edge[v * 4 + b];
-        if (nin == 0 || nout == 0) continue;                                         // :273
-        auto support = [&](int i, int j) -> u32 {
-            auto it = sup->paths.find(((u64)in[i] << 32) | out[j]);
-            return it == sup->paths.end() ? 0u : it->second;
-        };
-        std::vector<char> col_l(nin, 0);
-        bool col_r[4] = {false, false, false, false};
-        for (int i0 = 0; i0 < nin; i0++) {
-            if (col_l[i0]) continue;
-            // the group of in-edge i0: alternate between the two sides until nothing is added (dfsLeft / dfsRight :280-301)
-            std::vector<int> l{ i0 }, r, todo_l{ i0 }, todo_r;
-            col_l[i0] = 1;
-            while (!todo_l.empty() || !todo_r.empty()) {
-                if (!todo_l.empty()) {
-                    const int i = todo_l.back(); todo_l.pop_back();
-                    for (int j = 0; j < nout; j++) if (!col_r[j] && (int)support(i, j) >= cutoff) { col_r[j] = true; r.push_back(j); todo_r.push_back(j); }
-                } else {
-                    const int j = todo_r.back(); todo_r.pop_back();
-                    for (int i = 0; i < nin; i++) if (!col_l[i] && (int)support(i, j) >= cutoff) { col_l[i] = 1; l.push_back(i); todo_l.push_back(i); }
-                }
-            }
-            if (r.empty()) to_remove.push_back(in[i0]);                             // :304
-            else {
-                const u32 nn = first_new + (u32)new_src.size();
-                new_src.push_back((u32)v);
-                for (int i : l) { end_edge.push_back(in[i]); end_node.push_back(nn); }          // :307
-                for (int j : r) { start_edge.push_back(out[j]); start_node.push_back(nn); }     // :308
-            }
-        }
-        for (int j = 0; j < nout; j++) if (!col_r[j]) to_remove.push_back(out[j]);  // :311
-    }
-    GraphView &v = g->v;
-    const u64 nnew = new_src.size();
-    if (v.n_nodes + nnew >= (u64)NONE) return fail(ctx, GK_E_CAPACITY, "more than 2^32 graph nodes");
-    if (nnew) {
-        if (v.n_nodes + nnew > g->node_cap) { if (int rc = graph_grow_nodes(g, std::max<u64>(g->node_cap * 2, v.n_nodes + nnew))) return rc; }
-        u32 *d_src = nullptr, *d_a = nullptr, *d_b = nullptr;
-        const u64 nmv = std::max<u64>(end_edge.size(), start_edge.size());
-        hipError_t e = hipMalloc((void **)&d_src, nnew * 4);
-        if (e == hipSuccess) e = hipMalloc((void **)&d_a, std::max<u64>(nmv, 1) * 4);
-        if (e == hipSuccess) e = hipMalloc((void **)&d_b, std::max<u64>(nmv, 1) * 4);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_src, new_src.data(), nnew * 4, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_add_nodes, dim3(ggrid(ctx, nnew)), dim3(BLOCK), 0, ctx->stream, v, first_new, d_src, nnew);
-            e = hipGetLastError();
-        }
-        v.n_nodes += nnew;                                    // (the kernels below index the new nodes)
-        if (e == hipSuccess && !end_edge.empty()) {
-            e = hipMemcpyAsync(d_a, end_edge.data(), end_edge.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(d_b, end_node.data(), end_node.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-            if (e == hipSuccess) { hipLaunchKernelGGL(k_move_ends, dim3(ggrid(ctx, end_edge.size())), dim3(BLOCK), 0, ctx->stream, v, d_a, d_b, (u64)end_edge.size()); e = hipGetLastError(); }
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);      // d_a / d_b are reused below
-        }
-        if (e == hipSuccess && !start_edge.empty()) {
-            e = hipMemcpyAsync(d_a, start_edge.data(), start_edge.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(d_b, start_node.data(), start_node.size() * 4, hipMemcpyHostToDevice, ctx->stream);
-            if (e == hipSuccess) { hipLaunchKernelGGL(k_move_starts, dim3(ggrid(ctx, start_edge.size())), dim3(BLOCK), 0, ctx->stream, v, d_a, d_b, (u64)start_edge.size()); e = hipGetLastError(); }
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        (void)hipFree(d_src); (void)hipFree(d_a); (void)hipFree(d_b);
-        if (e != hipSuccess) return hip_fail(ctx, e, "gk_graph_split_by_support");
-        if (int rc = graph_build_index(g)) return rc;         // several nodes share a sequence now: the index lists them all
-    }
-    uint64_t removed = 0;
-    if (!to_remove.empty()) { if (int rc = gk_graph_remove_edges_by_id(g, to_remove.data(), to_remove.size(), &removed)) return rc; }   // :316
-    if (removed_edges) *removed_edges = removed;
-    if (new_nodes) *new_nodes = nnew;
-    return graph_refresh_counts(g);
 }
 
 }  // extern "C"

@@ -1267,6 +1267,7 @@ void part_scratch_free(gk_ctx *ctx, PartScratch *ps) {
 template <int W>
 static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d_keys, u64 nkeys_in, u64 nkeys_bound, bool from_empty,
                     const PartPlan &plan) {
+    const unsigned long long occ_before = m->occ_cached;     // the windows counted by earlier batches of this call (every batch ends with map_sync_counters)
     gk_ctx *ctx = m->ctx;
     Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u, 0u};
     PartArrays a;
@@ -1504,10 +1505,10 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         return GK_OK;
     };
     auto abandon = [&](bool table_touched) -> int {
-        unsigned long long occ = 0;
-        if (d_rec) {   // P2 already counted this batch's windows
-            GK_HIP(ctx, hipMemcpy(&occ, &m->d_ctr->occurrences, 8, hipMemcpyDeviceToHost));
-            occ -= std::min<unsigned long long>(occ, nkeys_bound);
+        if (d_rec) {   // P2 already counted this batch's windows: back to what the counter held when the batch began.  (Until round 3
+                       // the batch's BOUND was subtracted — for super-k-mer records an upper bound, not the windows they hold — which
+                       // took earlier batches' windows with it: a 1.9e9-window exchange that retried its second batch reported half.)
+            unsigned long long occ = occ_before;
             GK_HIP(ctx, hipMemcpy(&m->d_ctr->occurrences, &occ, 8, hipMemcpyHostToDevice));
             m->occ_cached = occ;
         }

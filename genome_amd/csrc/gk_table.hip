@@ -732,6 +732,8 @@ int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value) {
     }
     else if (n == "p4_grid") ctx->hook_p4_grid = (int)value;
     else if (n == "graph_walk_queue") ctx->hook_walk_queue = (int)value;
+    else if (n == "pairs_host") ctx->hook_pairs_host = (int)value;
+    else if (n == "test_pairs_small_sets") ctx->hook_pairs_small_sets = (int)value;
     else if (n == "filter_classic") ctx->hook_filter_classic = (int)value;
     else if (n == "graph_load_pct") ctx->hook_graph_load_pct = (int)value;
     else if (n == "fine_exact") ctx->hook_fine_exact = value < 0 ? -1 : value != 0;

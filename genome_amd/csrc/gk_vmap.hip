@@ -270,6 +270,17 @@ int vmap_put_new_dev(gk_vmap *m, const uint64_t *d_lo, const uint64_t *d_hi, con
 }
 int vmap_k(const gk_vmap *m) { return m->k; }
 gk_ctx *vmap_ctx(const gk_vmap *m) { return m->ctx; }
+// getAll for keys already in HBM, results left in HBM (the paired-end stage, gk_pairs.hip): pass 0 counts into d_cnt[n]; the
+// caller turns the counts into CSR offsets d_off[n + 1] and allocates d_out; pass 1 fills.  Stream-ordered, nothing is waited for.
+int vmap_get_all_dev(gk_vmap *m, const uint64_t *d_lo, const uint64_t *d_hi, uint64_t n, const unsigned long long *d_off, uint32_t *d_cnt, uint64_t *d_out) {
+    gk_ctx *ctx = m->ctx;
+    if (n == 0) return GK_OK;
+    const int grid = vgrid(ctx, n);
+    if (m->W == 1) hipLaunchKernelGGL(k_vm_get_all<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, vtable<1>(m), d_lo, d_hi, n, 0xffffffffu, d_off, d_cnt, d_out);
+    else hipLaunchKernelGGL(k_vm_get_all<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, vtable<2>(m), d_lo, d_hi, n, 0xffffffffu, d_off, d_cnt, d_out);
+    GK_HIP(ctx, hipGetLastError());
+    return GK_OK;
+}
 }  // namespace gk
 
 extern "C" {

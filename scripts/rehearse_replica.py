@@ -28,7 +28,7 @@ def main():
     ap.add_argument("--k", type=int, default=55)
     ap.add_argument("--genome", type=int, default=1_500_000_000)
     ap.add_argument("--coverage", type=float, default=6.0)
-    ap.add_argument("--chunk", type=int, default=20_000_000)
+    ap.add_argument("--chunk", type=int, default=10_000_000)
     ap.add_argument("--both", type=int, default=1, help="1: build the graph in both unitig constructions and compare")
     ap.add_argument("--out", default="gpurun_out/replica.json")
     a = ap.parse_args()
@@ -47,7 +47,9 @@ def main():
         ctx.synth_reads(d, c, L_, "G", 44, first, G, 0.0)
         sent, owned = dm.count_reads_dev(d, c, L_)
         occ += owned
-        print(f"counted {first + c} reads, {dm.local.size()} keys", flush=True)
+        st = dm.local.stats()
+        print(f"counted {first + c} reads, {dm.local.size()} keys", {k_: st[k_] for k_ in ("slots", "partitioned_launches", "direct_launches", "spilled_keys",
+              "failed_segments", "retries_direct", "repeat_heavy", "grows")}, dm.local.last_phase_ms(), flush=True)
     rep["count_s"] = time.perf_counter() - t0
     rep["windows"], rep["keys"] = occ, dm.size()
     ctx.free(d)

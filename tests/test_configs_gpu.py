@@ -147,8 +147,8 @@ def _graph_stage(ctx, pm, k, budget, tag):
     total = pm.size()
     want = pm.verify()
     ctx.trim()
-    elsewhere = sum(p.slots() * slot for p in pm.parts[1:])           # tables that are on other GPUs in the real run
-    base0 = ctx.mem_stats(reset_peak=True)["live"] - pm.parts[0].slots() * slot   # reads etc.: not this stage's
+    # what is on this GPU but would not be on rank 0's in the real run: the reads buffer and the other seven partitions' tables
+    base0 = ctx.mem_stats(reset_peak=True)["live"] - pm.parts[0].slots() * slot
     ctx.set_mem_budget(budget + base0)
     report = {"config": tag, "k": k, "keys": total, "budget_bytes": budget}
     try:
@@ -165,7 +165,7 @@ def _graph_stage(ctx, pm, k, budget, tag):
         full = pm.merged()
         report["gather_s"] = time.perf_counter() - t0
         assert full.size() == total and full.verify_checksum() == want
-        peak_gather = ctx.mem_stats()["peak"] - base0 - elsewhere
+        peak_gather = ctx.mem_stats()["peak"] - base0                 # (base0 holds the reads AND the seven partitions that are elsewhere in the real run)
         report["gather_peak_bytes"] = peak_gather
         report["replica_slots"], report["replica_load"] = full.slots(), total / full.slots()
         pm.close()
@@ -281,7 +281,7 @@ def test_c5_one_rank_share_k63_partitioned_prefiltered(ctx):
     _share(ctx, k=63, n=250_000_000, G=387_500_000, e=0.002, cfg=5, chunk=25_000_000, with_plain=False, graph_stage="c5_share_k63")
 
 
-@pytest.mark.parametrize("k,L_,hint", [(31, 150, 1_500_000_000), (55, 150, 720_000_000)])
+@pytest.mark.parametrize("k,L_,hint", [(31, 150, 1_500_000_000), (55, 150, 960_000_000)])
 def test_table_beyond_34_gb_stays_on_the_partitioned_pipeline(ctx, k, L_, hint):
     """C4's and C5's per-rank tables are 50-100 GB.  256 L1 buckets x 4096 fine buckets x 32 KiB end at 34 GB: a table that
     needs more gets 512 or 1024 L1 buckets (plan_segments) and keeps the LDS segment build — which used to hand such tables to

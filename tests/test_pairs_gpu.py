@@ -259,3 +259,31 @@ def test_walk_pairs_large_uniform_stream_is_cut_by_threads(ctx, ragged):
     assert len(want) > 0
     assert gpu_support_by_content(g, k, sup) == want
     vm.close(); g.close(); m.close()
+
+
+@pytest.mark.parametrize("mode", ["pairs_host", "test_pairs_small_sets"])
+@pytest.mark.parametrize("k,seed,err,rng", [(21, 2, 0.004, (55, 90)), (35, 4, 0.0, (50, 80))])
+def test_walk_pairs_host_form_and_overflow_fallback_give_the_same_support(ctx, mode, k, seed, err, rng):
+    """The walks run one wave per pair orientation on the device; an orientation whose sets outgrow the wave's LDS goes to the
+    host walker instead (exact either way), and `pairs_host` = 1 sends ALL of them there (the round-2 form, kept as an A/B
+    switch).  With the device's sets made tiny (test_pairs_small_sets) most orientations overflow: the mix of device-walked and
+    host-walked orientations must still add up to the oracle's support counts, bad pairs and walked orientations."""
+    reads = make_pairs(seed, k, err=err)
+    binb = dna.reads_to_bin(reads)
+    npairs = len(reads) // 2
+    m, ref = HipDNAMap(ctx, k), O.PMap(k, 1)
+    m.count_reads(binb, len(reads)); ref.count_reads(binb, len(reads))
+    m.deleteAll_lt(2); ref.delete_lt(2)
+    g, og = buildGraph(k, m), O.Graph(ref)
+    vm = g.getGraphMap()
+    sup, osup = Support(ctx), O.Support()
+    ctx.set_option(mode, 1)
+    try:
+        g.walkPairs(vm, sup, binb, npairs, *rng)
+    finally:
+        ctx.set_option(mode, 0)
+    walked = og.walk_pairs(osup, binb, npairs, *rng)
+    assert sup.sizes()[1:] == (osup.bad_pairs(), walked)
+    assert gpu_support_by_content(g, k, sup) == oracle_support_by_content(og, k, osup)
+    assert g.splitBySupport(sup, 3) == og.split_by_support(osup, 3)
+    vm.close(); g.close(); m.close()
