@@ -84,7 +84,7 @@ def cpu_baseline(rec_host: np.ndarray, nreads_total: int, k: int, target_s: floa
                               "sample": f"first {sample1} reads, {dt1:.1f} s, one ArrayDNAMap"}}
 
 
-def c2_variant(ctx, rec_ptr, n, L, k, mode, steps, warmup, host_buf=None):
+def c2_variant(ctx, rec_ptr, n, L, k, mode, steps, warmup, host_buf=None, prefetch=False):
     """C2 again, outside the headline: mode G (5 Mbp genome, 30x, 1 % error — repeats) device-resident, or the §8(d) reading
     of the metric: packed reads in PINNED HOST memory -> complete table in HBM (gk_map_count_reads: the upload runs in
     sub-chunks on a copy stream and overlaps the L1 scatter of the pipeline)."""
@@ -93,11 +93,13 @@ def c2_variant(ctx, rec_ptr, n, L, k, mode, steps, warmup, host_buf=None):
     m = HipDNAMap(ctx, k, int(n * nk * 1.05))
     kms, phases = [], []
 
-    def step():
+    def step(more=False):
         m.clear()
         if host_buf is None:
             m.count_reads_dev(rec_ptr, n, L)
         else:
+            if prefetch and more:                   # a streaming caller: the NEXT batch's upload is started before this batch is counted
+                m.prefetch_reads(host_buf, n)
             m.count_reads(host_buf, n)
         kms.append(m.last_count_kernel()[0]); phases.append(m.last_phase_ms())
 
@@ -105,9 +107,11 @@ def c2_variant(ctx, rec_ptr, n, L, k, mode, steps, warmup, host_buf=None):
         step()
     kms.clear(); phases.clear()
     ctx.sync()
+    if prefetch and host_buf is not None:
+        m.prefetch_reads(host_buf, n)
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
+    for i in range(steps):
+        step(i + 1 < steps)
     ctx.sync()
     dt = (time.perf_counter() - t0) / steps
     distinct = m.size()
@@ -207,6 +211,28 @@ def c3_object(ctx):
                                                    "frac_of_hbm_peak": k_[name]["moved_frac_of_hbm_peak"]}
                                             for name in ("k_classify<1>", "k_walk_q<1>", "k_filter_lt<1>", "k_rehash<1>") if name in k_}
         res["roofline"]["moved_by_pmc"]["source"] = os.path.relpath(pmc, ROOT)
+    # the same count from PINNED HOST memory (1.95 GB of `.bin` -> filtered table): the stream is cut where the device-resident count cuts
+    # its batches, the first chunk's upload overlaps its own L1 scatter piece by piece, every later chunk's upload runs beside the
+    # previous chunk's fine level (two staging areas)
+    if res is not None:
+        try:
+            nbytes = N * synth.record_stride(L)
+            hbuf = ctx.host_alloc(nbytes)
+            step_b = 256 << 20
+            for o in range(0, nbytes, step_b):
+                hbuf[o:o + step_b] = ctx.download(d + o, min(step_b, nbytes - o))
+            for timed in (False, True):
+                m.clear()
+                t0 = time.perf_counter(); occ_h = m.count_reads(hbuf, N); t_count = time.perf_counter() - t0
+                ph = m.last_phase_ms()
+                t0 = time.perf_counter(); m.deleteAll_lt(3); t_filter = time.perf_counter() - t0
+            res["host_fed"] = {"count_ms": t_count * 1e3, "filter_lt_ms": t_filter * 1e3, "occurrences": occ_h, "good_kmers_ge3": m.size(),
+                               "phases_ms": dict(zip(["k_part_hist1", "k_part_scatter1", "k_part_hist2+scans", "k_part_scatter2", "k_seg_insert"], ph)),
+                               "over_device_resident_count": t_count * 1e3 / res["wall_ms"]["count"], "host_bytes": nbytes,
+                               "what": "gk_map_count_reads over the same reads in pinned host memory, then filter_lt(3)"}
+            ctx.host_free(hbuf)
+        except Exception as e:          # noqa: BLE001
+            res["host_fed"] = {"error": repr(e)}
     m.close(); ctx.free(d)
     return res
 
@@ -476,11 +502,16 @@ def main():
 
             def pcie():
                 hb[:] = ctx.download(rec, n * stride)
-                o = c2_variant(ctx, None, n, L, k, "U", 10, 2, host_buf=hb)
+                single = c2_variant(ctx, None, n, L, k, "U", 10, 2, host_buf=hb)
+                o = c2_variant(ctx, None, n, L, k, "U", 10, 2, host_buf=hb, prefetch=True)
+                o["one_call_at_a_time_ms_per_step"] = single["ms_per_step"]
+                o["one_call_at_a_time_phases_ms"] = single["phases_ms"]
                 o["host_buffer_pages_per_numa_node"] = numa_of(hb.ctypes.data)
                 o["gpu_numa_nodes_sysfs"] = gpu_numa_node()
                 o["workload"] = ("SURVEY.md §8(d) reading of the metric: the headline's reads as a `.bin` stream in PINNED HOST memory -> complete "
-                                 "table in HBM (gk_map_count_reads; host framing walk + PCIe upload in sub-chunks overlapped with the L1 scatter)")
+                                 "table in HBM, 10 steps back to back the way a streaming caller runs them: gk_map_prefetch_reads starts batch i+1's "
+                                 "upload before gk_map_count_reads counts batch i, so the copy runs beside batch i's fine level (one_call_at_a_time = no "
+                                 "prefetch: the upload in sub-chunks overlapped with the L1 scatter only)")
                 ctx.host_free(hb)
                 return o
 

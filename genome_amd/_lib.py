@@ -79,6 +79,7 @@ SIGNATURES = {
     "gk_map_size": (C.c_int, [vp, u64p]),
     "gk_map_slots": (C.c_int, [vp, u64p]),
     "gk_map_count_reads": (C.c_int, [vp, u8p, C.c_size_t, C.c_uint64, u64p]),
+    "gk_map_prefetch_reads": (C.c_int, [vp, u8p, C.c_size_t, C.c_uint64]),
     "gk_map_count_reads_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, u64p]),
     "gk_map_update_inc": (C.c_int, [vp, u64p, u64p, C.c_uint64]),
     "gk_map_update_inc_dev": (C.c_int, [vp, vp, C.c_uint64]),

@@ -966,18 +966,40 @@ __global__ __launch_bounds__(BLOCK) void k_cc_hook(GraphView g, u32 *parent, u32
 __global__ __launch_bounds__(BLOCK) void k_cc_compress(GraphView g, u32 *parent) {
     for (u64 n = (u64)blockIdx.x * BLOCK + threadIdx.x; n < g.n_nodes; n += (u64)gridDim.x * BLOCK) parent[n] = cc_root(parent, (u32)n);
 }
-// component sizes.  A giant component means millions of increments of ONE counter, and same-address
-// atomics retire at ~88 per microsecond chip-wide (143 ms of the 169 ms retain step at C3): lanes of a
-// wave that share a root are combined first (ballot per distinct root), then one atomic per group.
+// Component sizes and summed edge lengths.  A giant component means millions of increments of ONE counter, and same-address
+// atomics retire at ~88 per microsecond chip-wide (143 ms of the 169 ms retain step at C3 in round 1; 7.7-10 ms in round 2
+// with a per-wave carry: still 4.4e5 atomics on the giant root).  Now every WORKGROUP keeps a (root -> partial sum) table in
+// LDS for its whole share of the nodes / edges: lanes of a wave that share a root are combined first (ballot), the wave adds
+// its partial to the LDS table, and the table goes out once, at the end — one global atomic per (workgroup, root): 2048 on the
+// giant root.  A root that finds the LDS table full goes straight to memory (distinct small components: no contention there).
+static constexpr u32 CC_TAB = 1024;
+template <class T> struct CcTable {
+    u32 root[CC_TAB];
+    T sum[CC_TAB];
+    __device__ __forceinline__ void clear() { for (u32 i = threadIdx.x; i < CC_TAB; i += BLOCK) { root[i] = NONE; sum[i] = 0; } }
+    // one lane per call and root
+    __device__ __forceinline__ void add(u32 r, T v, T *global) {
+        u32 h = hash32(r) & (CC_TAB - 1);
+        for (u32 n = 0; n < 16; n++) {
+            u32 cur = root[h];
+            if (cur == NONE) cur = atomicCAS(&root[h], NONE, r);
+            if (cur == NONE || cur == r) { atomicAdd(&sum[h], v); return; }
+            h = (h + 1) & (CC_TAB - 1);
+        }
+        atomicAdd(&global[r], v);
+    }
+    __device__ __forceinline__ void flush(T *global) {
+        for (u32 i = threadIdx.x; i < CC_TAB; i += BLOCK) if (root[i] != NONE && sum[i]) atomicAdd(&global[root[i]], sum[i]);
+    }
+};
 __global__ __launch_bounds__(BLOCK) void k_cc_sizes(GraphView g, const u32 *parent, u32 *size, unsigned long long *ncomp) {
+    __shared__ CcTable<u32> tab;
     __shared__ u32 s_roots;
     if (threadIdx.x == 0) s_roots = 0;
+    tab.clear();
     __syncthreads();
     const int lane = threadIdx.x & 63;
     u32 nroots = 0;
-    // (and the wave carries the last root's count from group to group: with a giant component nearly every group of 64 nodes
-    //  has that one root, so the wave adds it ONCE at the end instead of once per group — 4.4e5 atomics on one address at C3)
-    u32 c_root = 0xffffffffu, c_cnt = 0;                // wave-uniform
     for (u64 n0 = (u64)blockIdx.x * BLOCK + (threadIdx.x & ~63u); n0 < g.n_nodes; n0 += (u64)gridDim.x * BLOCK) {   // wave-uniform trip count
         const u64 n = n0 + lane;
         const bool active = n < g.n_nodes && g.node_alive[n];
@@ -987,28 +1009,23 @@ __global__ __launch_bounds__(BLOCK) void k_cc_sizes(GraphView g, const u32 *pare
             const int leader = __ffsll((long long)todo) - 1;
             const u32 lr = __shfl(root, leader);
             const unsigned long long same = __ballot(active && root == lr);
-            const u32 cnt = (u32)__popcll(same);
-            if (lr == c_root) c_cnt += cnt;
-            else if (cnt >= 8) {                        // a root that fills an eighth of the wave is worth carrying; the rest go straight out
-                if (lane == 0 && c_cnt) atomicAdd(&size[c_root], c_cnt);
-                c_root = lr; c_cnt = cnt;
-            } else if (lane == leader) atomicAdd(&size[lr], cnt);
+            if (lane == leader) tab.add(lr, (u32)__popcll(same), size);
             todo &= ~same;
         }
         nroots += (u32)__popcll(__ballot(active && root == (u32)n));
     }
-    if (lane == 0 && c_cnt) atomicAdd(&size[c_root], c_cnt);
     if (lane == 0 && nroots) atomicAdd(&s_roots, nroots);
     __syncthreads();
+    tab.flush(size);
     if (threadIdx.x == 0 && s_roots) atomicAdd(ncomp, (unsigned long long)s_roots);
 }
 // summed out-edge length per component (GraphBuilder.scala:44-46: comp.flatMap(_.outEdges.values).map(_.seq.size).sum): every
-// live edge adds its length to the root of its start node; lanes of a wave that share a root are combined first
+// live edge adds its length to the root of its start node
 __global__ __launch_bounds__(BLOCK) void k_cc_edge_len(GraphView g, const u32 *parent, unsigned long long *len) {
+    __shared__ CcTable<unsigned long long> tab;
+    tab.clear();
+    __syncthreads();
     const int lane = threadIdx.x & 63;
-    u32 c_root = 0xffffffffu;                           // wave-uniform: the last root's sum travels from group to group (see k_cc_sizes)
-    unsigned long long c_len = 0;
-    bool c_any = false;
     for (u64 e0 = (u64)blockIdx.x * BLOCK + (threadIdx.x & ~63u); e0 < g.n_edges; e0 += (u64)gridDim.x * BLOCK) {
         const u64 e = e0 + lane;
         const bool active = e < g.n_edges && g.e_alive[e];
@@ -1022,16 +1039,13 @@ __global__ __launch_bounds__(BLOCK) void k_cc_edge_len(GraphView g, const u32 *p
             const unsigned long long same = __ballot(mine);
             unsigned long long part = mine ? mylen : 0ull;
             for (int d = 32; d; d >>= 1) part += __shfl_down(part, d);
-            part = __shfl(part, 0);
-            if (c_any && lr == c_root) c_len += part;
-            else if (__popcll(same) >= 8) {
-                if (lane == 0 && c_any) atomicAdd(&len[c_root], c_len);
-                c_root = lr; c_len = part; c_any = true;
-            } else if (lane == leader) atomicAdd(&len[lr], part);
+            const unsigned long long tot = __shfl(part, 0);           // (lane 0 holds the wave's sum of this root's lengths)
+            if (lane == leader) tab.add(lr, tot, len);
             todo &= ~same;
         }
     }
-    if (lane == 0 && c_any) atomicAdd(&len[c_root], c_len);
+    __syncthreads();
+    tab.flush(len);
 }
 // one (node count, summed out-edge length) pair per component, in root order
 __global__ __launch_bounds__(BLOCK) void k_cc_collect(GraphView g, const u32 *parent, const u32 *size, const unsigned long long *len,

@@ -41,6 +41,8 @@ struct gk_ctx {
     int hook_p45_stripes = -1;       // over-provisioned fine level: stripes of L1 buckets whose P5 overlaps the next stripe's P4 (-1/1: none)
     int hook_graph_load_pct = -1;    // load factor (percent) of the table map_compact builds for the graph phase (-1: 40, 30 at k = 64)
     int hook_filter_classic = -1;    // deleteAll: 1 = tombstones + k_rehash (the older path), else the one-pass segment-wise filter + compaction
+    int64_t hook_max_stage = 0;      // test hook: bytes of `.bin` records per staging area (0: 704 MiB), so that a small stream is cut into many chunks
+    int hook_host_prefetch = -1;     // host-fed count: 0 = do not upload the next chunk beside the current chunk's P3 / P4 / P5 (A/B)
     int hook_pairs_host = -1;        // paired-end walks: 1 = all of them on host threads over a snapshot (the round-2 form), else one wave per pair orientation
     int hook_pairs_small_sets = -1;  // test hook: the device walks get tiny LDS sets, so that most orientations overflow to the host walker
     int hook_walk_queue = -1;        // unitig walk: 0 = one edge per lane (k_walk pass 0), else lanes fed from a queue (k_walk_q)
@@ -81,6 +83,9 @@ struct ReadSrc {
     // length.  The L1 scatter then checks every length byte for equality, and a mismatch gives the chunk back (PART_NOT_UNIFORM)
     // before anything but scratch has been touched.
     bool verify_uniform = false;
+    // the records were PREFETCHED: their upload to `rec` is already queued on the copy stream and this event fires when they
+    // have landed — the consumer waits for it instead of uploading (gk_map_count_reads looks one chunk ahead; gk_map_prefetch_reads)
+    hipEvent_t ready = nullptr;
 };
 int stage_source(gk_ctx *ctx, const ReadSrc &src);      // upload a host-fed source in one piece, stream-ordered on ctx->stream
 }
@@ -127,9 +132,17 @@ struct gk_map {
     uint64_t max_batch_keys = 0;         // 0 = default: windows per partitioned batch when the call's reads exceed the table's room
     float last_count_ms = 0.f;
     uint64_t last_count_occ = 0;
-    // staging buffer reused by host-fed count_reads
-    void *d_stage = nullptr;
-    size_t stage_bytes = 0;
+    // two staging areas of host-fed count_reads: one being consumed, one being filled by the copy stream (gk_table.hip)
+    struct StageSlot {
+        void *d = nullptr;
+        size_t cap = 0;
+        const uint8_t *host = nullptr;   // what was PREFETCHED into this area and not consumed yet (valid): host address, bytes
+        size_t bytes = 0;
+        bool valid = false;
+        hipEvent_t ev = nullptr;         // fires when the prefetched bytes have landed
+    } stage[2];
+    int stage_cur = 0;                   // the area the current (or last) chunk lives in
+    int stage_last_pf = 1;               // the area the last prefetch went to
     void *d_offsets = nullptr;
     size_t offsets_bytes = 0;
     // partitioned insert path (gk_partition.hip)

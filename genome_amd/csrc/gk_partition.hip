@@ -1428,6 +1428,12 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
                 launch_p2((int)std::min<u64>(std::max<u64>(nt, 1), (u64)ctx->cu_count * GK_OP_WGS_PER_CU), d_rec + (size_t)r0 * src.stride, nr);
                 if (int rc = piece_done(j, npieces)) return rc;
             }
+        } else if (src.ready) {
+            // Host-fed and PREFETCHED: the whole chunk's upload was queued on the copy stream while the previous chunk (or the
+            // caller's previous call) was in its fine level; one scatter behind the event.
+            GK_HIP(ctx, hipStreamWaitEvent(ctx->stream, src.ready, 0));
+            launch_p2(grid, d_rec, src.nreads);
+            if (pipelined) { if (int rc = piece_done(0, 1)) return rc; }
         } else {
             // Host-fed: upload in sub-chunks on the copy stream, scatter each as soon as it has landed.  The L1 regions are
             // append-only (cursor1), so P2 can run once per sub-chunk; P4 and P5 then see one batch.  With the caller's buffer

@@ -489,6 +489,7 @@ int map_sync_counters(gk_map *m) {
 
 int stage_source(gk_ctx *ctx, const ReadSrc &src) {
     if (!src.host) return GK_OK;
+    if (src.ready) { GK_HIP(ctx, hipStreamWaitEvent(ctx->stream, src.ready, 0)); return GK_OK; }      // prefetched: already on its way
     GK_HIP(ctx, hipMemcpyAsync(const_cast<uint8_t *>(src.rec), src.host, src.host_bytes, hipMemcpyHostToDevice, ctx->stream));
     return GK_OK;
 }
@@ -733,6 +734,8 @@ int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value) {
     else if (n == "p4_grid") ctx->hook_p4_grid = (int)value;
     else if (n == "graph_walk_queue") ctx->hook_walk_queue = (int)value;
     else if (n == "pairs_host") ctx->hook_pairs_host = (int)value;
+    else if (n == "host_prefetch") ctx->hook_host_prefetch = (int)value;
+    else if (n == "test_max_stage") ctx->hook_max_stage = (int64_t)std::max<int64_t>(0, value);
     else if (n == "test_pairs_small_sets") ctx->hook_pairs_small_sets = (int)value;
     else if (n == "filter_classic") ctx->hook_filter_classic = (int)value;
     else if (n == "graph_load_pct") ctx->hook_graph_load_pct = (int)value;
@@ -913,7 +916,8 @@ void gk_map_destroy(gk_map *m) {
     if (m->slots) (void)hipFree(m->slots);
     if (m->d_ctr) (void)hipFree(m->d_ctr);
     if (m->h_status) (void)hipHostFree(m->h_status);
-    if (m->d_stage) (void)hipFree(m->d_stage);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);       // (a prefetch may be on its way)
+    for (int i = 0; i < 2; i++) { if (m->stage[i].d) (void)hipFree(m->stage[i].d); if (m->stage[i].ev) (void)hipEventDestroy(m->stage[i].ev); }
     if (m->d_offsets) (void)hipFree(m->d_offsets);
     if (m->d_sample) (void)hipFree(m->d_sample);
     if (m->d_scratch) (void)hipFree(m->d_scratch);
@@ -989,6 +993,10 @@ static int launch_count(gk_map *m, const ReadSrc &src) {
     return GK_OK;
 }
 
+// bytes of `.bin` records one staging area holds at most: what one partitioned batch of 2^31 windows takes (150 bp reads, k = 31:
+// 17.9 M records of 39 bytes) — a host-fed count then cuts its stream where the device-resident one cuts its batches
+static constexpr size_t GK_MAX_STAGE_DEFAULT = 704u << 20;
+static inline size_t max_stage(const gk_ctx *ctx) { return ctx->hook_max_stage > 0 ? (size_t)ctx->hook_max_stage : GK_MAX_STAGE_DEFAULT; }
 static int reset_occ_counter(gk_map *m) {
     GK_HIP(m->ctx, hipMemsetAsync(&m->d_ctr->occurrences, 0, sizeof(unsigned long long), m->ctx->stream));
     m->occ_cached = 0;
@@ -1227,6 +1235,55 @@ int gk_map_count_superkmers_dev(gk_map *m, const void *dev_records, uint64_t nre
     return GK_OK;
 }
 
+// ---- host-fed streams: TWO staging areas in HBM ---------------------------------------------------------------------------
+// While the pipeline works on the chunk in one of them (its P3 / P4 / P5 never touch the records again), the copy stream
+// fills the other with the NEXT chunk — of the same call (the loop below looks one chunk ahead) or of the caller's next call
+// (gk_map_prefetch_reads).  The chunk that was prefetched is then scattered in one launch behind the upload's event; a chunk
+// that was not (the first of a call) is uploaded in pieces with P2 running on each piece as it lands (gk_partition.hip).
+// Every insert ends synchronised, so an area is free again as soon as its chunk's call has returned: no further events.
+static int stage_reserve(gk_map *m, int slot, size_t bytes) {
+    gk_ctx *ctx = m->ctx;
+    gk_map::StageSlot &st = m->stage[slot];
+    if (st.cap >= bytes) return GK_OK;
+    if (st.d) GK_HIP(ctx, hipFree(st.d));
+    st.d = nullptr; st.cap = 0;
+    GK_HIP(ctx, hipMalloc(&st.d, bytes));
+    st.cap = bytes;
+    return GK_OK;
+}
+// start the upload of host bytes [p, p + bytes) into a staging area that is not `in_use` (-1: none is) and remember what is on
+// its way; of two free areas the one that holds no unconsumed prefetch, else the older prefetch is overwritten
+static int stage_prefetch(gk_map *m, const uint8_t *p, size_t bytes, int in_use) {
+    gk_ctx *ctx = m->ctx;
+    int slot;
+    if (in_use >= 0) slot = 1 - in_use;
+    else if (m->stage[0].valid != m->stage[1].valid) slot = m->stage[0].valid ? 1 : 0;
+    else slot = 1 - m->stage_last_pf;
+    gk_map::StageSlot &st = m->stage[slot];
+    st.valid = false;
+    if (int rc = stage_reserve(m, slot, bytes + 64)) return rc;
+    if (!st.ev) GK_HIP(ctx, hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+    GK_HIP(ctx, hipMemcpyAsync(st.d, p, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    GK_HIP(ctx, hipEventRecord(st.ev, ctx->copy_stream));
+    st.host = p; st.bytes = bytes; st.valid = true;
+    m->stage_last_pf = slot;
+    return GK_OK;
+}
+
+int gk_map_prefetch_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nreads) {
+    if (int rc = check_map_lazy(m)) return rc;
+    gk_ctx *ctx = m->ctx;
+    if (!bin || !nbytes || !nreads) return fail(ctx, GK_E_INVALID, "gk_map_prefetch_reads: empty stream");
+    // (only the head of a long stream: what the next call's first chunk will hold at most)
+    {
+        // the head of the stream: whole records, as many as the next call's first chunk can hold (equal-length records assumed — a
+        // ragged stream's first chunk may end elsewhere, and the prefetch is then simply not used)
+        const size_t rb = 1 + (size_t)(bin[0] + 3) / 4;
+        const size_t want = std::min<size_t>(nbytes, std::max<size_t>(rb, max_stage(ctx) / rb * rb));
+        return stage_prefetch(m, bin, want, -1);
+    }
+}
+
 int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nreads, uint64_t *occurrences) {
     if (int rc = check_map_lazy(m)) return rc;
     gk_ctx *ctx = m->ctx;
@@ -1236,103 +1293,127 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
     if (nreads == 0) return GK_OK;
     if (int rc = reset_occ_counter(m)) return rc;
     // Walk the record framing once on the host (one length byte per record, PairedEndData.scala:24-31),
-    // cutting the stream into launches bounded in bytes (staging buffer) and in windows (load limit).
-    const size_t MAX_STAGE = 256u << 20;
-    size_t pos = 0;
-    u64 r = 0;
-    bool walk_this_chunk = false;
-    std::vector<u32> offs;
-    while (r < nreads) {
-        const size_t chunk_begin = pos;
-        const u64 r_begin = r;
-        u64 occ = 0;
-        const u64 occ_limit = reads_per_launch(m, 1);
-        offs.clear();
+    // cutting the stream into launches bounded in bytes (staging area) and in windows (load limit, key scratch).
+    struct Chunk {
+        size_t begin = 0, bytes = 0;
+        u64 r_begin = 0, reads = 0, occ = 0;
         int first_len = -1;
-        bool uniform = true;            // every record of the chunk has the same length: fixed stride, no offset table
+        bool uniform = true, unverified = false, valid = false;
+        std::vector<u32> offs;
+    };
+    // the chunk that starts at (pos, r); GK_E_FORMAT through *err
+    auto cut = [&](size_t pos, u64 r, bool walk, int *err) {
+        Chunk c;
+        c.begin = pos; c.r_begin = r;
+        if (r >= nreads) return c;
+        const size_t chunk_begin = pos;
+        u64 occ = 0;
+        // windows per chunk: what the table has room for on the direct path; one partitioned batch's key scratch otherwise
+        const u64 occ_limit = std::max<u64>(reads_per_launch(m, 1), use_partitioned(m, part_batch_keys(m)) ? part_batch_keys(m) : 0);
+        bool fast_prefix = false;
         // Fast prefix: a run of equal-length records (one sequencing run) is recognised by comparing one byte per
         // record, with no offset table built; it becomes a chunk of its own when it is long enough to be worth it.
-        bool fast_prefix = false, unverified = false;
         if (pos < nbytes) {
             const int len0 = bin[pos];
             const size_t rb0 = 1 + (size_t)(len0 + 3) / 4;
             const u64 nk0 = len0 >= m->k ? (u64)(len0 - m->k + 1) : 0;
             u64 cap = std::min<u64>(nreads - r, (nbytes - pos) / rb0);
-            cap = std::min<u64>(cap, std::max<u64>(1, MAX_STAGE / rb0));
+            cap = std::min<u64>(cap, std::max<u64>(1, max_stage(ctx) / rb0));
             if (nk0) cap = std::min<u64>(cap, std::max<u64>(1, occ_limit / nk0));
             const uint8_t *p0 = bin + pos;
             u64 run = 0;
             // What is left is EXACTLY (reads left) records of this length: one sequencing run, almost surely.  Then the
             // host does not walk a million length bytes (~1 ms per 39 MB: a third of the whole insert) — the L1 scatter
             // checks them on the device as it goes, and gives the chunk back if one differs (PART_NOT_UNIFORM).
-            const bool looks_uniform = !walk_this_chunk && !ctx->hook_host_ragged && !ctx->hook_part_exact && nk0 && (nbytes - pos) == (size_t)(nreads - r) * rb0 &&
+            const bool looks_uniform = !walk && !ctx->hook_host_ragged && !ctx->hook_part_exact && nk0 && (nbytes - pos) == (size_t)(nreads - r) * rb0 &&
                                        cap >= 4096 && use_partitioned(m, cap * nk0) && nk0 * (u64)m->W <= (u64)5632;
-            if (looks_uniform) { run = cap; unverified = true; }
+            if (looks_uniform) { run = cap; c.unverified = true; }
             while (run < cap && p0[run * rb0] == (uint8_t)len0) run++;
             if (run >= 4096 || (run == nreads - r && run > 0)) {
                 fast_prefix = true;
-                first_len = len0;
+                c.first_len = len0;
                 pos += run * rb0;
                 occ = run * nk0;
                 r += run;
-            }
+            } else c.unverified = false;
         }
         while (!fast_prefix && r < nreads) {
-            if (pos >= nbytes) return fail(ctx, GK_E_FORMAT, "truncated .bin stream: record " + std::to_string(r) + " starts past the end");
+            if (pos >= nbytes) { *err = 1; return c; }
             int len = bin[pos];
-            if (first_len < 0) first_len = len; else if (len != first_len) uniform = false;
+            if (c.first_len < 0) c.first_len = len; else if (len != c.first_len) c.uniform = false;
             size_t rb = 1 + (size_t)(len + 3) / 4;
-            if (pos + rb > nbytes) return fail(ctx, GK_E_FORMAT, "truncated .bin stream inside record " + std::to_string(r));
+            if (pos + rb > nbytes) { *err = 2; return c; }
             u64 nk = len >= m->k ? (u64)(len - m->k + 1) : 0;
-            if (r > r_begin && (pos + rb - chunk_begin > MAX_STAGE || occ + nk > occ_limit)) break;
-            offs.push_back((u32)(pos - chunk_begin));
+            if (r > c.r_begin && (pos + rb - chunk_begin > max_stage(ctx) || occ + nk > occ_limit)) break;
+            c.offs.push_back((u32)(pos - chunk_begin));
             pos += rb;
             occ += nk;
             r++;
         }
-        if (!offs.empty()) offs.push_back((u32)(pos - chunk_begin));
-        const size_t cbytes = pos - chunk_begin;
-        const u64 creads = r - r_begin;
-        if (m->stage_bytes < cbytes + 64) {
-            if (m->d_stage) GK_HIP(ctx, hipFree(m->d_stage));
-            m->d_stage = nullptr;
-            m->stage_bytes = 0;
-            GK_HIP(ctx, hipMalloc(&m->d_stage, cbytes + 64));
-            m->stage_bytes = cbytes + 64;
+        if (!c.offs.empty()) c.offs.push_back((u32)(pos - chunk_begin));
+        c.bytes = pos - chunk_begin; c.reads = r - c.r_begin; c.occ = occ;
+        c.valid = c.reads > 0;
+        return c;
+    };
+    auto format_error = [&](int err, const Chunk &c) {
+        return fail(ctx, GK_E_FORMAT, err == 1 ? "truncated .bin stream: record " + std::to_string(c.r_begin + c.reads) + " starts past the end"
+                                                : "truncated .bin stream inside record " + std::to_string(c.r_begin + c.reads));
+    };
+    int err = 0;
+    Chunk cur = cut(0, 0, false, &err);
+    if (err) return format_error(err, cur);
+    while (cur.valid) {
+        // this chunk's staging area: the one its bytes were prefetched into (by the previous round of this loop, or by
+        // gk_map_prefetch_reads before the call), else the one that is free
+        bool preloaded = false;
+        for (int sl = 0; sl < 2 && !preloaded; sl++) {
+            gk_map::StageSlot &st = m->stage[sl];
+            if (st.valid && st.host == bin + cur.begin && st.bytes >= cur.bytes) { preloaded = true; m->stage_cur = sl; st.valid = false; }
         }
-        if (m->offsets_bytes < offs.size() * sizeof(u32)) {
+        if (!preloaded) {
+            m->stage_cur = m->stage[0].valid && !m->stage[1].valid ? 1 : 0;       // (spare an unconsumed prefetch if one of the areas holds none)
+            m->stage[m->stage_cur].valid = false;
+            if (int rc = stage_reserve(m, m->stage_cur, cur.bytes + 64)) return rc;
+        }
+        // one chunk ahead: its upload runs on the copy stream beside this chunk's P3 / P4 / P5
+        Chunk nxt = cut(cur.begin + cur.bytes, cur.r_begin + cur.reads, false, &err);
+        if (err) return format_error(err, nxt);
+        if (nxt.valid && ctx->hook_host_prefetch != 0) { if (int rc = stage_prefetch(m, bin + nxt.begin, nxt.bytes, m->stage_cur)) return rc; }
+        if (m->offsets_bytes < cur.offs.size() * sizeof(u32)) {
             if (m->d_offsets) GK_HIP(ctx, hipFree(m->d_offsets));
             m->d_offsets = nullptr;
             m->offsets_bytes = 0;
-            GK_HIP(ctx, hipMalloc(&m->d_offsets, offs.size() * sizeof(u32)));
-            m->offsets_bytes = offs.size() * sizeof(u32);
+            GK_HIP(ctx, hipMalloc(&m->d_offsets, cur.offs.size() * sizeof(u32)));
+            m->offsets_bytes = cur.offs.size() * sizeof(u32);
         }
-        // the records stay in host memory for now: the consumer uploads them (ReadSrc::host)
+        // the records stay in host memory for now: the consumer uploads them (ReadSrc::host) — unless they are on their way already
         // a chunk of equal-length records (the usual case: one sequencing run) is a fixed-stride array: no offset
         // table to upload, and the partitioned path can take its one-extraction form
         ReadSrc src;
-        src.rec = (const uint8_t *)m->d_stage;
-        src.nreads = creads;
-        src.host = bin + chunk_begin;
-        src.host_bytes = cbytes;
-        src.verify_uniform = unverified;
-        if (uniform && first_len >= 0 && !ctx->hook_host_ragged) {
-            src.stride = 1 + (u32)(first_len + 3) / 4;
-            src.max_len = first_len;
+        src.rec = (const uint8_t *)m->stage[m->stage_cur].d;
+        src.nreads = cur.reads;
+        src.host = bin + cur.begin;
+        src.host_bytes = cur.bytes;
+        src.ready = preloaded ? m->stage[m->stage_cur].ev : nullptr;
+        src.verify_uniform = cur.unverified;
+        if (cur.uniform && cur.first_len >= 0 && !ctx->hook_host_ragged) {
+            src.stride = 1 + (u32)(cur.first_len + 3) / 4;
+            src.max_len = cur.first_len;
         } else {
-            GK_HIP(ctx, hipMemcpyAsync(m->d_offsets, offs.data(), offs.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+            GK_HIP(ctx, hipMemcpyAsync(m->d_offsets, cur.offs.data(), cur.offs.size() * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
             src.off = (const u32 *)m->d_offsets;
             src.max_len = 255;             // the host has walked this framing: every length byte is what the offsets say
         }
-        const int brc = insert_batch(m, src, nullptr, 0, occ);
+        const int brc = insert_batch(m, src, nullptr, 0, cur.occ);
         if (brc == PART_NOT_UNIFORM) {       // take the chunk again, this time walking its framing
-            pos = chunk_begin;
-            r = r_begin;
-            walk_this_chunk = true;
+            GK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));     // (a prefetch of the chunk after it may be in flight: it is simply dropped)
+            m->stage[0].valid = m->stage[1].valid = false;
+            cur = cut(cur.begin, cur.r_begin, true, &err);
+            if (err) return format_error(err, cur);
             continue;
         }
-        if (brc) return brc;
-        walk_this_chunk = false;
+        if (brc) { (void)hipStreamSynchronize(ctx->copy_stream); m->stage[0].valid = m->stage[1].valid = false; return brc; }
+        cur = nxt;
     }
     uint64_t occ = 0;
     if (int rc = read_occ_counter(m, &occ)) return rc;
@@ -1723,7 +1804,8 @@ int gk_map_trim(gk_map *m) {
     if (int rc = check_map_lazy(m)) return rc;
     gk_ctx *ctx = m->ctx;
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (m->d_stage) { (void)hipFree(m->d_stage); m->d_stage = nullptr; m->stage_bytes = 0; }
+    GK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    for (int i = 0; i < 2; i++) { m->stage[i].valid = false; if (m->stage[i].d) { (void)hipFree(m->stage[i].d); m->stage[i].d = nullptr; m->stage[i].cap = 0; } }
     if (m->d_offsets) { (void)hipFree(m->d_offsets); m->d_offsets = nullptr; m->offsets_bytes = 0; }
     if (m->d_scratch) { (void)hipFree(m->d_scratch); m->d_scratch = nullptr; m->scratch_bytes = 0; }
     part_scratch_free(ctx, m->part);

@@ -256,6 +256,11 @@ class HipDNAMap:
         L.check(L.lib().gk_map_count_reads(self.h, L.ptr(buf, C.c_uint8), buf.size, nreads, C.byref(occ)), self.ctx.h)
         return occ.value
 
+    def prefetch_reads(self, bin_bytes, nreads: int):
+        """start the upload of a (pinned) `.bin` stream's head; the next count_reads of the same buffer finds it on the device"""
+        buf = np.frombuffer(bin_bytes, np.uint8) if not isinstance(bin_bytes, np.ndarray) else np.ascontiguousarray(bin_bytes, np.uint8).reshape(-1)
+        L.check(L.lib().gk_map_prefetch_reads(self.h, L.ptr(buf, C.c_uint8), buf.size, nreads), self.ctx.h)
+
     def count_reads_dev(self, d_records: int, nreads: int, read_len: int) -> int:
         occ = C.c_uint64()
         L.check(L.lib().gk_map_count_reads_dev(self.h, d_records, nreads, read_len, C.byref(occ)), self.ctx.h)

@@ -146,6 +146,14 @@ int gk_map_trim(gk_map *m);
  * keys (sequencing coverage: mostly repeats): the insert pipeline samples the distinct keys it sees and sizes the
  * table for those (gk_map_stats: "est_new_distinct_last_batch"). */
 int gk_map_count_reads(gk_map *m, const uint8_t *bin_host, size_t nbytes, uint64_t nreads, uint64_t *occurrences);
+/* Start uploading the head of a `.bin` stream NOW (asynchronously, on the copy stream, into the staging area the map is not
+ * using) and return: the next gk_map_count_reads on THIS map whose stream starts at the same address then finds its first chunk
+ * on the device and scatters it in one launch.  A streaming caller prefetches batch i+1 before it counts batch i: the upload
+ * runs beside batch i's fine level.  (gk_map_count_reads does the same by itself between the chunks of ONE long stream.)  The
+ * buffer must be page-locked (gk_host_alloc / gk_host_register) for the copy to be asynchronous, and must stay unchanged until
+ * the count that consumes it has returned.  Reference: the reader thread of S/data/FreqFilter.scala:44-51 running ahead of
+ * the inserts through the actors' mailboxes. */
+int gk_map_prefetch_reads(gk_map *m, const uint8_t *bin_host, size_t nbytes, uint64_t nreads);
 /* same, records already in HBM at a fixed stride 1+ceil(read_len/4); read_len = the LONGEST record (shorter ones
  * are fine).  Device records are untrusted input: a length byte above read_len is clamped, never followed, and
  * the call then fails with GK_E_FORMAT (the map's contents are unspecified: clear it). */

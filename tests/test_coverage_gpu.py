@@ -370,3 +370,58 @@ def test_growth_across_a_change_of_the_l1_fan_out(ctx, k):
     finally:
         ctx.set_option("min_lnb1", 0)
         m.close(); ctx.free(d)
+
+
+@pytest.mark.parametrize("k", [21, 47])
+@pytest.mark.parametrize("shape", ["uniform", "odd_record", "ragged"])
+@pytest.mark.parametrize("path", ["auto", "partitioned", "direct"])
+def test_host_stream_in_many_chunks_with_the_next_chunk_uploaded_ahead(ctx, k, shape, path):
+    """A long host stream is cut into chunks of one staging area each; while the pipeline works on one chunk the copy stream
+    uploads the NEXT one into the second staging area, and that chunk is then scattered in one launch behind the upload's event
+    (gk_table.hip, two staging areas).  Here the staging size is shrunk (test_max_stage) so that a 26 000-read stream takes ~10
+    chunks: uniform records, a stream that only LOOKS uniform (one record a base shorter: the device check sends that chunk back
+    through the host walk while the chunk after it is already on its way), and a ragged stream (offset tables).  The table must
+    be the oracle's, with the look-ahead switched off too, and pinned as well as pageable host memory must work."""
+    n, L_ = 26000, 100
+    rec = synth.reads_mode_g(n, L_, 40000, 0.01, config_id=100 + k)
+    if shape == "odd_record":
+        rec = rec.copy()
+        rec[n // 2 + 7, 0] = L_ - 1
+        rec[n // 2 + 7, -1] &= 0x3f
+        stream = rec.tobytes()
+    elif shape == "ragged":
+        rnd = random.Random(k)
+        reads = [dna.unpack_2bit(rec[i, 1:], L_)[:rnd.choice([L_, L_ - 3, k, k - 1, 60])] for i in range(n)]
+        stream = dna.reads_to_bin(reads)
+    else:
+        stream = rec.tobytes()
+    ref = O.PMap(k, 1)
+    occ = ref.count_reads(stream, n)
+    want = ref.export_sorted()
+    ctx.set_option("test_max_stage", 64 << 10)
+    try:
+        for ahead in (1, 0):
+            ctx.set_option("host_prefetch", ahead)
+            m = HipDNAMap(ctx, k, occ)
+            m.set_insert_path(path)
+            assert m.count_reads(stream, n) == occ
+            assert_same_table(m.sorted_items(), want)
+            m.close()
+        # pinned memory (asynchronous copies for real), and the caller's own prefetch of the stream's head
+        hb = ctx.host_alloc(len(stream))
+        hb[:] = np.frombuffer(stream, np.uint8)
+        m = HipDNAMap(ctx, k, occ)
+        m.set_insert_path(path)
+        m.prefetch_reads(hb, n)
+        assert m.count_reads(hb, n) == occ
+        assert_same_table(m.sorted_items(), want)
+        m.prefetch_reads(hb, n)                           # a prefetch nobody consumes: the next count is of ANOTHER buffer
+        m.clear()
+        assert m.count_reads(stream, n) == occ
+        assert_same_table(m.sorted_items(), want)
+        m.prefetch_reads(hb, n)                           # ... and one that is still pending when the map goes away
+        m.close()
+        ctx.host_free(hb)
+    finally:
+        ctx.set_option("test_max_stage", 0)
+        ctx.set_option("host_prefetch", -1)
