@@ -144,6 +144,7 @@ SIGNATURES = {
     "gk_graph_retain_largest": (C.c_int, [vp, u64p, u64p]),
     "gk_graph_component_stats": (C.c_int, [vp, C.POINTER(C.c_uint32), u64p, C.c_uint64, u64p]),
     "gk_graph_checksum": (C.c_int, [vp, u64p, u64p]),
+    "gk_graph_bucketed_table_stats": (C.c_int, [vp, C.POINTER(C.c_float), u64p]),
     "gk_graph_build_stats": (C.c_int, [vp, C.POINTER(C.c_float), u64p, C.POINTER(C.c_int)]),
     "gk_graph_export_nodes": (C.c_int, [vp, u64p, u64p, C.c_uint64, u64p]),
     "gk_graph_export_edges": (C.c_int, [vp, u64p, u64p, u64p, u64p, i64p, i64p, C.c_uint64, u64p, u8p, C.c_uint64, u64p]),

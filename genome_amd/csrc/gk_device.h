@@ -418,6 +418,70 @@ template <int W> GK_D Kmer<W> slot_key(const Slot<W> *slots, u64 i, u32 tagged) 
     return from_stored(load_stored(&slots[i]), tagged ? (u32)(i & 3u) : 0u);
 }
 
+// ------------------------------------------------------------------------------------------
+// MINIMIZER-BUCKETED table (the graph phase's own copy of the k-mer set, gk_graph.hip): bucket = owner_of(key, k, nb), i.e. a
+// hash of the k-mer's strand-symmetric minimizer, so that consecutive k-mers of the genome — a k-mer and most of its 8
+// de Bruijn neighbours, a unitig's next step — sit in ONE small region (a power of two of slots, load <= 0.5) instead of in
+// eight random 128-byte lines of a hashed table: the classify pass and the unitig walks then find their probes in L1 / L2.
+// Probing is linear inside the region from the key's slot hash.  Read-only after it is built; k = 64 keeps the hashed table.
+// ------------------------------------------------------------------------------------------
+template <int W> struct MbTable {
+    Slot<W> *slots;          // the regions, back to back
+    const u64 *off;          // [nb + 1]: first slot of every bucket's region
+    u32 nb;
+    u32 both;                // as Table::both
+    u64 nslots;
+    static constexpr u32 tagged = 0;
+    GK_HD u64 capacity() const { return nslots; }
+};
+template <int W> GK_HD u32 mb_bucket(const MbTable<W> &t, Kmer<W> x, int k) { return (u32)owner_of(x, k, (int)t.nb); }
+// where a key's probe starts, and the region it stays in: {first slot of the region, size - 1, start position}
+template <int W> struct ProbeAt { const Slot<W> *reg; u64 base; u32 mask, pos, step; };
+template <int W> GK_D ProbeAt<W> probe_at(const Table<W> &t, Kmer<W> q, int) {
+    const u64 h = slot_hash(q);
+    const u64 base = (u64)seg_of(t, h) << SegBits<W>::value;
+    const u32 pos = t.tagged ? ((seg_pos<W>(h) & ~3u) | key_tag(q)) : home_pos(t, h);
+    return ProbeAt<W>{t.slots + base, base, (1u << SegBits<W>::value) - 1u, pos, t.tagged ? 4u : 1u};
+}
+template <int W> GK_D ProbeAt<W> probe_at_bucket(const MbTable<W> &t, Kmer<W> q, u32 b) {
+    const u64 base = t.off[b];
+    const u32 mask = (u32)(t.off[b + 1] - base) - 1u;
+    return ProbeAt<W>{t.slots + base, base, mask, (u32)slot_hash(q) & mask, 1u};
+}
+template <int W> GK_D ProbeAt<W> probe_at(const MbTable<W> &t, Kmer<W> q, int k) { return probe_at_bucket(t, q, mb_bucket(t, q, k)); }
+// linear probe from p.pos (the caller may have looked at that slot already: `skip_first`); global slot index or -1
+template <int W> GK_D i64 probe_find(const ProbeAt<W> &p, Kmer<W> key, bool skip_first = false) {
+    const Stored<W> k = to_stored(key);
+    u32 i = skip_first ? (p.pos + p.step) & p.mask : p.pos;
+    for (u32 n = skip_first ? p.step : 0u; n <= p.mask; n += p.step) {
+        const u64 c0 = p.reg[i].w0;
+        if constexpr (W == 1) { if (c0 == k.w0) return (i64)(p.base + i); }
+        else { if (c0 == k.w0 && p.reg[i].w1 == k.w1) return (i64)(p.base + i); }
+        if (c0 == KEY_EMPTY) return -1;
+        i = (i + p.step) & p.mask;
+    }
+    return -1;
+}
+template <int W> GK_D i64 table_find(const MbTable<W> &t, Kmer<W> key, int k) { return probe_find(probe_at(t, key, k), key); }
+template <int W> GK_D i64 table_find(const Table<W> &t, Kmer<W> key, int) { return table_find(t, key); }
+template <int W> GK_D Kmer<W> slot_key(const MbTable<W> &t, u64 i) { return from_stored(load_stored(&t.slots[i])); }
+template <int W> GK_D Kmer<W> slot_key(const Table<W> &t, u64 i) { return slot_key(t.slots, i, t.tagged); }
+// `contains` on either strand (see table_find_either below): x and rc(x) share their bucket, so ONE minimizer serves both probes
+template <int W> GK_D i64 table_find_either(const MbTable<W> &t, Kmer<W> x, int k, bool *fwd) {
+    Kmer<W> rc = revcomp(x, k);
+    const i32 hx = ref_hash(x), hr = ref_hash(rc);
+    const u32 b = mb_bucket(t, x, k);
+    if (!t.both) {
+        if (hx < hr) { *fwd = true; return probe_find(probe_at_bucket(t, x, b), x); }
+        if (hx > hr) { *fwd = false; return probe_find(probe_at_bucket(t, rc, b), rc); }
+    }
+    const bool x_first = !kmer_less(rc, x);
+    const i64 s = probe_find(probe_at_bucket(t, x_first ? x : rc, b), x_first ? x : rc);
+    if (s >= 0) { *fwd = x_first; return s; }
+    *fwd = !x_first;
+    return probe_find(probe_at_bucket(t, x_first ? rc : x, b), x_first ? rc : x);
+}
+
 // Graph.buildGraph `contains` (Graph.scala:270): either strand.  Only the hash-rule canonical
 // orientation can be a stored key, except in the tie h(x) == h(rc x) where occurrences seen as x
 // are filed under rc x and vice versa (FreqFilter.scala:31-32) — then both are probed, the

@@ -58,6 +58,8 @@ struct gk_graph {
     float build_ms[6] = {0, 0, 0, 0, 0, 0};
     u64 walked_bases = 0;        // bases emitted by the unitig construction (= total edge length at build time)
     int used_pj = 0;
+    float mbt_ms = 0;            // building the minimizer-bucketed copy of the table, when the build used one ("graph_mbt")
+    u64 mbt_slots = 0;
     // host snapshot of the edge arrays for the paired-end walks, valid while `epoch` (bumped by every edit) has not moved:
     // a stream of gk_graph_walk_pairs batches downloads the graph once
     u64 epoch = 0, snap_epoch = ~0ull;

@@ -34,6 +34,7 @@
 using namespace gk;
 
 #include "gk_graph.h"
+#include "gk_scan.h"
 
 template <int W> __device__ __forceinline__ Kmer<W> node_kmer(const GraphView &g, u64 n);
 template <> __device__ __forceinline__ Kmer<1> node_kmer<1>(const GraphView &g, u64 n) { return Kmer<1>{g.node_lo[n]}; }
@@ -82,10 +83,18 @@ __device__ __forceinline__ u64 block_reserve(u32 v, unsigned long long *cursor, 
 // ---------------------------------------------------------------------------------------------
 // build
 // ---------------------------------------------------------------------------------------------
+template <class T> struct is_mb { static constexpr bool value = false; };
+template <int W> struct is_mb<MbTable<W>> { static constexpr bool value = true; };
+// score of one m-mer as minimizer_score has it: hash of its canonical form (gk_device.h)
+__device__ __forceinline__ u32 mmer_score(u32 w, int m) {
+    const u32 r = (u32)revcomp(Kmer<1>{(u64)w}, m).lo;
+    return hash32(w < r ? w : r);
+}
+
 // op1 of Graph.buildGraph (Graph.scala:320-329) for every live stored key: incoming/outcoming
 // through `contains` on both strands (:270-282), 8 lookups per key; result kept in the slot.
-template <int W>
-__global__ __launch_bounds__(BLOCK) void k_classify(Table<W> t, int k, unsigned long long *n_term) {
+template <int W, class TT>
+__global__ __launch_bounds__(BLOCK) void k_classify(TT t, int k, unsigned long long *n_term) {
     // The table this runs on is 40 % full (map_compact): walking the slots directly leaves 60 % of every wave idle through
     // the eight lookups.  A workgroup therefore takes CLASSIFY_SPT slots per thread at a time, compacts the live ones'
     // indices into LDS (ballot + one LDS atomic per wave) and classifies from that dense list: every lane has work, and a
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(BLOCK) void k_classify(Table<W> t, int k, unsigned 
     for (u32 li = threadIdx.x; li < nlive; li += BLOCK) {
         const u64 i = base + s_idx[li];
         Slot<W> *s = &t.slots[i];
-        Kmer<W> y = slot_key(t.slots, i, t.tagged);
+        Kmer<W> y = slot_key(t, i);
         u32 in = 0, out = 0;
         // The 8 lookups are independent, but each is a dependent chain that starts with a cold random
         // sector; done one after the other a lane has ONE miss in flight (168 ms for 1.5e8 16-byte keys).
@@ -126,10 +135,25 @@ __global__ __launch_bounds__(BLOCK) void k_classify(Table<W> t, int k, unsigned 
         // CU the touched lines (0.5 MB) do not survive in the 32 KiB L1 — nor, 32 CUs to an XCD, in its 4 MiB L2 — until the
         // resolve loop comes back to them, and re-reading them there fetched most sectors from memory TWICE.
         Kmer<W> q[8];
-        const Slot<W> *qseg[8];
-        u32 qpos[8];
+        ProbeAt<W> pa[8];
         u64 w0v[8];
         u32 ties = 0;
+        // (minimizer-bucketed table: the candidates' buckets from ONE pass over this k-mer's m-mers — a candidate shares k - 1
+        //  bases with it, so its minimizer is the minimum of the shared windows' scores and of its one new window)
+        u32 base_succ = 0xffffffffu, base_pred = 0xffffffffu;
+        const int mm_ = k < 11 ? k : 11;
+        if constexpr (is_mb<TT>::value) {
+            const int nwin = k - mm_ + 1;
+            u32 mid = 0xffffffffu, s_first = 0xffffffffu, s_last = 0xffffffffu;
+            for (int wdw = 0; wdw < nwin; wdw++) {
+                const u32 sc = mmer_score((u32)window_bits(y, 2 * wdw) & (u32)low_mask(2 * mm_), mm_);
+                if (wdw == 0) s_first = sc;
+                if (wdw == nwin - 1) s_last = sc;
+                if (wdw != 0 && wdw != nwin - 1) mid = min(mid, sc);
+            }
+            base_succ = nwin > 1 ? min(mid, s_last) : 0xffffffffu;          // windows 1 .. nwin-1 of y = windows 0 .. nwin-2 of a successor
+            base_pred = nwin > 1 ? min(mid, s_first) : 0xffffffffu;         // windows 0 .. nwin-2 of y = windows 1 .. nwin-1 of a predecessor
+        }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const Kmer<W> x = (j & 1) ? append_base(y, j >> 1, k) : prepend_base(j >> 1, y, k);
@@ -137,10 +161,14 @@ __global__ __launch_bounds__(BLOCK) void k_classify(Table<W> t, int k, unsigned 
             const i32 hx = ref_hash(x), hr = ref_hash(rc);
             if ((hx == hr || t.both) && !(x == rc)) ties |= 1u << j;   // both strands may be stored: slow path below
             q[j] = hx < hr ? x : rc;
-            const u64 h = slot_hash(q[j]);
-            qseg[j] = t.slots + ((u64)seg_of(t, h) << SegBits<W>::value);
-            qpos[j] = t.tagged ? ((seg_pos<W>(h) & ~3u) | key_tag(q[j])) : home_pos(t, h);
-            w0v[j] = qseg[j][qpos[j]].w0;
+            if constexpr (is_mb<TT>::value) {
+                const u32 neww = (u32)window_bits(x, (j & 1) ? 2 * (k - mm_) : 0) & (u32)low_mask(2 * mm_);
+                const u32 score = min((j & 1) ? base_succ : base_pred, mmer_score(neww, mm_));
+                pa[j] = probe_at_bucket(t, q[j], (u32)(((u64)hash32(score ^ 0x5bd1e995u) * (u64)t.nb) >> 32));
+            } else {
+                pa[j] = probe_at(t, q[j], k);
+            }
+            w0v[j] = pa[j].reg[pa[j].pos].w0;
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -151,14 +179,12 @@ __global__ __launch_bounds__(BLOCK) void k_classify(Table<W> t, int k, unsigned 
                 hit = table_find_either(t, x, k, &f) >= 0;
             } else {
                 // first slot from the register; only a slot that is occupied by ANOTHER key sends the probe on (to memory)
-                constexpr u32 smask = (1u << SegBits<W>::value) - 1u;
-                const u32 step = t.tagged ? 4u : 1u;
                 if (w0v[j] == KEY_EMPTY) hit = false;
                 else {
                     bool first_is_it;
                     if constexpr (W == 1) first_is_it = w0v[j] == q[j].lo;
-                    else { const Stored<2> sk = to_stored(q[j]); first_is_it = w0v[j] == sk.w0 && qseg[j][qpos[j]].w1 == sk.w1; }
-                    hit = first_is_it || seg_find(qseg[j], (qpos[j] + step) & smask, q[j], t.tagged) >= 0;
+                    else { const Stored<2> sk = to_stored(q[j]); first_is_it = w0v[j] == sk.w0 && pa[j].reg[pa[j].pos].w1 == sk.w1; }
+                    hit = first_is_it || probe_find(pa[j], q[j], true) >= 0;
                 }
             }
             if (hit) { if (j & 1) out |= 1u << (j >> 1); else in |= 1u << (j >> 1); }
@@ -171,7 +197,7 @@ __global__ __launch_bounds__(BLOCK) void k_classify(Table<W> t, int k, unsigned 
         // is marked SECONDARY so the pair yields one pair of nodes
         Kmer<W> rc = revcomp(y, k);
         bool secondary = false;
-        if ((t.both || ref_hash(y) == ref_hash(rc)) && !(y == rc) && kmer_less(rc, y) && table_find(t, rc) >= 0) secondary = true;
+        if ((t.both || ref_hash(y) == ref_hash(rc)) && !(y == rc) && kmer_less(rc, y) && table_find(t, rc, k) >= 0) secondary = true;
         if (secondary) aux |= AUX_SECONDARY;
         s->aux = aux;
         if (term && !secondary) cnt++;
@@ -186,8 +212,8 @@ __global__ __launch_bounds__(BLOCK) void k_classify(Table<W> t, int k, unsigned 
 // The terminal slots, compacted.  One workgroup takes 16 slots per thread at a time and reserves its output with ONE atomic:
 // the cursor is a single address, and same-address atomics retire at ~88 per microsecond chip-wide — one per 256 slots
 // (1.25e6 of them over C3's 3.2e8-slot table) was 15 of this kernel's 16 ms.
-template <int W>
-__global__ __launch_bounds__(BLOCK) void k_collect_terminals(Table<W> t, int k, u64 *tslots, unsigned long long *cursor,
+template <int W, class TT>
+__global__ __launch_bounds__(BLOCK) void k_collect_terminals(TT t, int k, u64 *tslots, unsigned long long *cursor,
                                                              unsigned long long *n_edges) {
     constexpr int PER = 16;
     __shared__ u32 lds4[BLOCK / 64];
@@ -209,7 +235,7 @@ __global__ __launch_bounds__(BLOCK) void k_collect_terminals(Table<W> t, int k, 
                 if ((aux & AUX_TERMINAL) && !(aux & AUX_SECONDARY)) {
                     selmask |= 1u << q;
                     // out(y) + out(rc y) = popc(out) + popc(in); a palindrome (y == rc y, even k) is ONE node
-                    const Kmer<W> y = slot_key(t.slots, i, t.tagged);
+                    const Kmer<W> y = slot_key(t, i);
                     edges += (y == revcomp(y, k)) ? __popc((aux >> 4) & 15u) : __popc(aux & 0xffu);
                 }
             }
@@ -227,8 +253,8 @@ __global__ __launch_bounds__(BLOCK) void k_collect_terminals(Table<W> t, int k, 
 // nodeMap (Graph.scala:343-347): node 2j = the stored terminal k-mer, node 2j+1 = its reverse
 // complement (termKmers = set ++ set.map(revComplement), :330-333); plus the (node, base) stubs of
 // buildEdges (:351): one edge per outgoing base, in A,G,C,T order.
-template <int W>
-__global__ __launch_bounds__(BLOCK) void k_make_nodes(Table<W> t, int k, const u64 *tslots, u64 nT, GraphView g,
+template <int W, class TT>
+__global__ __launch_bounds__(BLOCK) void k_make_nodes(TT t, int k, const u64 *tslots, u64 nT, GraphView g,
                                                       unsigned long long *ecursor) {
     __shared__ u32 lds4[BLOCK / 64];
     __shared__ unsigned long long s_base;
@@ -241,7 +267,7 @@ __global__ __launch_bounds__(BLOCK) void k_make_nodes(Table<W> t, int k, const u
         if (j < nT) {
             const u64 slot = tslots[j];
             const u32 aux = t.slots[slot].aux;
-            y = slot_key(t.slots, slot, t.tagged);
+            y = slot_key(t, slot);
             rc = revcomp(y, k);
             pal = (y == rc);
             m0 = (aux >> 4) & 15u;                  // outcoming(y)
@@ -282,8 +308,8 @@ __global__ __launch_bounds__(BLOCK) void k_make_nodes(Table<W> t, int k, const u
 //         them on a bushy error graph: 7 bases on average at C3) writes its sequence straight away.
 // pass 1: only for edges longer than WALK_BUF: walk again and emit the bases 2 bits each at e_off (assigned in pass 0).
 static constexpr u32 WALK_BUF = 128;          // bases kept in four 64-bit registers
-template <int W>
-__global__ __launch_bounds__(BLOCK) void k_walk(Table<W> t, int k, GraphView g, int pass, u64 max_steps,
+template <int W, class TT>
+__global__ __launch_bounds__(BLOCK) void k_walk(TT t, int k, GraphView g, int pass, u64 max_steps,
                                                 unsigned long long *pool_cursor, unsigned long long *n_long, u32 *err) {
     __shared__ u32 lds4[BLOCK / 64];
     __shared__ unsigned long long s_base;
@@ -359,8 +385,8 @@ __global__ __launch_bounds__(BLOCK) void k_walk(Table<W> t, int k, GraphView g, 
 // its idle lanes by ballot.  Nothing else in the loop is shared: the first WALK_BUF bases of an edge go to a 32-byte staging
 // slot per edge, and k_place_edges afterwards assigns the pool offsets (one atomic per 2048 edges) and copies the staged
 // bases.  Edges longer than WALK_BUF are emitted by k_walk's pass 1 as before.
-template <int W>
-__global__ __launch_bounds__(BLOCK) void k_walk_q(Table<W> t, int k, GraphView g, u64 max_steps,
+template <int W, class TT>
+__global__ __launch_bounds__(BLOCK) void k_walk_q(TT t, int k, GraphView g, u64 max_steps,
                                                   unsigned long long *queue, ulonglong2 *stage, unsigned long long *n_long, u32 *err) {
     constexpr u64 CHUNK = 1024;
     const int lane = threadIdx.x & 63;
@@ -511,8 +537,8 @@ __device__ __forceinline__ u64 rank_of(const RankBlk *rb, u64 slot) {
     const RankBlk b = rb[slot >> 6];
     return b.base + (u64)__popcll(b.mask & ((1ull << (slot & 63)) - 1ull));
 }
-template <int W>
-__global__ __launch_bounds__(BLOCK) void k_rank_masks(Table<W> t, RankBlk *rb, u64 nblk, u32 *chunk_tot, u64 nchunks) {
+template <int W, class TT>
+__global__ __launch_bounds__(BLOCK) void k_rank_masks(TT t, RankBlk *rb, u64 nblk, u32 *chunk_tot, u64 nchunks) {
     __shared__ u32 s_tot;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u64 ncap = t.capacity();
@@ -581,14 +607,14 @@ __device__ __forceinline__ bool pj_absorbed(u64 s) { return (s & PJ_ABS) && s !=
 __device__ __forceinline__ u32 pj_node(u64 s) { return (u32)s; }
 __device__ __forceinline__ int pj_first(u64 s) { return (int)((s >> 32) & 3u); }
 
-template <int W>
-__global__ __launch_bounds__(BLOCK) void k_pj_init(Table<W> t, int k, const RankBlk *__restrict__ rb, u64 *st) {
+template <int W, class TT>
+__global__ __launch_bounds__(BLOCK) void k_pj_init(TT t, int k, const RankBlk *__restrict__ rb, u64 *st) {
     const u64 ncap = t.capacity();
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < ncap; i += (u64)gridDim.x * BLOCK) {
         if (!slot_live(&t.slots[i])) continue;
         const u32 aux = t.slots[i].aux;
         if (aux & (AUX_NODE | AUX_TERMINAL | AUX_SECONDARY)) continue;
-        const Kmer<W> y = slot_key(t.slots, i, t.tagged);
+        const Kmer<W> y = slot_key(t, i);
         const u64 r = rank_of(rb, i);
         for (int ori = 0; ori < 2; ori++) {
             const int nb = single_out_base(aux, ori);
@@ -618,8 +644,8 @@ __global__ __launch_bounds__(BLOCK) void k_pj_round(u64 *st, u64 n, u32 *changed
     if (ch) changed[0] = 1;
 }
 
-template <int W>
-__global__ __launch_bounds__(BLOCK) void k_pj_edges(Table<W> t, int k, GraphView g, const RankBlk *__restrict__ rb, const u64 *__restrict__ st, u32 *err) {
+template <int W, class TT>
+__global__ __launch_bounds__(BLOCK) void k_pj_edges(TT t, int k, GraphView g, const RankBlk *__restrict__ rb, const u64 *__restrict__ st, u32 *err) {
     for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < g.n_edges; e += (u64)gridDim.x * BLOCK) {
         const u32 n = g.e_start[e];
         const Kmer<W> u0 = append_base(node_kmer<W>(g, n), g.e_first[e], k);
@@ -653,8 +679,8 @@ __device__ __forceinline__ void pool_or(uint8_t *pool, u64 off, u64 pos, int bas
 }
 
 // every interior oriented k-mer u places the base that follows it (see the derivation above): a scan over the table's slots
-template <int W>
-__global__ __launch_bounds__(BLOCK) void k_pj_emit(Table<W> t, int k, GraphView g, const RankBlk *__restrict__ rb, const u64 *__restrict__ st, u32 *err) {
+template <int W, class TT>
+__global__ __launch_bounds__(BLOCK) void k_pj_emit(TT t, int k, GraphView g, const RankBlk *__restrict__ rb, const u64 *__restrict__ st, u32 *err) {
     const u64 tid = (u64)blockIdx.x * BLOCK + threadIdx.x, stride = (u64)gridDim.x * BLOCK;
     for (u64 e = tid; e < g.n_edges; e += stride) pool_or(g.pool, g.e_off[e], 0, g.e_first[e]);       // builder += base  :352
     const u64 ncap = t.capacity();
@@ -1472,12 +1498,11 @@ int graph_build_index(gk_graph *g) {
     return GK_OK;
 }
 
-template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
+// TT: the table the graph phase reads — the map's own hashed table, or the minimizer-bucketed copy built from it (graph_build_entry)
+template <int W, class TT> static int graph_build_impl(gk_map *m, gk_graph *g, TT t) {
     gk_ctx *ctx = m->ctx;
-    // (m->dirty: keys were inserted verbatim and at least one was not its k-mer's hash-rule orientation — the reference's
-    //  `contains` probes both strands unconditionally, Graph.scala:270; so does every lookup below then)
-    Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u, m->dirty ? 1u : 0u};
     const int k = m->k;
+    const u64 tcap = t.capacity();
     unsigned long long *d_cnt = nullptr;     // [0] terminals [1] cursor [2] edges [3] ecursor [4] pool cursor
     u32 *d_err = nullptr;
     u64 *tslots = nullptr;
@@ -1502,7 +1527,7 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
         t_prev = now;
     };
     // 1. degree classification of every live key
-    hipLaunchKernelGGL(k_classify<W>, dim3(ggrid(ctx, m->capacity)), dim3(BLOCK), 0, ctx->stream, t, k, &d_cnt[0]);
+    hipLaunchKernelGGL((k_classify<W, TT>), dim3(ggrid(ctx, tcap)), dim3(BLOCK), 0, ctx->stream, t, k, &d_cnt[0]);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1513,7 +1538,7 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
     // 2. terminal slots -> nodes (both strands) and edge stubs
     e = hipMalloc((void **)&tslots, std::max<u64>(nT, 1) * 8);
     if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: alloc nodes"));
-    hipLaunchKernelGGL(k_collect_terminals<W>, dim3(ggrid(ctx, m->capacity / 16 + 1)), dim3(BLOCK), 0, ctx->stream, t, k, tslots, &d_cnt[1], &d_cnt[2]);
+    hipLaunchKernelGGL((k_collect_terminals<W, TT>), dim3(ggrid(ctx, tcap / 16 + 1)), dim3(BLOCK), 0, ctx->stream, t, k, tslots, &d_cnt[1], &d_cnt[2]);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 24, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1525,7 +1550,7 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
     if ((rc = graph_alloc_edges(g, nE)) != GK_OK) return done(rc);
     g->v.k = k;
     if (nT) {
-        hipLaunchKernelGGL(k_make_nodes<W>, dim3(ggrid(ctx, nT)), dim3(BLOCK), 0, ctx->stream, t, k, tslots, nT, g->v, &d_cnt[3]);
+        hipLaunchKernelGGL((k_make_nodes<W, TT>), dim3(ggrid(ctx, nT)), dim3(BLOCK), 0, ctx->stream, t, k, tslots, nT, g->v, &d_cnt[3]);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 32, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1549,7 +1574,7 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
         };
         if (use_pj) {
             // what is alive here besides the table: 16 B per live key (st) + 0.25 B per slot (rb) — DESIGN.md section 6
-            const u64 nstates = 2 * m->size, nblk = (m->capacity + 63) / 64, nchunks = (nblk + RANK_CHUNK - 1) / RANK_CHUNK;
+            const u64 nstates = 2 * m->size, nblk = (tcap + 63) / 64, nchunks = (nblk + RANK_CHUNK - 1) / RANK_CHUNK;
             if (nstates >= PJ_MAX_STATES) return done(fail(ctx, GK_E_CAPACITY, "more than 2^33 k-mers: beyond the pointer-jumping state's index"));
             e = hipMalloc((void **)&rb, nblk * sizeof(RankBlk));
             if (e == hipSuccess) e = hipMalloc((void **)&chunk_tot, nchunks * 4);
@@ -1557,7 +1582,7 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
             if (e == hipSuccess) e = hipMalloc((void **)&st, std::max<u64>(nstates, 1) * 8);
             if (e == hipSuccess) e = hipMemsetAsync(st, 0xff, std::max<u64>(nstates, 1) * 8, ctx->stream);         // PJ_UNREG
             if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: pointer-jumping arrays")); }
-            hipLaunchKernelGGL(k_rank_masks<W>, dim3((int)std::min<u64>(nchunks, (u64)ctx->cu_count * 8)), dim3(BLOCK), 0, ctx->stream, t, rb, nblk, chunk_tot, nchunks);
+            hipLaunchKernelGGL((k_rank_masks<W, TT>), dim3((int)std::min<u64>(nchunks, (u64)ctx->cu_count * 8)), dim3(BLOCK), 0, ctx->stream, t, rb, nblk, chunk_tot, nchunks);
             hipLaunchKernelGGL(k_rank_scan, dim3(1), dim3(1024), 0, ctx->stream, chunk_tot, chunk_base, nchunks);
             hipLaunchKernelGGL(k_rank_fill, dim3((int)std::min<u64>(nchunks, (u64)ctx->cu_count * 8)), dim3(RANK_CHUNK), 0, ctx->stream, rb, nblk, chunk_base, nchunks);
             unsigned long long ranked = 0;
@@ -1566,7 +1591,7 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: slot ranks")); }
             if (ranked != m->size) { pj_free(); return done(fail(ctx, GK_E_STATE, "live slots (" + std::to_string(ranked) + ") differ from the map's size (" + std::to_string(m->size) + ")")); }
-            hipLaunchKernelGGL(k_pj_init<W>, dim3(ggrid(ctx, m->capacity)), dim3(BLOCK), 0, ctx->stream, t, k, rb, st);
+            hipLaunchKernelGGL((k_pj_init<W, TT>), dim3(ggrid(ctx, tcap)), dim3(BLOCK), 0, ctx->stream, t, k, rb, st);
             e = hipGetLastError();
             // a chain of n k-mers is resolved after ceil(log2 n) rounds; what still moves then is an all-(1,1) cycle (Graph.scala:375)
             int max_rounds = 2;
@@ -1582,7 +1607,7 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
                 if (!flags[0]) break;
             }
             if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: pj rounds")); }
-            hipLaunchKernelGGL(k_pj_edges<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, rb, st, d_err);
+            hipLaunchKernelGGL((k_pj_edges<W, TT>), dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, rb, st, d_err);
         } else {
             // every oriented interior k-mer lies on exactly one edge: sum of lengths <= edges + 2 x live keys, and every edge
             // rounds up to a byte — the pool can be allocated before the walk, so the walk can write as it goes
@@ -1590,12 +1615,12 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
             e = hipMalloc((void **)&g->v.pool, g->pool_cap);
             if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: pool")); }
             if (ctx->hook_walk_queue == 0)        // ("graph_walk_queue": 0 = one edge per lane, the round-1 form; A/B)
-                hipLaunchKernelGGL(k_walk<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, 0, m->capacity + 1, &d_cnt[4], &d_cnt[6], d_err);
+                hipLaunchKernelGGL((k_walk<W, TT>), dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, 0, tcap + 1, &d_cnt[4], &d_cnt[6], d_err);
             else {
                 e = hipMalloc((void **)&stage, std::max<u64>(nE, 1) * 32);
                 if (e != hipSuccess) { pj_free(); return done(hip_fail(ctx, e, "gk_graph_build: edge staging")); }
                 const int gq = (int)std::min<u64>((nE + 4 * BLOCK - 1) / (4 * BLOCK), (u64)ctx->cu_count * 8);
-                hipLaunchKernelGGL(k_walk_q<W>, dim3(std::max(gq, 1)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, m->capacity + 1, &d_cnt[7], stage, &d_cnt[6], d_err);
+                hipLaunchKernelGGL((k_walk_q<W, TT>), dim3(std::max(gq, 1)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, tcap + 1, &d_cnt[7], stage, &d_cnt[6], d_err);
                 hipLaunchKernelGGL(k_place_edges, dim3(ggrid(ctx, nE / 8 + 1)), dim3(BLOCK), 0, ctx->stream, g->v, stage, &d_cnt[4]);
             }
         }
@@ -1626,12 +1651,12 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
         if (use_pj) {
             e = hipMemsetAsync(g->v.pool, 0, g->pool_cap, ctx->stream);
             if (e == hipSuccess) {
-                hipLaunchKernelGGL(k_pj_emit<W>, dim3(ggrid(ctx, std::max<u64>(m->capacity, nE))), dim3(BLOCK), 0, ctx->stream, t, k, g->v, rb, st, d_err);
+                hipLaunchKernelGGL((k_pj_emit<W, TT>), dim3(ggrid(ctx, std::max<u64>(tcap, nE))), dim3(BLOCK), 0, ctx->stream, t, k, g->v, rb, st, d_err);
                 e = hipGetLastError();
             }
             if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream);
         } else if (h_cnt[6]) {       // edges longer than the walk's register buffer: second walk, emitting
-            hipLaunchKernelGGL(k_walk<W>, dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, 1, m->capacity + 1, &d_cnt[4], &d_cnt[6], d_err);
+            hipLaunchKernelGGL((k_walk<W, TT>), dim3(ggrid(ctx, nE)), dim3(BLOCK), 0, ctx->stream, t, k, g->v, 1, tcap + 1, &d_cnt[4], &d_cnt[6], d_err);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1649,6 +1674,103 @@ template <int W> static int graph_build_impl(gk_map *m, gk_graph *g) {
     g->walked_bases = g->live_len;
     lap(5);
     return done(rc);
+}
+
+template <int W> __global__ __launch_bounds__(BLOCK) void k_mb_clear(Slot<W> *slots, u64 n) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        if constexpr (W == 1) slots[i] = Slot<1>{KEY_EMPTY, 0u, 0u};
+        else slots[i] = Slot<2>{KEY_EMPTY, KEY_EMPTY, 0u, 0u};
+    }
+}
+
+// ---- the minimizer-bucketed copy (MbTable, gk_device.h) ------------------------------------------------------------------------
+template <int W> __global__ __launch_bounds__(BLOCK) void k_mb_count(Table<W> src, int k, u32 nb, u32 *cnt, u32 *bucket_of) {
+    const u64 ncap = src.capacity();
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < ncap; i += (u64)gridDim.x * BLOCK) {
+        if (!slot_live(&src.slots[i])) continue;
+        const u32 b = (u32)owner_of(slot_key(src, i), k, (int)nb);
+        bucket_of[i] = b;
+        atomicAdd(&cnt[b], 1u);
+    }
+}
+// keys in a bucket -> slots of its region: the power of two that keeps the load at or under 0.5, 8 at least
+__global__ __launch_bounds__(BLOCK) void k_mb_sizes(u32 *cnt, u32 nb) {
+    for (u64 b = (u64)blockIdx.x * BLOCK + threadIdx.x; b < nb; b += (u64)gridDim.x * BLOCK) {
+        u32 want = max(8u, 2u * cnt[b]), p = 8u;
+        while (p < want) p <<= 1;
+        cnt[b] = p;
+    }
+}
+template <int W> __global__ __launch_bounds__(BLOCK) void k_mb_fill(Table<W> src, const u32 *bucket_of, MbTable<W> dst, u32 *err) {
+    const u64 ncap = src.capacity();
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < ncap; i += (u64)gridDim.x * BLOCK) {
+        if (!slot_live(&src.slots[i])) continue;
+        const Kmer<W> key = slot_key(src, i);
+        const Stored<W> kk = to_stored(key);
+        const ProbeAt<W> p = probe_at_bucket(dst, key, bucket_of[i]);
+        Slot<W> *reg = const_cast<Slot<W> *>(p.reg);
+        u32 at = p.pos;
+        bool placed = false;
+        for (u32 n = 0; n <= p.mask && !placed; n++, at = (at + 1) & p.mask) {
+            // (every key of the source is unique: a slot is taken by claiming its first word; with 16-byte keys a slot whose first
+            //  word equals ours belongs to ANOTHER key that shares it — see seg_claim_unique)
+            const u64 c0 = cas64(&reg[at].w0, KEY_EMPTY, kk.w0);
+            if constexpr (W == 1) { if (c0 == KEY_EMPTY) placed = true; }
+            else { if ((c0 == KEY_EMPTY || c0 == kk.w0) && cas64(&reg[at].w1, KEY_EMPTY, kk.w1) == KEY_EMPTY) placed = true; }
+            if (placed) reg[at].extra = src.slots[i].extra;
+        }
+        if (!placed) *err = 1u;
+    }
+}
+
+template <int W> static int graph_build_entry(gk_map *m, gk_graph *g) {
+    gk_ctx *ctx = m->ctx;
+    // (m->dirty: keys were inserted verbatim and at least one was not its k-mer's hash-rule orientation — the reference's
+    //  `contains` probes both strands unconditionally, Graph.scala:270; so does every lookup below then)
+    Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u, m->dirty ? 1u : 0u};
+    // "graph_mbt" = 1: classify and walk on a minimizer-bucketed COPY of the table (A/B, profiles/r03); never for k = 64 (tagged slots)
+    const bool use_mb = ctx->hook_graph_mbt > 0 && m->k != 64 && m->size >= 4096;
+    if (!use_mb) return graph_build_impl<W, Table<W>>(m, g, t);
+    const auto t0 = std::chrono::steady_clock::now();
+    const u32 nb = (u32)std::min<u64>(std::max<u64>(m->size / (u64)std::max(ctx->hook_graph_mbt_keys, 16), 1), 1u << 30);
+    u32 *d_cnt = nullptr, *d_bucket = nullptr, *d_err = nullptr;
+    unsigned long long *d_off = nullptr, total = 0;
+    u64 *d_sums = nullptr;
+    Slot<W> *slots = nullptr;
+    auto done = [&](int code) {
+        for (void *p : {(void *)d_cnt, (void *)d_bucket, (void *)d_err, (void *)d_off, (void *)d_sums, (void *)slots}) if (p) (void)hipFree(p);
+        return code;
+    };
+    hipError_t e = hipMalloc((void **)&d_cnt, (u64)nb * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_bucket, m->capacity * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_off, ((u64)nb + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_sums, ((u64)nb / SCAN_CHUNK + 2) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_err, 4);
+    if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, (u64)nb * 4, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_err, 0, 4, ctx->stream);
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: bucketed table"));
+    hipLaunchKernelGGL(k_mb_count<W>, dim3(ggrid(ctx, m->capacity)), dim3(BLOCK), 0, ctx->stream, t, m->k, nb, d_cnt, d_bucket);
+    hipLaunchKernelGGL(k_mb_sizes, dim3(ggrid(ctx, nb)), dim3(BLOCK), 0, ctx->stream, d_cnt, nb);
+    e = scan_counts(ctx, d_cnt, nb, d_off, d_sums);
+    if (e == hipSuccess) e = hipMemcpyAsync(&total, d_off + nb, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: bucket regions"));
+    e = hipMalloc((void **)&slots, total * sizeof(Slot<W>));
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: bucketed table"));
+    hipLaunchKernelGGL(k_mb_clear<W>, dim3(ggrid(ctx, total / 4 + 1)), dim3(BLOCK), 0, ctx->stream, slots, (u64)total);
+    MbTable<W> mt{slots, reinterpret_cast<const u64 *>(d_off), nb, m->dirty ? 1u : 0u, (u64)total};
+    hipLaunchKernelGGL(k_mb_fill<W>, dim3(ggrid(ctx, m->capacity)), dim3(BLOCK), 0, ctx->stream, t, d_bucket, mt, d_err);
+    u32 h_err = 0;
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: filling the bucketed table"));
+    if (h_err) return done(fail(ctx, GK_E_STATE, "gk_graph_build: a bucket region filled up (internal sizing error)"));
+    (void)hipFree(d_bucket); d_bucket = nullptr;
+    (void)hipFree(d_cnt); d_cnt = nullptr;
+    g->mbt_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    g->mbt_slots = total;
+    return done(graph_build_impl<W, MbTable<W>>(m, g, mt));
 }
 
 int check_graph(const gk_graph *g) {
@@ -1670,7 +1792,7 @@ int gk_graph_build(gk_map *m, gk_graph **out) {
     g->ctx = m->ctx;
     g->k = m->k;
     g->W = m->W;
-    int rc = m->W == 1 ? graph_build_impl<1>(m, g) : graph_build_impl<2>(m, g);
+    int rc = m->W == 1 ? graph_build_entry<1>(m, g) : graph_build_entry<2>(m, g);
     if (rc != GK_OK) {
         graph_free_arrays(g);
         delete g;
@@ -1950,6 +2072,13 @@ int gk_graph_build_stats(gk_graph *g, float *phase_ms6, uint64_t *walked_bases, 
     if (phase_ms6) for (int i = 0; i < 6; i++) phase_ms6[i] = g->build_ms[i];
     if (walked_bases) *walked_bases = g->walked_bases;
     if (pointer_jumping) *pointer_jumping = g->used_pj;
+    return GK_OK;
+}
+
+int gk_graph_bucketed_table_stats(gk_graph *g, float *build_ms, uint64_t *slots) {
+    if (int rc = check_graph(g)) return rc;
+    if (build_ms) *build_ms = g->mbt_ms;
+    if (slots) *slots = g->mbt_slots;
     return GK_OK;
 }
 

@@ -45,6 +45,8 @@ struct gk_ctx {
     int hook_host_prefetch = -1;     // host-fed count: 0 = do not upload the next chunk beside the current chunk's P3 / P4 / P5 (A/B)
     int hook_pairs_host = -1;        // paired-end walks: 1 = all of them on host threads over a snapshot (the round-2 form), else one wave per pair orientation
     int hook_pairs_small_sets = -1;  // test hook: the device walks get tiny LDS sets, so that most orientations overflow to the host walker
+    int hook_graph_mbt = -1;         // gk_graph_build: 1 = classify and walk on a minimizer-bucketed copy of the table (A/B)
+    int hook_graph_mbt_keys = 256;   // ... keys per bucket on average
     int hook_walk_queue = -1;        // unitig walk: 0 = one edge per lane (k_walk pass 0), else lanes fed from a queue (k_walk_q)
     int hook_p4_grid = -1;           // over-provisioned fine level: P4 workgroups per CU (-1: 4, or 2 of the 1024-thread form)
     int hook_p4_wide = -1;           // exact fine level, 8-byte keys: -1 auto (by nb2), 0 sort 4096 keys at a time, 1 sort 8192 (1024 threads)
@@ -139,6 +141,7 @@ struct gk_map {
         const uint8_t *host = nullptr;   // what was PREFETCHED into this area and not consumed yet (valid): host address, bytes
         size_t bytes = 0;
         bool valid = false;
+        bool armed = false;              // chosen and sized, the copy not issued yet (map_fire_prefetch)
         hipEvent_t ev = nullptr;         // fires when the prefetched bytes have landed
     } stage[2];
     int stage_cur = 0;                   // the area the current (or last) chunk lives in
@@ -219,6 +222,7 @@ constexpr int PART_NOT_UNIFORM = 2;      // ReadSrc::verify_uniform failed: walk
 struct PartPlan { bool estimate = false; bool fine_exact = false; bool check_canon = false; double grow_ahead = 1.0; };
 int part_count(gk_map *m, PartScratch **pps, const ReadSrc &src, const uint64_t *d_keys, uint64_t nkeys_in, uint64_t nkeys_bound,
                bool from_empty, const PartPlan &plan);
+int map_fire_prefetch(gk_map *m, hipEvent_t after);   // issue the armed host -> staging uploads on the copy stream behind `after` (nullptr: at once)
 int map_ensure_sample(gk_map *m);                    // allocate the distinct-key sample set on first use
 // if the table cannot take `new_distinct` more keys, grow it (rehash, or plain re-allocation from empty) for `size_for` more
 int map_make_room(gk_map *m, uint64_t new_distinct, uint64_t size_for, bool from_empty, bool keep_lnb1 = false);

@@ -1493,6 +1493,8 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
     }
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipEventRecord(ctx->pev[2], ctx->stream));
+    // the NEXT chunk's (or the caller's next batch's) upload, armed before this batch began, starts when this L1 scatter ends
+    if (int rc = map_fire_prefetch(m, ctx->pev[2])) return rc;
 
     // ---- between the levels ----------------------------------------------------------------------------------
     // Did the spill list overflow (extreme skew)?  Then the batch has to take the direct path.  A table

@@ -654,6 +654,7 @@ int gk_ctx_create(int device, gk_ctx **out) {
     if (const char *u = getenv("GK_P45_STRIPES")) ctx->hook_p45_stripes = atoi(u);
     if (const char *u = getenv("GK_MIN_LNB1")) ctx->hook_min_lnb1 = std::max(0, std::min((int)gk::MAX_LNB1, atoi(u)));      // (tests: the whole suite over 512 / 1024 L1 buckets)
     if (const char *u = getenv("GK_GRAPH_UNITIGS")) ctx->hook_unitigs = !strcmp(u, "walk") ? 1 : !strcmp(u, "pj") ? 2 : 0;
+    if (const char *u = getenv("GK_GRAPH_MBT")) ctx->hook_graph_mbt = atoi(u);            // (tests: the whole graph suite over the bucketed table)
     *out = ctx;
     return GK_OK;
 }
@@ -733,6 +734,8 @@ int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value) {
     }
     else if (n == "p4_grid") ctx->hook_p4_grid = (int)value;
     else if (n == "graph_walk_queue") ctx->hook_walk_queue = (int)value;
+    else if (n == "graph_mbt") ctx->hook_graph_mbt = (int)value;
+    else if (n == "graph_mbt_keys") ctx->hook_graph_mbt_keys = (int)std::max<int64_t>(16, value);
     else if (n == "pairs_host") ctx->hook_pairs_host = (int)value;
     else if (n == "host_prefetch") ctx->hook_host_prefetch = (int)value;
     else if (n == "test_max_stage") ctx->hook_max_stage = (int64_t)std::max<int64_t>(0, value);
@@ -1251,24 +1254,43 @@ static int stage_reserve(gk_map *m, int slot, size_t bytes) {
     st.cap = bytes;
     return GK_OK;
 }
-// start the upload of host bytes [p, p + bytes) into a staging area that is not `in_use` (-1: none is) and remember what is on
-// its way; of two free areas the one that holds no unconsumed prefetch, else the older prefetch is overwritten
-static int stage_prefetch(gk_map *m, const uint8_t *p, size_t bytes, int in_use) {
+// ARM the upload of host bytes [p, p + bytes) into a staging area that is not `in_use` (-1: none is): the area is chosen and
+// sized, the copy itself is issued by map_fire_prefetch — from the insert pipeline right after its L1 scatter has been
+// launched, gated on that scatter's end, so that the copy runs beside the fine level (P3 / P4 / P5) and NOT beside the
+// scatter: P2 is latency-bound and a running host copy doubles its time (measured: 0.58 -> 1.18 ms at C2 with the next step's
+// 39 MB arriving meanwhile; profiles/r03).  Of two free areas the one that holds no unconsumed prefetch is taken.
+static int stage_prefetch_arm(gk_map *m, const uint8_t *p, size_t bytes, int in_use) {
     gk_ctx *ctx = m->ctx;
     int slot;
     if (in_use >= 0) slot = 1 - in_use;
     else if (m->stage[0].valid != m->stage[1].valid) slot = m->stage[0].valid ? 1 : 0;
     else slot = 1 - m->stage_last_pf;
     gk_map::StageSlot &st = m->stage[slot];
-    st.valid = false;
+    st.valid = false; st.armed = false;
     if (int rc = stage_reserve(m, slot, bytes + 64)) return rc;
     if (!st.ev) GK_HIP(ctx, hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
-    GK_HIP(ctx, hipMemcpyAsync(st.d, p, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
-    GK_HIP(ctx, hipEventRecord(st.ev, ctx->copy_stream));
-    st.host = p; st.bytes = bytes; st.valid = true;
+    st.host = p; st.bytes = bytes; st.armed = true;
     m->stage_last_pf = slot;
     return GK_OK;
 }
+}  // extern "C"
+namespace gk {
+// issue every armed upload on the copy stream, behind `after` (an event of the main stream; nullptr: at once)
+int map_fire_prefetch(gk_map *m, hipEvent_t after) {
+    gk_ctx *ctx = m->ctx;
+    for (int sl = 0; sl < 2; sl++) {
+        gk_map::StageSlot &st = m->stage[sl];
+        if (!st.armed) continue;
+        st.armed = false;
+        if (after) GK_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, after, 0));
+        GK_HIP(ctx, hipMemcpyAsync(st.d, st.host, st.bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+        GK_HIP(ctx, hipEventRecord(st.ev, ctx->copy_stream));
+        st.valid = true;
+    }
+    return GK_OK;
+}
+}
+extern "C" {
 
 int gk_map_prefetch_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nreads) {
     if (int rc = check_map_lazy(m)) return rc;
@@ -1280,7 +1302,7 @@ int gk_map_prefetch_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t
         // ragged stream's first chunk may end elsewhere, and the prefetch is then simply not used)
         const size_t rb = 1 + (size_t)(bin[0] + 3) / 4;
         const size_t want = std::min<size_t>(nbytes, std::max<size_t>(rb, max_stage(ctx) / rb * rb));
-        return stage_prefetch(m, bin, want, -1);
+        return stage_prefetch_arm(m, bin, want, -1);
     }
 }
 
@@ -1369,16 +1391,18 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
         for (int sl = 0; sl < 2 && !preloaded; sl++) {
             gk_map::StageSlot &st = m->stage[sl];
             if (st.valid && st.host == bin + cur.begin && st.bytes >= cur.bytes) { preloaded = true; m->stage_cur = sl; st.valid = false; }
+            else if (st.armed && st.host == bin + cur.begin) st.armed = false;      // armed for THIS chunk but never fired (nothing ran before it): the piece-wise upload below is the faster way
         }
         if (!preloaded) {
-            m->stage_cur = m->stage[0].valid && !m->stage[1].valid ? 1 : 0;       // (spare an unconsumed prefetch if one of the areas holds none)
-            m->stage[m->stage_cur].valid = false;
+            const bool busy0 = m->stage[0].valid || m->stage[0].armed, busy1 = m->stage[1].valid || m->stage[1].armed;
+            m->stage_cur = busy0 && !busy1 ? 1 : 0;       // (spare a pending prefetch if one of the areas holds none)
+            m->stage[m->stage_cur].valid = m->stage[m->stage_cur].armed = false;
             if (int rc = stage_reserve(m, m->stage_cur, cur.bytes + 64)) return rc;
         }
         // one chunk ahead: its upload runs on the copy stream beside this chunk's P3 / P4 / P5
         Chunk nxt = cut(cur.begin + cur.bytes, cur.r_begin + cur.reads, false, &err);
         if (err) return format_error(err, nxt);
-        if (nxt.valid && ctx->hook_host_prefetch != 0) { if (int rc = stage_prefetch(m, bin + nxt.begin, nxt.bytes, m->stage_cur)) return rc; }
+        if (nxt.valid && ctx->hook_host_prefetch != 0) { if (int rc = stage_prefetch_arm(m, bin + nxt.begin, nxt.bytes, m->stage_cur)) return rc; }
         if (m->offsets_bytes < cur.offs.size() * sizeof(u32)) {
             if (m->d_offsets) GK_HIP(ctx, hipFree(m->d_offsets));
             m->d_offsets = nullptr;
@@ -1405,14 +1429,15 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
             src.max_len = 255;             // the host has walked this framing: every length byte is what the offsets say
         }
         const int brc = insert_batch(m, src, nullptr, 0, cur.occ);
+        if (brc == GK_OK) { if (int rc = map_fire_prefetch(m, nullptr)) return rc; }      // (still armed: the path that ran had no L1 scatter to gate it on)
         if (brc == PART_NOT_UNIFORM) {       // take the chunk again, this time walking its framing
             GK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));     // (a prefetch of the chunk after it may be in flight: it is simply dropped)
-            m->stage[0].valid = m->stage[1].valid = false;
+            for (int sl = 0; sl < 2; sl++) m->stage[sl].valid = m->stage[sl].armed = false;
             cur = cut(cur.begin, cur.r_begin, true, &err);
             if (err) return format_error(err, cur);
             continue;
         }
-        if (brc) { (void)hipStreamSynchronize(ctx->copy_stream); m->stage[0].valid = m->stage[1].valid = false; return brc; }
+        if (brc) { (void)hipStreamSynchronize(ctx->copy_stream); for (int sl = 0; sl < 2; sl++) m->stage[sl].valid = m->stage[sl].armed = false; return brc; }
         cur = nxt;
     }
     uint64_t occ = 0;
@@ -1805,7 +1830,7 @@ int gk_map_trim(gk_map *m) {
     gk_ctx *ctx = m->ctx;
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     GK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
-    for (int i = 0; i < 2; i++) { m->stage[i].valid = false; if (m->stage[i].d) { (void)hipFree(m->stage[i].d); m->stage[i].d = nullptr; m->stage[i].cap = 0; } }
+    for (int i = 0; i < 2; i++) { m->stage[i].valid = m->stage[i].armed = false; if (m->stage[i].d) { (void)hipFree(m->stage[i].d); m->stage[i].d = nullptr; m->stage[i].cap = 0; } }
     if (m->d_offsets) { (void)hipFree(m->d_offsets); m->d_offsets = nullptr; m->offsets_bytes = 0; }
     if (m->d_scratch) { (void)hipFree(m->d_scratch); m->d_scratch = nullptr; m->scratch_bytes = 0; }
     part_scratch_free(ctx, m->part);

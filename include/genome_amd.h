@@ -331,6 +331,9 @@ int gk_graph_checksum(gk_graph *g, uint64_t *nodes_checksum, uint64_t *edges_che
  * unitig measurement (k_walk pass 0 or pointer jumping), pool reservation, unitig emission, node index + counts} (wall ms,
  * every phase ends in a stream sync); *walked_bases = bases emitted; *pointer_jumping = 1 if k_pj_* built the unitigs. */
 int gk_graph_build_stats(gk_graph *g, float *phase_ms6, uint64_t *walked_bases, int *pointer_jumping);
+/* When gk_graph_build ran on a minimizer-bucketed copy of the table (gk_ctx_set_option "graph_mbt" = 1): wall ms of building the
+ * copy and its slots; 0 / 0 otherwise.  Diagnostics of an A/B switch. */
+int gk_graph_bucketed_table_stats(gk_graph *g, float *build_ms, uint64_t *slots);
 /* Graph.getGraphMap (Graph.scala:90-119): putNew of every node's k-mer -> NodeGraphPosition(node id) and of the k-mers at
  * distance 1 .. len-1 along every edge -> EdgeGraphPosition(edge id, dist) into `vm` (same k, same context).  *entries =
  * number of entries added = sum of edge lengths + nodes - edges (the reference prints both side by side, :117; here the
