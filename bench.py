@@ -316,6 +316,8 @@ def main():
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running with {world} ranks", file=sys.stderr)
     sharded = world > 1 or args.sharded
+    if args.opt:        # A/B switches exist in the TEST build of the library only (the product library has no option switch)
+        os.environ.setdefault("GK_LIB_PATH", os.path.join(ROOT, "genome_amd", "libgenome_amd_test.so"))
 
     from genome_amd import synth
     from genome_amd.dnamap import Context, HipDNAMap

@@ -15,8 +15,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# GK_LIB_PATH: load another build of the SAME library (a -DGK_TIMERS or tuning variant under genome_amd/variants/) without
-# overwriting the product .so; there is still no fallback if the file is missing.
+# GK_LIB_PATH: load another build of the SAME library — the TEST build (libgenome_amd_test.so: the product's objects plus the test
+# hooks; tests/conftest.py selects it), a -DGK_TIMERS or tuning variant under genome_amd/variants/ — without overwriting the
+# product .so; there is still no fallback if the file is missing.
 LIB_PATH = os.environ.get("GK_LIB_PATH") or os.path.join(_HERE, "libgenome_amd.so")
 
 GK_OK = 0
@@ -57,7 +58,6 @@ SIGNATURES = {
     "gk_ctx_mem_stats": (C.c_int, [vp, u64p, u64p, u64p, C.c_int]),
     "gk_ctx_set_mem_budget": (C.c_int, [vp, C.c_uint64]),
     "gk_map_add_map": (C.c_int, [vp, vp]),
-    "gk_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
     "gk_map_verify": (C.c_int, [vp, u64p, u64p, u64p, u64p]),
     "gk_map_set_max_batch_keys": (C.c_int, [vp, C.c_uint64]),
     "gk_map_trim": (C.c_int, [vp]),
@@ -98,7 +98,6 @@ SIGNATURES = {
     "gk_map_count_superkmers_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, u64p]),
     "gk_dist_unique_id": (C.c_int, [vp]),
     "gk_dist_create": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]),
-    "gk_dist_create_loopback": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]),
     "gk_dist_destroy": (None, [vp]),
     "gk_dist_rank": (C.c_int, [vp]),
     "gk_dist_world": (C.c_int, [vp]),
@@ -160,6 +159,14 @@ SIGNATURES = {
 }
 
 
+# what only the TEST build of the library exports (include/genome_amd_test.h; genome_amd/libgenome_amd_test.so)
+TEST_SIGNATURES = {
+    "gk_ctx_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
+    "gk_dist_create_loopback": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]),
+}
+TEST_LIB_PATH = os.path.join(_HERE, "libgenome_amd_test.so")
+
+
 def lib():
     """Load the HIP library; raises (never falls back) when it is missing."""
     global _lib
@@ -172,8 +179,22 @@ def lib():
             f = getattr(L, name)
             f.restype = res
             f.argtypes = args
+        for name, (res, args) in TEST_SIGNATURES.items():     # present in the test build only
+            f = getattr(L, name, None)
+            if f is not None:
+                f.restype = res
+                f.argtypes = args
         _lib = L
     return _lib
+
+
+def test_hook(name: str):
+    """an entry point of the test build; a clear error when the product library is the one that is loaded"""
+    f = getattr(lib(), name, None)
+    if f is None:
+        raise GkError(GK_E_STATE, f"{name} is a test hook: it is not in {os.path.basename(LIB_PATH)} — load the test build "
+                                  f"(GK_LIB_PATH={TEST_LIB_PATH})")
+    return f
 
 
 def device_count() -> int:

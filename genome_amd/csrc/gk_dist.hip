@@ -32,7 +32,7 @@
 #include <thread>
 #include <vector>
 
-#include "gk_internal.h"
+#include "gk_dist.h"
 #include "gk_tile.h"
 
 using namespace gk;
@@ -90,88 +90,6 @@ Rccl *rccl() {
 }
 }  // namespace
 
-// ---- loopback transport (tests): the ranks of one "node" are threads of ONE process on ONE device --------------------------
-// RCCL refuses two ranks on one GPU, and only one GPU is reachable from the build box: gk_dist_create_loopback gives every
-// rank a handle whose sends, receives and reductions go through this hub instead — device-to-device copies between the
-// ranks' buffers, matched pairwise in posting order like RCCL's — so that the exchange logic of gk_dist_* (sizes, regions,
-// buffer rotation, the order of operations across ranks) runs with world > 1 before it ever meets a real communicator.  It is
-// STRICTER than RCCL in two ways that make it a better test: a group's end blocks until every peer has posted the matching
-// operation (an inconsistent order of operations across ranks deadlocks here at once), and a send whose size differs from
-// the matching receive is an error.
-namespace {
-struct LoopHub {
-    std::mutex mu;
-    std::condition_variable cv;
-    int world = 0, refs = 0;
-    struct Op { void *ptr; size_t bytes; hipStream_t stream; hipEvent_t ready; bool *done; int *err; };
-    std::deque<Op> sends[64][64], recvs[64][64];          // [src][dst], in posting order
-    // reductions / gathers: one at a time, every rank contributes
-    unsigned long long gen = 0;
-    int arrived = 0;
-    double contrib[64][32];
-    double result[64 * 32];
-    std::vector<hipEvent_t> events;                       // every event the transport made; destroyed with the hub
-    ~LoopHub() { for (hipEvent_t e : events) if (e) (void)hipEventDestroy(e); }
-};
-std::mutex g_hubs_mu;
-std::map<std::string, std::shared_ptr<LoopHub>> g_hubs;
-}  // namespace
-
-struct gk_dist {
-    gk_ctx *ctx = nullptr;
-    int rank = 0, world = 1;
-    ncclComm_t comm = nullptr;
-    std::shared_ptr<LoopHub> loop;                   // the loopback transport (tests) instead of RCCL
-    std::string loop_key;
-    struct Posted { bool send; void *ptr; size_t bytes; int peer; hipStream_t stream; };
-    std::vector<Posted> group;                       // loopback: the operations of the group being built
-    // Every RCCL call of this handle goes to ONE stream of its own (operations on a communicator must not run concurrently):
-    // the exchange of batch i+1 can then be in flight while the owner pipeline of batch i runs on the context's stream.
-    hipStream_t comm_stream = nullptr;
-    // exchange scratch, kept between calls.  THREE send buffers (a route being written on the second stream, one whose
-    // records are on the wire, one being counted) and TWO receive buffers (on the wire / being counted).
-    static constexpr int NROUTE = 3;
-    uint8_t *d_sendbuf[NROUTE] = {nullptr, nullptr, nullptr}, *d_recv[2] = {nullptr, nullptr};
-    u64 send_cap[NROUTE] = {0, 0, 0}, recv_records[2] = {0, 0};      // capacities in record slots (send: world regions of send_cap / world)
-    int slot = 0;                                    // record slot bytes the buffers were sized for
-    // routes that were begun and not yet counted: at most three, first in, first out
-    struct Route {
-        int k = 0, read_len = 0; const void *records = nullptr; u64 nreads = 0;
-        // settled (owner thread): the routing kernel has finished, a region that was too small has been routed again, and
-        // this rank's verdict on its own half of the exchange is in local_rc — what it will tell its peers
-        bool settled = false;
-        int local_rc = 0;
-        std::string local_err;
-        uint64_t recs[64] = {}, kmers[64] = {};       // per owner
-        bool exchanged = false;                      // counts known, records on the wire (or arrived) in d_recv[rbuf]
-        int rbuf = 0;
-        u64 nrec_in = 0, nkm_in = 0, sent = 0;
-        int error = 0;                               // the batch was dropped (by agreement of all ranks, or by the transport): reported when its turn comes
-        std::string error_text;
-    };
-    Route route[NROUTE];
-    int head = 0, npending = 0;                      // route[head] is the oldest; the next route goes to (head + npending) % NROUTE
-    u64 nexchanged = 0;                              // exchanges posted so far: the next one receives into d_recv[nexchanged & 1]
-    unsigned long long *d_route_cnt = nullptr;       // [NROUTE][SKM_COUNT_WORDS] counters of the routing kernels on the second stream
-    unsigned long long *h_route_cnt = nullptr;       // pinned copy
-    hipEvent_t route_done[NROUTE] = {nullptr, nullptr, nullptr};   // recorded behind each route's counter copy
-    hipEvent_t exch_done[NROUTE] = {nullptr, nullptr, nullptr};    // recorded behind each batch's receives
-    hipEvent_t join = nullptr;                       // main stream -> communication stream
-    unsigned long long *d_cnt = nullptr;             // [8 x 64]: (records, k-mers, status) per peer to send [0, 3 x 64), as received [3 x 64, 6 x 64), scalars behind
-    unsigned long long *h_cnt = nullptr;             // pinned mirror
-    float last_ms[4] = {0, 0, 0, 0};                 // route, exchange, owner count, total (wall)
-    float last_helper_ms = 0;                        // host time of the exchange that ran beside the last owner count
-    // ONE helper thread per handle, started on first use: it runs the exchange of the next batch beside the owner count
-    // (a std::thread per step was 30-50 us of clone + join each).  It never touches the context's error string, its
-    // streams or its block pool's frees: errors come back in the route, replaced buffers go to `garbage` for the owner thread.
-    std::thread worker;
-    std::mutex wmu;
-    std::condition_variable wcv;
-    std::function<void()> job;
-    bool job_pending = false, job_running = false, quit = false;
-    std::vector<void *> garbage;
-};
-
 static void helper_main(gk_dist *d) {
     (void)hipSetDevice(d->ctx->device);
     std::unique_lock<std::mutex> lk(d->wmu);
@@ -215,8 +133,9 @@ static void drain_garbage(gk_dist *d) {
     for (void *p : g) (void)hipFree(p);
 }
 
+static thread_local const gk_dist *tl_dist = nullptr;       // whose transport explains an error code (set by dist_check)
 static std::string comm_error_text(int code) {
-    if (code == 3) return "transport error (loopback: a send and its receive differ in size, or a HIP call failed)";
+    if (tl_dist && tl_dist->xport) return tl_dist->xport->error_text(code);
     Rccl *r = rccl();
     return r->GetErrorString ? r->GetErrorString(code) : "RCCL error";
 }
@@ -227,121 +146,28 @@ static std::string comm_error_text(int code) {
             return gk::fail((ctx), GK_E_COMM, std::string(#call) + ": " + comm_error_text(r__)); \
     } while (0)
 
-// ---- transport: RCCL, or the loopback hub -----------------------------------------------------------------------------------
-static size_t dtype_bytes(int dt) { return dt == ncclUint64 || dt == ncclFloat64 ? 8 : 1; }
-static int xGroupStart(gk_dist *d) {
-    if (!d->loop) return rccl()->GroupStart();
-    d->group.clear();
-    return ncclSuccess;
-}
-static int xSend(gk_dist *d, const void *p, size_t count, int dt, int peer, hipStream_t st) {
-    if (!d->loop) return rccl()->Send(p, count, dt, peer, d->comm, st);
-    d->group.push_back({true, const_cast<void *>(p), count * dtype_bytes(dt), peer, st});
-    return ncclSuccess;
-}
-static int xRecv(gk_dist *d, void *p, size_t count, int dt, int peer, hipStream_t st) {
-    if (!d->loop) return rccl()->Recv(p, count, dt, peer, d->comm, st);
-    d->group.push_back({false, p, count * dtype_bytes(dt), peer, st});
-    return ncclSuccess;
-}
-static int xGroupEnd(gk_dist *d) {
-    if (!d->loop) return rccl()->GroupEnd();
-    LoopHub &h = *d->loop;
-    const size_t n = d->group.size();
-    std::unique_ptr<bool[]> done(new bool[n]());
-    int err = 0;
-    std::unique_lock<std::mutex> lk(h.mu);
-    for (size_t i = 0; i < n; i++) {
-        const gk_dist::Posted &o = d->group[i];
-        hipEvent_t ev = nullptr;
-        if (o.send) {                                 // the data is ready once the sender's stream reaches this point
-            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, o.stream) != hipSuccess) err = 1;
-            h.events.push_back(ev);
-            h.sends[d->rank][o.peer].push_back({o.ptr, o.bytes, o.stream, ev, &done[i], &err});
-        } else {
-            h.recvs[o.peer][d->rank].push_back({o.ptr, o.bytes, o.stream, nullptr, &done[i], &err});
-        }
-    }
-    // match whatever can be matched (any thread may complete any pair), then wait for the rest of this group
-    auto match_all = [&]() {
-        for (int s = 0; s < h.world; s++)
-            for (int r = 0; r < h.world; r++)
-                while (!h.sends[s][r].empty() && !h.recvs[s][r].empty()) {
-                    LoopHub::Op a = h.sends[s][r].front(), b = h.recvs[s][r].front();
-                    h.sends[s][r].pop_front(); h.recvs[s][r].pop_front();
-                    int e = 0;
-                    if (a.bytes != b.bytes) e = 2;                               // RCCL would hang or corrupt here
-                    else if (a.bytes) {
-                        hipEvent_t copied = nullptr;
-                        if (hipStreamWaitEvent(b.stream, a.ready, 0) != hipSuccess) e = 1;
-                        if (!e && hipMemcpyAsync(b.ptr, a.ptr, a.bytes, hipMemcpyDeviceToDevice, b.stream) != hipSuccess) e = 1;
-                        // the sender may reuse its buffer only after the copy: its stream waits for it
-                        if (!e && (hipEventCreateWithFlags(&copied, hipEventDisableTiming) != hipSuccess || hipEventRecord(copied, b.stream) != hipSuccess ||
-                                   hipStreamWaitEvent(a.stream, copied, 0) != hipSuccess)) e = 1;
-                        if (copied) h.events.push_back(copied);
-                    }
-                    if (e) { *a.err = e; *b.err = e; }
-                    *a.done = true; *b.done = true;
-                }
-    };
-    auto all_done = [&]() { for (size_t i = 0; i < n; i++) if (!done[i]) return false; return true; };
-    match_all();
-    h.cv.notify_all();
-    while (!all_done()) {
-        h.cv.wait(lk);
-        match_all();
-        h.cv.notify_all();
-    }
-    lk.unlock();
-    d->group.clear();
-    return err ? 3 /* ncclInternalError */ : ncclSuccess;
-}
-// all-reduce (sum / max) of n <= 32 values of 8 bytes, or (gather = true) one value from every rank to every rank
-static int loop_collective(gk_dist *d, const void *in, void *out, size_t n, int dt, int op, bool gather, hipStream_t st) {
-    LoopHub &h = *d->loop;
-    if (n > 32 || (gather && n != 1)) return 3;
-    double mine[32];
-    if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(mine, in, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 3;
-    double res[64 * 32];
-    size_t nres = gather ? (size_t)h.world : n;
-    {
-        std::unique_lock<std::mutex> lk(h.mu);
-        const unsigned long long gen = h.gen;
-        memcpy(h.contrib[d->rank], mine, n * 8);
-        if (++h.arrived == h.world) {
-            for (size_t i = 0; i < nres; i++) {
-                if (gather) { memcpy(&h.result[i], &h.contrib[i][0], 8); continue; }
-                if (dt == ncclFloat64) {
-                    double acc = h.contrib[0][i];
-                    for (int r = 1; r < h.world; r++) acc = op == ncclMax ? std::max(acc, h.contrib[r][i]) : acc + h.contrib[r][i];
-                    h.result[i] = acc;
-                } else {
-                    unsigned long long acc = 0, v;
-                    for (int r = 0; r < h.world; r++) { memcpy(&v, &h.contrib[r][i], 8); acc = op == ncclMax ? std::max(acc, v) : acc + v; }
-                    memcpy(&h.result[i], &acc, 8);
-                }
-            }
-            h.arrived = 0;
-            h.gen++;
-            h.cv.notify_all();
-        } else {
-            h.cv.wait(lk, [&]() { return h.gen != gen; });
-        }
-        memcpy(res, h.result, nres * 8);
-    }
-    return hipMemcpyAsync(out, res, nres * 8, hipMemcpyHostToDevice, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess ? ncclSuccess : 3;
-}
-static int xAllReduce(gk_dist *d, const void *in, void *out, size_t n, int dt, int op, hipStream_t st) {
-    if (!d->loop) return rccl()->AllReduce(in, out, n, dt, op, d->comm, st);
-    return loop_collective(d, in, out, n, dt, op, false, st);
-}
-static int xAllGather(gk_dist *d, const void *in, void *out, size_t n_per_rank, int dt, hipStream_t st) {
-    if (!d->loop) return rccl()->AllGather(in, out, n_per_rank, dt, d->comm, st);
-    return loop_collective(d, in, out, n_per_rank, dt, ncclSum, true, st);
-}
+// ---- the RCCL transport -----------------------------------------------------------------------------------------------------
+namespace {
+int rccl_group_start(gk_dist *) { return rccl()->GroupStart(); }
+int rccl_send(gk_dist *d, const void *p, size_t count, int dt, int peer, hipStream_t st) { return rccl()->Send(p, count, dt, peer, (ncclComm_t)d->comm, st); }
+int rccl_recv(gk_dist *d, void *p, size_t count, int dt, int peer, hipStream_t st) { return rccl()->Recv(p, count, dt, peer, (ncclComm_t)d->comm, st); }
+int rccl_group_end(gk_dist *) { return rccl()->GroupEnd(); }
+int rccl_all_reduce(gk_dist *d, const void *in, void *out, size_t n, int dt, int op, hipStream_t st) { return rccl()->AllReduce(in, out, n, dt, op, (ncclComm_t)d->comm, st); }
+int rccl_all_gather(gk_dist *d, const void *in, void *out, size_t n, int dt, hipStream_t st) { return rccl()->AllGather(in, out, n, dt, (ncclComm_t)d->comm, st); }
+std::string rccl_error_text(int code) { Rccl *r = rccl(); return r->GetErrorString ? r->GetErrorString(code) : "RCCL error"; }
+void rccl_close(gk_dist *d) { if (d->comm && rccl()->CommDestroy) (void)rccl()->CommDestroy((ncclComm_t)d->comm); d->comm = nullptr; }
+const Transport RCCL_TRANSPORT = {rccl_group_start, rccl_send, rccl_recv, rccl_group_end, rccl_all_reduce, rccl_all_gather, rccl_error_text, rccl_close};
+}  // namespace
+static int xGroupStart(gk_dist *d) { return d->xport->group_start(d); }
+static int xSend(gk_dist *d, const void *p, size_t count, int dt, int peer, hipStream_t st) { return d->xport->send(d, p, count, dt, peer, st); }
+static int xRecv(gk_dist *d, void *p, size_t count, int dt, int peer, hipStream_t st) { return d->xport->recv(d, p, count, dt, peer, st); }
+static int xGroupEnd(gk_dist *d) { return d->xport->group_end(d); }
+static int xAllReduce(gk_dist *d, const void *in, void *out, size_t n, int dt, int op, hipStream_t st) { return d->xport->all_reduce(d, in, out, n, dt, op, st); }
+static int xAllGather(gk_dist *d, const void *in, void *out, size_t n_per_rank, int dt, hipStream_t st) { return d->xport->all_gather(d, in, out, n_per_rank, dt, st); }
 
 static int dist_check(const gk_dist *d) {
-    if (!d || !d->ctx || (!d->comm && !d->loop)) return fail(nullptr, GK_E_INVALID, "null or closed gk_dist handle");
+    if (!d || !d->ctx || !d->xport) return fail(nullptr, GK_E_INVALID, "null or closed gk_dist handle");
+    tl_dist = d;
     hipError_t e = hipSetDevice(d->ctx->device);
     if (e != hipSuccess) return hip_fail(d->ctx, e, "hipSetDevice");
     return GK_OK;
@@ -365,33 +191,12 @@ int gk_dist_unique_id(void *id128) {
     return GK_OK;
 }
 
-static int dist_create(gk_ctx *ctx, int rank, int world, const void *id128, bool loopback, gk_dist **out) {
-    if (!ctx || !out || !id128) return fail(ctx, GK_E_INVALID, "gk_dist_create: null argument");
+}  // extern "C"
+namespace gk {
+int dist_create_common(gk_ctx *ctx, int rank, int world, gk_dist **out) {
     *out = nullptr;
-    if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail(ctx, GK_E_INVALID, "gk_dist_create: need 0 <= rank < world <= 64");
-    Rccl *r = loopback ? nullptr : rccl();
-    if (r && !r->why.empty()) return fail(ctx, GK_E_COMM, r->why);
-    GK_HIP(ctx, hipSetDevice(ctx->device));
     gk_dist *d = new gk_dist();
     d->ctx = ctx; d->rank = rank; d->world = world;
-    if (loopback) {
-        // the ranks of one loopback "node" find each other by the id (any 128 bytes every rank was given alike)
-        d->loop_key.assign((const char *)id128, 128);
-        std::lock_guard<std::mutex> lk(g_hubs_mu);
-        std::shared_ptr<LoopHub> &h = g_hubs[d->loop_key];
-        if (!h) { h = std::make_shared<LoopHub>(); h->world = world; }
-        if (h->world != world) { delete d; return fail(ctx, GK_E_INVALID, "gk_dist_create_loopback: the ranks of one id disagree about the world size"); }
-        h->refs++;
-        d->loop = h;
-    } else {
-        ncclUniqueId id;
-        memcpy(id.internal, id128, 128);
-        int rc = r->CommInitRank(&d->comm, world, id, rank);
-        if (rc != ncclSuccess) {
-            delete d;
-            return fail(ctx, GK_E_COMM, std::string("ncclCommInitRank: ") + (r->GetErrorString ? r->GetErrorString(rc) : "error"));
-        }
-    }
     hipError_t e = hipMalloc((void **)&d->d_cnt, 8 * 64 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc((void **)&d->h_cnt, 8 * 64 * sizeof(unsigned long long), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void **)&d->d_route_cnt, gk_dist::NROUTE * SKM_COUNT_WORDS * sizeof(unsigned long long));
@@ -404,9 +209,28 @@ static int dist_create(gk_ctx *ctx, int rank, int world, const void *id128, bool
     *out = d;
     return GK_OK;
 }
+}  // namespace gk
+extern "C" {
 
-int gk_dist_create(gk_ctx *ctx, int rank, int world, const void *id128, gk_dist **out) { return dist_create(ctx, rank, world, id128, false, out); }
-int gk_dist_create_loopback(gk_ctx *ctx, int rank, int world, const void *id128, gk_dist **out) { return dist_create(ctx, rank, world, id128, true, out); }
+int gk_dist_create(gk_ctx *ctx, int rank, int world, const void *id128, gk_dist **out) {
+    if (!ctx || !out || !id128) return fail(ctx, GK_E_INVALID, "gk_dist_create: null argument");
+    *out = nullptr;
+    if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail(ctx, GK_E_INVALID, "gk_dist_create: need 0 <= rank < world <= 64");
+    Rccl *r = rccl();
+    if (!r->why.empty()) return fail(ctx, GK_E_COMM, r->why);
+    GK_HIP(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(id.internal, id128, 128);
+    ncclComm_t comm = nullptr;
+    const int rc = r->CommInitRank(&comm, world, id, rank);
+    if (rc != ncclSuccess) return fail(ctx, GK_E_COMM, std::string("ncclCommInitRank: ") + (r->GetErrorString ? r->GetErrorString(rc) : "error"));
+    gk_dist *d = nullptr;
+    if (int c = dist_create_common(ctx, rank, world, &d)) { if (r->CommDestroy) (void)r->CommDestroy(comm); return c; }
+    d->xport = &RCCL_TRANSPORT;
+    d->comm = comm;
+    *out = d;
+    return GK_OK;
+}
 
 void gk_dist_destroy(gk_dist *d) {
     if (!d) return;
@@ -415,12 +239,7 @@ void gk_dist_destroy(gk_dist *d) {
     if (ctx) { (void)hipSetDevice(ctx->device); drain_garbage(d); }
     if (d->ctx) { (void)hipSetDevice(d->ctx->device); (void)hipStreamSynchronize(d->ctx->stream); }
     if (d->comm_stream) (void)hipStreamSynchronize(d->comm_stream);
-    if (d->comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(d->comm);
-    if (d->loop) {
-        std::lock_guard<std::mutex> lk(g_hubs_mu);
-        if (--d->loop->refs == 0) g_hubs.erase(d->loop_key);
-        d->loop.reset();
-    }
+    if (d->xport && d->xport->close) d->xport->close(d);
     if (d->ctx && d->ctx->copy_stream) (void)hipStreamSynchronize(d->ctx->copy_stream);
     for (int i = 0; i < gk_dist::NROUTE; i++) if (d->d_sendbuf[i]) (void)hipFree(d->d_sendbuf[i]);
     for (int i = 0; i < 2; i++) if (d->d_recv[i]) (void)hipFree(d->d_recv[i]);

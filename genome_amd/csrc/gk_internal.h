@@ -62,6 +62,12 @@ struct gk_ctx {
     size_t mem_budget = 0;                                   // gk_ctx_set_mem_budget: plan as if the device had this much memory (0: all of it)
     uint64_t pool_hits = 0, pool_misses = 0;
     std::recursive_mutex pool_mu;                            // (gk_dist's helper thread grows its buffers beside the owner pipeline)
+    // the path-choice model's coefficients for THIS device (gk_table.hip: path_cost): 0 not measured yet, 1 measured, 2 reference values
+    int cost_state = 0;
+    alignas(8) unsigned char cost_blob[96] = {};
+    double measured_copy_tbps = 0, measured_cas_gps = 0;
+    // what the same two kernels measure on the box of the round 1-2 profiles (64 MiB working sets: partly Infinity Cache)
+    double ref_copy_tbps = 6.0, ref_cas_gps = 30.0;
     std::string err;
 };
 

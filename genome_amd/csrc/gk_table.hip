@@ -606,6 +606,8 @@ static int check_map(gk_map *m) {                  // slots must be valid afterw
     return map_materialize(m);
 }
 
+extern "C" __attribute__((weak)) void gk_testhooks_env(gk_ctx *ctx);      // gk_testhooks.hip; absent from the product library
+
 extern "C" {
 
 int gk_device_count(void) {
@@ -647,14 +649,10 @@ int gk_ctx_create(int device, gk_ctx **out) {
     }
     ctx->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->pool_limit = (size_t)prop.totalGlobalMem / 3;
-    // test / A-B hooks: the environment is read HERE, once (see gk_ctx_set_option for the programmatic form)
-    ctx->hook_no_reserve = getenv("GK_TEST_NO_RESERVE") != nullptr;
-    ctx->hook_host_ragged = getenv("GK_HOST_RAGGED") != nullptr;
-    ctx->hook_part_exact = getenv("GK_PART_EXACT") != nullptr;
-    if (const char *u = getenv("GK_P45_STRIPES")) ctx->hook_p45_stripes = atoi(u);
-    if (const char *u = getenv("GK_MIN_LNB1")) ctx->hook_min_lnb1 = std::max(0, std::min((int)gk::MAX_LNB1, atoi(u)));      // (tests: the whole suite over 512 / 1024 L1 buckets)
-    if (const char *u = getenv("GK_GRAPH_UNITIGS")) ctx->hook_unitigs = !strcmp(u, "walk") ? 1 : !strcmp(u, "pj") ? 2 : 0;
-    if (const char *u = getenv("GK_GRAPH_MBT")) ctx->hook_graph_mbt = atoi(u);            // (tests: the whole graph suite over the bucketed table)
+    // Test / A-B switches exist only in the TEST build of the library (libgenome_amd_test.so = this library + gk_testhooks.o):
+    // there the environment is read HERE, once, and gk_ctx_set_option is the programmatic form.  The product library has
+    // neither: nothing in a host JVM's environment can change its behaviour.
+    if (gk_testhooks_env) gk_testhooks_env(ctx);
     *out = ctx;
     return GK_OK;
 }
@@ -708,44 +706,6 @@ int gk_ctx_set_mem_budget(gk_ctx *ctx, uint64_t bytes) {
 
 const char *gk_last_error(const gk_ctx *ctx) { return ctx ? ctx->err.c_str() : tls_err.c_str(); }
 int gk_ctx_device(const gk_ctx *ctx) { return ctx ? ctx->device : -1; }
-
-int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value) {
-    if (!ctx || !name) return fail(ctx, GK_E_INVALID, "gk_ctx_set_option: null argument");
-    const std::string n(name);
-    if (n == "test_no_reserve") ctx->hook_no_reserve = value != 0;
-    else if (n == "host_ragged") ctx->hook_host_ragged = value != 0;
-    else if (n == "part_exact") ctx->hook_part_exact = value != 0;
-    else if (n == "graph_unitigs") {
-        if (value < 0 || value > 2) return fail(ctx, GK_E_INVALID, "graph_unitigs: 0 auto, 1 walk, 2 pointer jumping");
-        ctx->hook_unitigs = (int)value;
-    } else if (n == "p4_direct") ctx->hook_p4_direct = value < 0 ? -1 : value != 0;
-    else if (n == "p2_wide") ctx->hook_p2_wide = value < 0 ? -1 : value != 0;
-    else if (n == "p2_sorted") ctx->hook_p2_sorted = value < 0 ? -1 : value != 0;
-    else if (n == "p4_wide") ctx->hook_p4_wide = value < 0 ? -1 : (value >= 2 ? 2 : value != 0);
-    else if (n == "p45_stripes") ctx->hook_p45_stripes = (int)value;
-    else if (n == "p24_pieces") ctx->hook_p24_pieces = (int)value;
-    else if (n == "dist_exchange_ahead") ctx->hook_dist_ahead = (int)value;
-    else if (n == "test_dist_small_send") ctx->hook_dist_small_send = (int)std::max<int64_t>(0, value);
-    else if (n == "test_dist_fail_exchange") ctx->hook_dist_fail = value > 0 ? -(int)value : (int)value;
-    else if (n == "test_max_nb2") ctx->hook_max_nb2 = (int)std::max<int64_t>(0, value);
-    else if (n == "min_lnb1") {
-        if (value < 0 || value > (int64_t)gk::MAX_LNB1) return fail(ctx, GK_E_INVALID, "min_lnb1: 0..10");
-        ctx->hook_min_lnb1 = (int)value;
-    }
-    else if (n == "p4_grid") ctx->hook_p4_grid = (int)value;
-    else if (n == "graph_walk_queue") ctx->hook_walk_queue = (int)value;
-    else if (n == "graph_mbt") ctx->hook_graph_mbt = (int)value;
-    else if (n == "graph_mbt_keys") ctx->hook_graph_mbt_keys = (int)std::max<int64_t>(16, value);
-    else if (n == "pairs_host") ctx->hook_pairs_host = (int)value;
-    else if (n == "host_prefetch") ctx->hook_host_prefetch = (int)value;
-    else if (n == "test_max_stage") ctx->hook_max_stage = (int64_t)std::max<int64_t>(0, value);
-    else if (n == "test_pairs_small_sets") ctx->hook_pairs_small_sets = (int)value;
-    else if (n == "filter_classic") ctx->hook_filter_classic = (int)value;
-    else if (n == "graph_load_pct") ctx->hook_graph_load_pct = (int)value;
-    else if (n == "fine_exact") ctx->hook_fine_exact = value < 0 ? -1 : value != 0;
-    else return fail(ctx, GK_E_INVALID, "gk_ctx_set_option: unknown option '" + n + "'");
-    return GK_OK;
-}
 
 int gk_ctx_sync(gk_ctx *ctx) {
     if (!ctx) return fail(nullptr, GK_E_INVALID, "null ctx");
@@ -1025,11 +985,57 @@ struct PathCost {
     double stream_tbps = 4.6;       // k_seg_insert writes / reads the table at 4.6 TB/s; k_clear reaches 4.95
     double fixed_us = 60.0;         // launches, the small scans, one or two host round trips
 };
-static const PathCost COST;
+// The coefficients above were measured on ONE MI355X (round 1-2 profiles).  What differs from card to card (another HBM stack
+// speed, a power cap, another part of the family) is taken from TWO numbers measured on the context's own device the first time
+// a path has to be chosen: its streaming copy rate (the box of the profiles: 4.85 TB/s) and its random 64-bit CAS rate (17.6 G/s).
+// The streaming phases' prices scale with the first, the direct path's with the second; ~3 ms, once per context.
+__global__ __launch_bounds__(256) void k_calib_cas(u64 *arr, u64 mask, u64 n) {
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) (void)cas64(&arr[mix64(i) & mask], ~0ull, i);
+}
+static const PathCost &path_cost(gk_ctx *ctx) {
+    static const PathCost REF;
+    if (ctx->cost_state == 1) return *reinterpret_cast<const PathCost *>(ctx->cost_blob);
+    if (ctx->cost_state == 2) return REF;
+    static_assert(sizeof(PathCost) <= sizeof(ctx->cost_blob), "cost blob");
+    ctx->cost_state = 2;                                           // (whatever happens below, measure once)
+    constexpr u64 N16 = (64u << 20) / 16, NCAS = 1u << 23;           // 64 MiB copied, 8 M CAS into a 64 MiB table
+    uint4 *a = nullptr, *b = nullptr;
+    if (hipMalloc((void **)&a, N16 * 16) != hipSuccess || hipMalloc((void **)&b, N16 * 16) != hipSuccess) { (void)hipGetLastError(); if (a) (void)hipFree(a); return REF; }
+    const int grid = ctx->cu_count * 8;
+    float ms_copy = 0, ms_cas = 0;
+    hipError_t e = hipMemsetAsync(a, 0xff, N16 * 16, ctx->stream);
+    for (int r = 0; r < 3 && e == hipSuccess; r++) {               // the third launch is the timed one
+        if (r == 2) e = hipEventRecord(ctx->ev0, ctx->stream);
+        hipLaunchKernelGGL(k_stream_copy, dim3(grid), dim3(256), 0, ctx->stream, a, b, N16);
+    }
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(ctx->ev1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms_copy, ctx->ev0, ctx->ev1);
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev0, ctx->stream);
+    if (e == hipSuccess) hipLaunchKernelGGL(k_calib_cas, dim3(grid), dim3(256), 0, ctx->stream, (u64 *)a, (u64)(N16 * 2 - 1), (u64)NCAS);
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(ctx->ev1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms_cas, ctx->ev0, ctx->ev1);
+    (void)hipFree(a); (void)hipFree(b);
+    if (e != hipSuccess || ms_copy <= 0 || ms_cas <= 0) { (void)hipGetLastError(); return REF; }
+    const double copy_tbps = 2.0 * N16 * 16 / (ms_copy * 1e-3) / 1e12, cas_gps = NCAS / (ms_cas * 1e-3) / 1e9;
+    // (a 64 MiB working set partly lives in the 256 MB Infinity Cache: the RATIOS to the reference box are what is used, and they are
+    //  clamped — a calibration that is off by more than 2x says more about the moment it ran than about the card)
+    const double fs = std::min(2.0, std::max(0.5, copy_tbps / ctx->ref_copy_tbps)), fa = std::min(2.0, std::max(0.5, cas_gps / ctx->ref_cas_gps));
+    PathCost c = REF;
+    c.stream_tbps *= fs;
+    c.p2_ps /= fs; c.p3_ps /= fs; c.p4_ps /= fs; c.p4_ps_per_nb2 /= fs; c.p5_ps /= fs;
+    c.direct_ps /= fa;
+    memcpy(ctx->cost_blob, &c, sizeof(c));
+    ctx->measured_copy_tbps = copy_tbps; ctx->measured_cas_gps = cas_gps;
+    ctx->cost_state = 1;
+    return *reinterpret_cast<const PathCost *>(ctx->cost_blob);
+}
 static bool use_partitioned(const gk_map *m, u64 occ) {
     if (m->insert_path == 1 || !part_supported(m)) return false;
     if (m->insert_path == 2) return true;
     if (m->skewed) return false;          // this map's data has already defeated even the L1 regions once (one k-mer, millions of times)
+    const PathCost &COST = path_cost(m->ctx);
     const double tb = (double)m->capacity * (double)slot_bytes(m->W);
     const double pass_us = tb / (COST.stream_tbps * 1e6);
     const double us_direct = (double)occ * COST.direct_ps * 1e-6 + (m->pending_clear ? pass_us : 0.0);
@@ -1853,14 +1859,16 @@ int gk_map_stats(gk_map *m, char *json, size_t cap) {
                      "\"load\":%.6f,\"occurrences\":%llu,\"grows\":%llu,\"last_count_kernel_ms\":%.6f,"
                      "\"last_count_occurrences\":%llu,\"partitioned_launches\":%llu,\"direct_launches\":%llu,"
                      "\"spilled_keys\":%llu,\"failed_segments\":%llu,\"retries_direct\":%llu,\"est_new_distinct_last_batch\":%llu,"
-                     "\"noncanonical_keys\":%s,\"repeat_heavy\":%s,\"last_count_host_gap_ms\":%.4f,\"device\":%d,\"cu_count\":%d}",
+                     "\"noncanonical_keys\":%s,\"repeat_heavy\":%s,\"last_count_host_gap_ms\":%.4f,\"device\":%d,\"cu_count\":%d,"
+                     "\"calib_copy_tbps\":%.4f,\"calib_cas_gps\":%.4f}",
                      m->k, m->W, slot_bytes(m->W), (unsigned long long)m->capacity, (unsigned long long)m->size,
                      (unsigned long long)m->tombstones, m->capacity ? (double)m->size / (double)m->capacity : 0.0,
                      (unsigned long long)m->total_occurrences, (unsigned long long)m->grows, m->last_count_ms,
                      (unsigned long long)m->last_count_occ, (unsigned long long)m->part_launches,
                      (unsigned long long)m->direct_launches, (unsigned long long)m->spilled_keys,
                      (unsigned long long)m->failed_segments, (unsigned long long)m->retries_direct, (unsigned long long)m->est_distinct_last,
-                     m->dirty ? "true" : "false", m->repeats ? "true" : "false", m->gap_ms, m->ctx->device, m->ctx->cu_count);
+                     m->dirty ? "true" : "false", m->repeats ? "true" : "false", m->gap_ms, m->ctx->device, m->ctx->cu_count,
+                     m->ctx->measured_copy_tbps, m->ctx->measured_cas_gps);
     if (w < 0 || (size_t)w >= cap) return fail(m->ctx, GK_E_CAPACITY, "stats buffer too small");
     return GK_OK;
 }

@@ -203,7 +203,12 @@ int vm_sync(gk_vmap *m) {
     m->size = h[0];
     if (h[1]) {
         GK_HIP(m->ctx, hipMemsetAsync(m->d_ctr + 1, 0, 8, m->ctx->stream));
-        return fail(m->ctx, GK_E_CAPACITY, "value map: a table segment filled up (internal sizing error)");
+        // every copy of a key lives in the ONE segment its hash names (2048 entries of 8-byte keys, 1024 of 16-byte keys, a quarter
+        // of that at k = 64): a key stored more often than that — or a heavy key plus its segment's other keys — cannot be helped by
+        // growing the table (the reference's putNew probes the whole table and has no such bound: ArrayDNAMap.scala:152-162)
+        return fail(m->ctx, GK_E_CAPACITY, "value map: a segment filled up — one key stored more often than a segment holds (" +
+                                               std::to_string((1u << seg_bits_for(m->W)) / (m->k == 64 ? 4u : 1u)) +
+                                               " entries)?  The batch's other entries ARE stored (gk_vmap_size counts them)");
     }
     return GK_OK;
 }

@@ -46,7 +46,7 @@ class HipDist:
         assert len(id128) == 128
         self.ctx, self.rank, self.world = ctx, rank, world
         self.h = L.vp()
-        create = L.lib().gk_dist_create_loopback if loopback else L.lib().gk_dist_create
+        create = L.test_hook("gk_dist_create_loopback") if loopback else L.lib().gk_dist_create
         L.check(create(ctx.h, rank, world, C.create_string_buffer(id128, 128), C.byref(self.h)), ctx.h)
 
     def close(self):

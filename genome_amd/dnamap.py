@@ -38,8 +38,8 @@ class Context:
             pass
 
     def set_option(self, name: str, value: int):
-        """Test / A-B switches (include/genome_amd.h: gk_ctx_set_option)."""
-        L.check(L.lib().gk_ctx_set_option(self.h, name.encode(), int(value)), self.h)
+        """Test / A-B switches (include/genome_amd_test.h: gk_ctx_set_option; the TEST build of the library only)."""
+        L.check(L.test_hook("gk_ctx_set_option")(self.h, name.encode(), int(value)), self.h)
 
     def sync(self):
         """Wait for everything queued on the context's stream."""

@@ -24,6 +24,9 @@
  *      and k>64 takes its un-specialised ArrayDNASeq path: GK_E_UNSUPPORTED_K.
  *   - There is no CPU fallback: without a gfx950 device every compute call fails with
  *     GK_E_NODEVICE / GK_E_HIP.
+ *   - This is everything a host binds.  The library's test hooks (A/B switches of the kernels, failure injection, a loopback
+ *     transport that runs several ranks on one GPU) are NOT in libgenome_amd.so: they live in the test build,
+ *     libgenome_amd_test.so, behind include/genome_amd_test.h.
  */
 #ifndef GENOME_AMD_H
 #define GENOME_AMD_H
@@ -75,19 +78,6 @@ int gk_ctx_mem_stats(gk_ctx *ctx, uint64_t *live, uint64_t *peak, uint64_t *park
  * load factor of the table the graph phase reads, the key scratch of an insert batch — then use min(free, bytes - live).  For a
  * GPU shared with other work, and for rehearsing an 8-GPU replica's budget at an eighth of its size. */
 int gk_ctx_set_mem_budget(gk_ctx *ctx, uint64_t bytes);
-/* Test / A-B switches (never needed in production).  Their defaults are read from the environment ONCE, in
- * gk_ctx_create (GK_TEST_NO_RESERVE, GK_HOST_RAGGED, GK_PART_EXACT, GK_GRAPH_UNITIGS=walk|pj); no entry point
- * consults the environment afterwards.  Names: "test_no_reserve", "host_ragged", "part_exact" (0/1),
- * "graph_unitigs" (0 auto, 1 walk, 2 pointer jumping), "graph_walk_queue" (0: one edge per lane), "graph_load_pct" (load factor
- * of the compacted table, percent), "p4_direct" / "fine_exact" / "p2_wide" / "p2_sorted" (-1 auto, 0, 1), "p4_wide" (-1 auto, 0: 4096-key sorts, 1: 8192, 2: 12288),
- * "p45_stripes" (P5 of one stripe of L1 buckets beside P4 of the next), "p24_pieces" (P4 of one piece of a batch beside the L1
- * scatter of the next), "p4_grid" (P4 workgroups per CU), "filter_classic" (1: tombstones + rehash instead of the streaming
- * rebuild), "dist_exchange_ahead" (0: gk_dist_count_routed does not post the next batch's exchange ahead; every rank alike):
- * A/B switches of the kernels in gk_partition.hip / gk_graph.hip / gk_dist.hip; what each measured is in DESIGN.md and
- * profiles/r02.  "min_lnb1" (also GK_MIN_LNB1; 9 / 10: tables of enough segments get 512 / 1024 L1 buckets, the fan-out of
- * tables beyond 34 GB) and "test_max_nb2" (the pipeline refuses tables of more fine buckets per L1 bucket) stage the
- * large-table paths on small tables. */
-int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value);
 /* Pinned host memory: gk_map_count_reads / gk_prefilter_add_reads read the caller's `.bin` buffer with asynchronous copies
  * that overlap the insert kernels only if the buffer is page-locked — allocate it here, or register an existing one (a JNI
  * direct ByteBuffer's address) for as long as it is passed in.  Pageable buffers work, at a staged copy's speed. */
@@ -232,7 +222,11 @@ int gk_vmap_create(gk_ctx *ctx, int k, uint64_t capacity_hint, gk_vmap **out);  
 void gk_vmap_destroy(gk_vmap *m);
 int gk_vmap_k(const gk_vmap *m);
 int gk_vmap_size(gk_vmap *m, uint64_t *n);                                         /* DNAMap.size :50 — entries, duplicates included */
-/* DNAMap.putNew(key, v) (:55; Container.putNew ArrayDNAMap.scala:152-162), batched: no duplicate check — a multimap */
+/* DNAMap.putNew(key, v) (:55; Container.putNew ArrayDNAMap.scala:152-162), batched: no duplicate check — a multimap.
+ * BOUND (the reference has none): all copies of a key live in the one 32 KiB / 24 KiB segment its hash names, so one key can be
+ * stored at most 2048 times (k <= 31), 1024 times (34 <= k <= 63) or 256 times (k = 64), less what else shares the segment;
+ * beyond that the call fails with GK_E_CAPACITY, the batch's other entries stay stored (a failed batch is NOT rolled back;
+ * gk_vmap_size tells what is in).  Graph.getGraphMap stores a k-mer once per graph position: far from the bound. */
 int gk_vmap_put_new_batch(gk_vmap *m, const uint64_t *lo, const uint64_t *hi, const uint64_t *values, uint64_t n);
 /* DNAMap.update(key, v) (:53; Container.update :115-127), batched: insert, or overwrite the first entry of the key; for a key
  * that occurs several times in one batch the LAST occurrence wins, as in the reference's sequential loop */
@@ -264,12 +258,6 @@ int gk_vmap_export(gk_vmap *m, uint64_t *lo, uint64_t *hi, uint64_t *values, uin
  * All gk_dist_* calls that move data are COLLECTIVE: every rank of the communicator must make them, in the same order. */
 int gk_dist_unique_id(void *id128);                                   /* out: 128 bytes */
 int gk_dist_create(gk_ctx *ctx, int rank, int world, const void *id128, gk_dist **out);
-/* TEST transport: the ranks are threads of ONE process on ONE device; sends, receives and reductions go through a hub in the
- * library (device-to-device copies matched pairwise in posting order) instead of RCCL, which refuses two ranks on one GPU.  Every
- * rank passes the same 128 id bytes (any) and its own context; calls block until the peers have posted the matching operation
- * (an inconsistent order of operations across ranks deadlocks at once; a send and its receive that differ in size are GK_E_COMM).
- * Everything else about the handle is the product code path. */
-int gk_dist_create_loopback(gk_ctx *ctx, int rank, int world, const void *id128, gk_dist **out);
 void gk_dist_destroy(gk_dist *d);
 int gk_dist_rank(const gk_dist *d);
 int gk_dist_world(const gk_dist *d);

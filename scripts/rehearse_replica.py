@@ -16,6 +16,7 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("GK_LIB_PATH", os.path.join(sys.path[0], "genome_amd", "libgenome_amd_test.so"))      # (graph_unitigs is a test-build switch)
 
 from genome_amd import synth                                   # noqa: E402
 from genome_amd.dist import DistDNAMap, HipDist, unique_id     # noqa: E402

@@ -7,6 +7,8 @@ prefilter_distinct > 0: two passes over the reads through the exact singleton pr
 import sys, time, json
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
+if len(sys.argv) > 9 and sys.argv[9]:      # option switches live in the test build of the library
+    __import__('os').environ.setdefault("GK_LIB_PATH", __import__('os').path.join(sys.path[0], "genome_amd", "libgenome_amd_test.so"))
 from genome_amd import synth
 from genome_amd.dnamap import Context, HipDNAMap
 from genome_amd.graph import buildGraph

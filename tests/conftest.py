@@ -6,6 +6,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The tests drive the library's test hooks (gk_ctx_set_option, the loopback transport): they load the TEST build — the product
+# library's own objects plus csrc/gk_testhooks.o — unless the caller chose a build (a variant under genome_amd/variants/).
+# smoke() and bench.py load the product library.
+os.environ.setdefault("GK_LIB_PATH", os.path.join(ROOT, "genome_amd", "libgenome_amd_test.so"))
 
 
 def pytest_configure(config):

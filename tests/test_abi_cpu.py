@@ -14,22 +14,32 @@ from oracle import pyref as R
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _declared(header):
+    hdr = open(os.path.join(ROOT, "include", header)).read()
+    return set(re.findall(r"\b(gk_[a-z0-9_]+)\s*\(", hdr)) - {"gk_status"}
+
+
 def test_library_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, "include", "genome_amd.h")).read()
-    declared = set(re.findall(r"\b(gk_[a-z0-9_]+)\s*\(", hdr))
-    declared -= {"gk_status"}
-    assert len(declared) >= 35
-    lib = C.CDLL(L.LIB_PATH)
-    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    """The PRODUCT library exports exactly what include/genome_amd.h declares — and none of the test hooks; the TEST build adds
+    what include/genome_amd_test.h declares (tests/conftest.py loads that one)."""
+    declared = _declared("genome_amd.h")
+    hooks = _declared("genome_amd_test.h") - declared          # (its comments name product entry points too)
+    assert len(declared) >= 35 and hooks
+    product = C.CDLL(os.path.join(ROOT, "genome_amd", "libgenome_amd.so"))
+    missing = [s for s in sorted(declared) if not hasattr(product, s)]
     assert not missing, missing
+    assert not [s for s in sorted(hooks) if hasattr(product, s)], "test hooks in the product library"
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    test_build = C.CDLL(L.TEST_LIB_PATH)
+    assert not [s for s in sorted(declared | hooks) if not hasattr(test_build, s)]
+    assert hooks == set(L.TEST_SIGNATURES), hooks ^ set(L.TEST_SIGNATURES)
+    assert os.path.samefile(L.LIB_PATH, L.TEST_LIB_PATH) or "variants" in L.LIB_PATH      # what this test session has loaded
 
 
 def test_integration_md_accounts_for_every_declared_symbol():
     """INTEGRATION.md shows the reference-side binding of the path's entry points (its JNI layer, §2-§4) and lists the rest with
     the reason they are not bound (§7): together they must cover the header."""
-    hdr = open(os.path.join(ROOT, "include", "genome_amd.h")).read()
-    declared = set(re.findall(r"\b(gk_[a-z0-9_]+)\s*\(", hdr))
+    declared = _declared("genome_amd.h")
     text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     missing = sorted(s for s in declared if s not in text)
     assert not missing, missing

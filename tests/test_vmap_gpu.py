@@ -274,3 +274,22 @@ def test_checkgraph_invariant_every_kmer_of_the_genome_is_in_the_graph_map(ctx, 
     assert lens == olens and len(lens) > 0
     assert (len(lens), sum(lens), lens[len(lens) // 2], lens[-1]) == (len(olens), sum(olens), olens[len(olens) // 2], olens[-1])
     vm.close(); graph.close(); m.close()
+
+
+def test_put_new_of_one_key_beyond_a_segment_is_refused_with_a_clear_message(ctx):
+    """The reference's putNew probes the whole table; here every copy of a key lives in the one segment its hash names (include/
+    genome_amd.h states the bound): 2048 copies of an 8-byte key fit, many more do not — GK_E_CAPACITY with a message that names
+    the bound, nothing aborts, and the entries that did fit are there (a failed batch is not rolled back)."""
+    k = 21
+    vm = HipValueMap(ctx, k, 1 << 14)
+    key = "ACGT" * 5 + "A"
+    other = "TTGCA" * 4 + "G"
+    vm.putNew_batch([key] * 1500 + [other] * 3, list(range(1503)))
+    assert len(vm.getAll(key)) == 1500 and sorted(vm.getAll(other)) == [1500, 1501, 1502]
+    with pytest.raises(L.GkError) as e:
+        vm.putNew_batch([key] * 1000, list(range(2000, 3000)))
+    assert e.value.code == L.GK_E_CAPACITY and "segment" in str(e.value) and "2048" in str(e.value)
+    n = len(vm.getAll(key))
+    assert 1500 < n <= 2048 and vm.size() == n + 3
+    assert sorted(vm.getAll(other)) == [1500, 1501, 1502]
+    vm.close()
