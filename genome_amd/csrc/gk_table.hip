@@ -1397,7 +1397,16 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
         for (int sl = 0; sl < 2 && !preloaded; sl++) {
             gk_map::StageSlot &st = m->stage[sl];
             if (st.valid && st.host == bin + cur.begin && st.bytes >= cur.bytes) { preloaded = true; m->stage_cur = sl; st.valid = false; }
-            else if (st.armed && st.host == bin + cur.begin) st.armed = false;      // armed for THIS chunk but never fired (nothing ran before it): the piece-wise upload below is the faster way
+        }
+        if (!preloaded) {
+            // Armed for this very stream but never fired (no insert ran since): the piece-wise upload below is the faster way for
+            // THIS chunk, so the request is dropped — the OLDER one if two are armed: a streaming caller that re-uses one buffer
+            // has armed the next batch too (same address), and that one must stay armed to fire behind this batch's scatter.
+            const int older = 1 - m->stage_last_pf;
+            const bool a0 = m->stage[older].armed && m->stage[older].host == bin + cur.begin;
+            const bool a1 = m->stage[1 - older].armed && m->stage[1 - older].host == bin + cur.begin;
+            if (a0) m->stage[older].armed = false;
+            else if (a1) m->stage[1 - older].armed = false;
         }
         if (!preloaded) {
             const bool busy0 = m->stage[0].valid || m->stage[0].armed, busy1 = m->stage[1].valid || m->stage[1].armed;
