@@ -197,14 +197,16 @@ def c3_object(ctx):
                "graph": {"nodes_edges_bases_built": built, "build_phase_ms": ph, "pointer_jumping": bs["pointer_jumping"],
                          "components": comps, "largest_component_nodes": kept, "nodes_edges_bases_final": final},
                "roofline": {"count": roof(occ * (2.0 * L / (8.0 * nk) + 16.0) + distinct * 8.0, t["count"] * 1e3),
-                            "filter_lt": roof(20.0 * st["slots"], t["filter_lt"] * 1e3),
+                            "filter_lt": roof((st["slot_bytes"] + 4.0) * st["slots"], t["filter_lt"] * 1e3),
                             "classify": roof(80.0 * good, ph["classify"]),
                             "unitig_walk": roof(9.25 * bs["walked_bases"], walk_ms),
                             "bytes_per_unit": "SURVEY.md §8d: 16.3 B/occurrence (+8 B/distinct key) count; 20 B/slot filter (12 B scan + 8 B tombstone; the wall "
                                               "time also holds the rebuild into a table sized for the survivors); 80 B/live key classify; 9.25 B/walked base"}}
     # what the memory system carried for the graph kernels, from the committed PMC passes over this same flow (every read request is
     # a 128-byte line, also for a 16-byte random probe: the algorithmic fractions above understate how busy HBM is)
-    pmc = os.path.join(ROOT, "profiles", "r02", "pmc_c3_v11.json")
+    pmc = os.path.join(ROOT, "profiles", "r03", "pmc_c3.json")
+    if not os.path.exists(pmc):
+        pmc = os.path.join(ROOT, "profiles", "r02", "pmc_c3_v11.json")
     if res is not None and os.path.exists(pmc):
         k_ = json.load(open(pmc))["kernels"]
         res["roofline"]["moved_by_pmc"] = {name: {"fetch_bytes": k_[name]["fetch_bytes"], "write_bytes": k_[name]["write_bytes"], "ms": k_[name]["total_ms"],
@@ -410,7 +412,7 @@ def main():
         phases = np.mean(np.array(phase_ms), axis=0)
         stats = m.stats()
         partitioned = stats["partitioned_launches"] > 0
-        slot_b = 16 if W == 1 else 24
+        slot_b = stats["slot_bytes"]            # 12 (8-byte keys in a count table), 16 (the graph layout) or 24 (16-byte keys)
         # ALGORITHMIC bytes of one insert+count pass, whatever kernels carry it
         abytes = (algorithmic_bytes_count_kernel(units, distinct_rank, L, k) if not sharded
                   else algorithmic_bytes_insert_kernel(units, distinct_rank, k))
@@ -436,11 +438,13 @@ def main():
         avg_kernel_ms = kernel_time_ms
         achieved = abytes / (avg_kernel_ms * 1e-3) / 1e9
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r02", "pmc_pipeline_v14.json") if partitioned else os.path.join(ROOT, "profiles", "r01", "pmc_count_reads_v2.json")
-        if partitioned and not os.path.exists(pmc_file):
-            pmc_file = os.path.join(ROOT, "profiles", "r02", "pmc_pipeline_v13.json")
-        if partitioned and not os.path.exists(pmc_file):
-            pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_pipeline_v8.json")
+        # HBM traffic of one step by the PMC counters: the newest committed pass over this very command (scripts/profile_round.sh)
+        pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_count_reads_v2.json")
+        if partitioned:
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03", "pmc_pipeline_*.json"))) or \
+                sorted(glob.glob(os.path.join(ROOT, "profiles", "r02", "pmc_pipeline_v1[34].json")))
+            pmc_file = cands[-1] if cands else pmc_file
         if not sharded and args.mode == "U" and n == 1_000_000 and L == 150 and k == 31 and os.path.exists(pmc_file):
             pj = json.load(open(pmc_file))
             traffic = pj.get("hbm_bytes_per_launch", pj.get("k_count_reads<1>", {}).get("hbm_bytes_per_launch"))
@@ -455,7 +459,7 @@ def main():
                                    + ("single-partition DNAMap kernel" if not sharded else
                                       f"minimizer-sharded PartitionedDNAMap, {world} partitions, RCCL all-to-all"),
                        "reads_per_gpu": n, "read_len": L, "k": k, "mode": args.mode,
-                       "table_slots_per_gpu": m.slots(), "slot_bytes": 16 if W == 1 else 24,
+                       "table_slots_per_gpu": m.slots(), "slot_bytes": stats["slot_bytes"],
                        "insert_path": "partitioned" if partitioned else "direct"},
             "occurrences_per_s": occ_total / (dt_max / args.steps),
             "distinct_per_step": distinct_total, "occurrences_per_step": occ_total,

@@ -215,6 +215,8 @@ template <int W> GK_D uint4 empty_vec(u32 i) {
         return make_uint4(lo, lo, hi, hi);
     }
 }
+template <int W> GK_D uint4 empty_vec_of(const Slot<W> *, u32 i) { return empty_vec<W>(i); }
+template <int W> GK_D void slot_tomb(Slot<W> *s) { s->w0 = ~0ULL - 1; }
 // number of slots whose FIRST key word lies in vector i of a segment and is EMPTY (a slot is free iff its w0 is EMPTY)
 template <int W> GK_D u32 empty_w0_in_vec(u32 i, uint4 v) {
     if constexpr (W == 1) { (void)i; return (v.x & v.y) == ~0u ? 1u : 0u; }
@@ -225,6 +227,39 @@ template <int W> GK_D u32 empty_w0_in_vec(u32 i, uint4 v) {
         return 0u;
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// CSlot — the 12-byte slot of a COUNT table with 8-byte keys (k <= 31): what the reference stores per entry, an 8-byte key and a
+// 4-byte value (ArrayDNAMap.scala:74-89), and nothing else.  The 62-bit key is kept as two 31-bit halves, each with a spare top
+// bit and each claimed by its own 32-bit CAS — the two-word protocol of Slot<2> (claim w0, then w1; whoever sets w1 owns the
+// slot) at half the width: a 12-byte slot is only 4-byte aligned, which rules out a 64-bit CAS on its key.  No `aux`: the graph
+// phase's annotation exists only in the 16-byte Slot<1> tables that deleteAll / the gather / gk_map_create_for_graph build
+// (gk_map::graph_layout).  A segment of 2048 slots is 24 KiB instead of 32: a quarter less to stream per table pass.
+// ------------------------------------------------------------------------------------------
+struct CSlot { u32 w0, w1, extra; };
+static_assert(sizeof(CSlot) == 12, "count slot layout");
+static constexpr u32 KEY_EMPTY32 = ~0u, KEY_TOMB32 = ~0u - 1u;
+GK_HD u32 c_w0(Kmer<1> x) { return (u32)x.lo & 0x7fffffffu; }
+GK_HD u32 c_w1(Kmer<1> x) { return (u32)(x.lo >> 31); }                   // (a k <= 31 k-mer is below 2^62: this is below 2^31)
+GK_D bool slot_live(const CSlot *s) { return s->w0 != KEY_EMPTY32 && s->w0 != KEY_TOMB32; }
+GK_D u32 slot_count(const CSlot *s) { return s->extra + 1u; }
+GK_D Kmer<1> slot_key(const CSlot *slots, u64 i, u32 = 0u) { return Kmer<1>{(u64)slots[i].w0 | ((u64)slots[i].w1 << 31)}; }
+GK_D void slot_tomb(CSlot *s) { s->w0 = KEY_TOMB32; }
+// an array of EMPTY count slots as 16-byte vectors: 32-bit words {~0, ~0, 0} per slot, four per vector
+GK_D uint4 empty_vec_of(const CSlot *, u32 i) {
+    const u32 a = (4u * i) % 3u;                            // which word of its slot the vector's first 32-bit word is
+    return make_uint4(a == 2u ? 0u : ~0u, a == 1u ? 0u : ~0u, a == 0u ? 0u : ~0u, a == 2u ? 0u : ~0u);
+}
+GK_D u32 empty_w0_in_vec_of(const CSlot *, u32 i, uint4 v) {
+    const u32 a = (4u * i) % 3u;                            // word j of the vector is a w0 iff (a + j) % 3 == 0
+    u32 n = 0;
+    if (a == 0u) n = (v.x == ~0u) + (v.w == ~0u);
+    else if (a == 1u) n = (v.z == ~0u);
+    else n = (v.y == ~0u);
+    return n;
+}
+
+template <int W> GK_D u32 empty_w0_in_vec_of(const Slot<W> *, u32 i, uint4 v) { return empty_w0_in_vec<W>(i, v); }
 
 // The table is an array of SEGMENTS of 2^seg_bits slots (2048 16-B slots = 32 KiB, or 1024 24-B slots = 24 KiB), and linear probing wraps INSIDE a segment.  A segment is the unit one workgroup can hold
 // in LDS, which is what lets a batch be radix-partitioned by segment and built there with LDS
@@ -244,8 +279,8 @@ template <> struct SegBits<1> { static constexpr u32 value = GK_SEG_BITS1; };
 template <> struct SegBits<2> { static constexpr u32 value = GK_SEG_BITS1 - 1; };
 
 static constexpr u32 MAX_LNB1 = 10;      // up to 1024 L1 buckets
-template <int W> struct Table {
-    Slot<W> *slots;
+template <int W, class S = Slot<W>> struct Table {
+    S *slots;
     u32 nb2;           // fine buckets per L1 bucket
     u32 lnb1;          // log2(L1 buckets), 0..MAX_LNB1
     u32 tagged;        // 1 for k = 64: slot index mod 4 carries the key's last base
@@ -254,15 +289,15 @@ template <int W> struct Table {
     GK_HD u64 nseg() const { return (u64)nb2 << lnb1; }
     GK_HD u64 capacity() const { return nseg() << SegBits<W>::value; }
 };
-template <int W> GK_HD u32 seg_l1(const Table<W> &t, u64 h) { return t.lnb1 ? (u32)(h >> (64 - t.lnb1)) : 0u; }
-template <int W> GK_HD u32 seg_fine(const Table<W> &t, u64 h) {
+template <int W, class S> GK_HD u32 seg_l1(const Table<W, S> &t, u64 h) { return t.lnb1 ? (u32)(h >> (64 - t.lnb1)) : 0u; }
+template <int W, class S> GK_HD u32 seg_fine(const Table<W, S> &t, u64 h) {
     const u32 shift = t.lnb1 > 8 ? 32u - t.lnb1 : 24u;
     return (u32)((((h >> shift) & 0xffffffffULL) * (u64)t.nb2) >> 32);
 }
-template <int W> GK_HD u32 seg_of(const Table<W> &t, u64 h) { return seg_l1(t, h) * t.nb2 + seg_fine(t, h); }
+template <int W, class S> GK_HD u32 seg_of(const Table<W, S> &t, u64 h) { return seg_l1(t, h) * t.nb2 + seg_fine(t, h); }
 template <int W> GK_HD u32 seg_pos(u64 h) { return (u32)h & ((1u << SegBits<W>::value) - 1u); }
 // where a key's probe starts in its segment
-template <int W> GK_HD u32 home_pos(const Table<W> &, u64 h) { return seg_pos<W>(h); }
+template <int W, class S> GK_HD u32 home_pos(const Table<W, S> &, u64 h) { return seg_pos<W>(h); }
 
 struct Counters {      // device-resident, one per map
     unsigned long long size;        // live keys
@@ -368,13 +403,62 @@ GK_D i64 seg_claim_unique(Slot<2> *seg, u32 pos, Kmer<2> key, u32 tagged = 0u) {
     }
     return -1;
 }
-struct GlobalCas { GK_D u64 operator()(u64 *p, u64 e, u64 v) const { return cas64(p, e, v); } };
+GK_D u32 cas32(u32 *p, u32 expect, u32 val) {
+    __hip_atomic_compare_exchange_strong(p, &expect, val, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return expect;   // old value
+}
+struct GlobalCas {
+    GK_D u64 operator()(u64 *p, u64 e, u64 v) const { return cas64(p, e, v); }
+    GK_D u32 operator()(u32 *p, u32 e, u32 v) const { return cas32(p, e, v); }
+};
+// the two-word protocol of seg_add(Slot<2>) on 31-bit halves
+template <class CAS, class ADD>
+GK_D int seg_add(CSlot *seg, u32 pos, Kmer<1> key, u32 add, CAS cas, ADD addf, u32 = 0u) {
+    constexpr u32 smask = (1u << SegBits<1>::value) - 1u;
+    const u32 k0 = c_w0(key), k1 = c_w1(key);
+    u32 i = pos;
+    for (u32 n = 0; n <= smask; ++n) {
+        CSlot *s = &seg[i];
+        u32 c0 = s->w0;
+        int claimed = 0;
+        if (c0 == KEY_EMPTY32) {
+            c0 = cas(&s->w0, KEY_EMPTY32, k0);
+            if (c0 == KEY_EMPTY32) c0 = k0;
+        }
+        if (c0 == k0) {
+            u32 c1 = s->w1;
+            if (c1 == KEY_EMPTY32) {
+                c1 = cas(&s->w1, KEY_EMPTY32, k1);
+                if (c1 == KEY_EMPTY32) { c1 = k1; claimed = 1; }
+            }
+            if (c1 == k1) {
+                const u32 a = add - (u32)claimed;
+                if (a) addf(&s->extra, a);
+                return claimed;
+            }
+        }
+        i = (i + 1) & smask;
+    }
+    return -1;
+}
+GK_D i64 seg_claim_unique(CSlot *seg, u32 pos, Kmer<1> key, u32 = 0u) {
+    constexpr u32 smask = (1u << SegBits<1>::value) - 1u;
+    const u32 k0 = c_w0(key), k1 = c_w1(key);
+    u32 i = pos;
+    for (u32 n = 0; n <= smask; ++n) {
+        u32 c0 = seg[i].w0;
+        if (c0 == KEY_EMPTY32) { c0 = cas32(&seg[i].w0, KEY_EMPTY32, k0); if (c0 == KEY_EMPTY32) c0 = k0; }
+        if (c0 == k0 && seg[i].w1 == KEY_EMPTY32 && cas32(&seg[i].w1, KEY_EMPTY32, k1) == KEY_EMPTY32) return (i64)i;
+        i = (i + 1) & smask;
+    }
+    return -1;
+}
 struct GlobalAdd { GK_D void operator()(u32 *p, u32 v) const { add32_noret(p, v); } };
 
 // the HBM form: one global CAS per new key, one no-return add per repeat
-template <int W> GK_D int table_add(const Table<W> &t, Kmer<W> key, u32 add, u32 *err) {
+template <int W, class S> GK_D int table_add(const Table<W, S> &t, Kmer<W> key, u32 add, u32 *err) {
     const u64 h = slot_hash(key);
-    Slot<W> *seg = t.slots + ((u64)seg_of(t, h) << SegBits<W>::value);
+    S *seg = t.slots + ((u64)seg_of(t, h) << SegBits<W>::value);
     int r = seg_add(seg, home_pos(t, h), key, add, GlobalCas(), GlobalAdd(), t.tagged);
     if (r < 0) { *err = 1; return 0; }
     return r;
@@ -405,7 +489,19 @@ GK_D i64 seg_find(const Slot<2> *seg, u32 pos, Kmer<2> key, u32 tagged = 0u) {
     }
     return -1;
 }
-template <int W> GK_D i64 table_find(const Table<W> &t, Kmer<W> key) {
+GK_D i64 seg_find(const CSlot *seg, u32 pos, Kmer<1> key, u32 = 0u) {
+    constexpr u32 smask = (1u << SegBits<1>::value) - 1u;
+    const u32 k0 = c_w0(key), k1 = c_w1(key);
+    u32 i = pos;
+    for (u32 n = 0; n <= smask; ++n) {
+        const u32 c0 = seg[i].w0;
+        if (c0 == k0 && seg[i].w1 == k1) return (i64)i;
+        if (c0 == KEY_EMPTY32) return -1;
+        i = (i + 1) & smask;
+    }
+    return -1;
+}
+template <int W, class S> GK_D i64 table_find(const Table<W, S> &t, Kmer<W> key) {
     const u64 h = slot_hash(key);
     const u64 base = (u64)seg_of(t, h) << SegBits<W>::value;
     i64 r = seg_find(t.slots + base, home_pos(t, h), key, t.tagged);
@@ -414,6 +510,9 @@ template <int W> GK_D i64 table_find(const Table<W> &t, Kmer<W> key) {
 template <int W> GK_D bool slot_live(const Slot<W> *s) { return s->w0 != KEY_EMPTY && s->w0 != KEY_TOMB; }
 template <int W> GK_D u32 slot_count(const Slot<W> *s) { return s->extra + 1u; }
 // the key held by slot i of a table (i = global slot index; segments are multiples of 4 slots)
+// ... with the tag (a k = 64 key's last base) given explicitly: for a RANGE of slots whose first index the caller knows
+template <int W> GK_D Kmer<W> slot_key_tag(const Slot<W> *slots, u64 i, u32 tag) { return from_stored(load_stored(&slots[i]), tag); }
+GK_D Kmer<1> slot_key_tag(const CSlot *slots, u64 i, u32) { return slot_key(slots, i); }
 template <int W> GK_D Kmer<W> slot_key(const Slot<W> *slots, u64 i, u32 tagged) {
     return from_stored(load_stored(&slots[i]), tagged ? (u32)(i & 3u) : 0u);
 }

@@ -1788,6 +1788,9 @@ int gk_graph_build(gk_map *m, gk_graph **out) {
     *out = nullptr;
     GK_HIP(m->ctx, hipSetDevice(m->ctx->device));
     if (int rc = map_materialize(m)) return rc;
+    // The graph phase annotates every k-mer in its slot: a COUNT table of 8-byte keys (12-byte slots, no annotation word) is
+    // rebuilt into the graph layout first — what deleteAll(v < rounds) does anyway on the reference's path (GraphBuilder.scala:30-36).
+    if (int rc = map_to_graph_layout(m)) return rc;
     gk_graph *g = new gk_graph();
     g->ctx = m->ctx;
     g->k = m->k;

@@ -115,7 +115,8 @@ struct gk_map {
     int W = 1;                   // 64-bit words per key
     uint64_t capacity = 0;       // slots = nseg * 2^seg_bits
     uint32_t nb2 = 1, lnb1 = 0;  // segment geometry (gk::Table)
-    void *slots = nullptr;       // Slot<W>[capacity]
+    void *slots = nullptr;       // CSlot / Slot<1> / Slot<2> [capacity], by W and `layout`
+    int layout = 0;              // gk::LAYOUT_COUNT or gk::LAYOUT_GRAPH (always GRAPH-shaped Slot<2> for W = 2: the field then only says what the table is FOR)
     gk::Counters *d_ctr = nullptr;
     // pinned host landing area of the small device->host reads a batch ends with: [Counters][PartStatus] (a copy into
     // pageable memory is staged and synchronous: five of them cost 0.12 ms of a 2.1 ms step)
@@ -178,7 +179,12 @@ int hip_fail(const gk_ctx *ctx, hipError_t e, const char *what);
 
 inline bool k_supported(int k) { return (k >= 2 && k <= 31) || (k >= 34 && k <= 64); }
 inline int words_for_k(int k) { return k <= 32 ? 1 : 2; }
-inline size_t slot_bytes(int W) { return W == 1 ? 16 : 24; }      // sizeof(gk::Slot<W>)
+inline size_t slot_bytes(int W) { return W == 1 ? 16 : 24; }      // sizeof(gk::Slot<W>): value maps, and k-mer tables in the GRAPH layout
+// A k-mer table with 8-byte keys comes in two layouts (gk_device.h): COUNT = 12-byte CSlot (key + count: what counting streams),
+// GRAPH = 16-byte Slot<1> (+ the graph phase's annotation word: what deleteAll, the gather and gk_map_create_for_graph leave).
+// 16-byte keys have one layout (24-byte Slot<2>).
+enum { LAYOUT_COUNT = 0, LAYOUT_GRAPH = 1 };
+inline size_t slot_bytes(int W, int layout) { return W == 2 ? 24 : (layout == LAYOUT_GRAPH ? 16 : 12); }
 inline uint32_t seg_bits_for(int W) { return W == 1 ? gk::SegBits<1>::value : gk::SegBits<2>::value; }
 // segment geometry for at least `want_slots` slots: nb1 = 2^lnb1 L1 buckets x nb2 fine buckets.  256 L1 buckets at most
 // — unless that would take more fine buckets per L1 bucket than the partitioned insert pipeline handles (PLAN_MAX_NB2):
@@ -205,6 +211,15 @@ inline uint64_t pow2ceil(uint64_t v) {
     return p;
 }
 
+inline size_t map_slot_bytes(const gk_map *m) { return slot_bytes(m->W, m->layout); }
+// run BODY with `W` (constexpr int) and `S` (the slot type) bound to what the map's table is made of
+#define GK_BY_SLOT(m_, ...)                                                                              \
+    do {                                                                                                 \
+        if ((m_)->W == 2) { constexpr int W = 2; using S = gk::Slot<2>; (void)W; __VA_ARGS__; }          \
+        else if ((m_)->layout == gk::LAYOUT_GRAPH) { constexpr int W = 1; using S = gk::Slot<1>; (void)W; __VA_ARGS__; } \
+        else { constexpr int W = 1; using S = gk::CSlot; (void)W; __VA_ARGS__; }                         \
+    } while (0)
+
 // table ops used across translation units
 int map_reserve(gk_map *m, uint64_t extra_keys);     // grow so that size+extra stays under the load limit
 int map_sync_counters(gk_map *m);                    // refresh m->size, detect device-side error flag
@@ -213,6 +228,7 @@ int map_add_keys_direct(gk_map *m, const uint64_t *d_keys, uint64_t n);   // k_a
 int map_insert_keys_dev(gk_map *m, const uint64_t *d_keys, uint64_t n, bool verbatim);
 int map_add_counted_keys_dev(gk_map *m, const uint64_t *d_keys, const int32_t *d_counts, uint64_t n);   // update(key, c, _ + c), canonical device keys   // update(key, 1, _+1) for device keys, either path
 int map_export_range_dev(gk_map *m, uint64_t s0, uint64_t s1, uint64_t *d_keys, int32_t *d_cnt, unsigned long long *d_cursor, uint64_t *n_out);
+int map_to_graph_layout(gk_map *m);                  // 8-byte keys in 12-byte count slots -> 16-byte graph slots (streaming rebuild); no-op otherwise
 int map_create_for_graph(gk_ctx *ctx, int k, uint64_t keys, gk_map **out);      // a new map sized the way the graph phase wants it
 void *map_scratch(gk_map *m, size_t bytes);          // pooled scratch (grown, never shrunk); nullptr + error set on failure
 // partitioned path (part_count may return PART_RETRY_DIRECT: take the direct path for this batch)

@@ -905,6 +905,7 @@ struct LdsCas {
     __device__ __forceinline__ u64 operator()(u64 *p, u64 e, u64 v) const {
         return atomicCAS(reinterpret_cast<unsigned long long *>(p), (unsigned long long)e, (unsigned long long)v);
     }
+    __device__ __forceinline__ u32 operator()(u32 *p, u32 e, u32 v) const { return atomicCAS(p, e, v); }
 };
 struct LdsAdd {
     __device__ __forceinline__ void operator()(u32 *p, u32 v) const { atomicAdd(p, v); }
@@ -984,6 +985,44 @@ __device__ __forceinline__ int lds_add_look(Slot<2> *seg, u32 pos, Kmer<2> key) 
     return -1;
 }
 
+// the 12-byte count slot (8-byte keys as two 31-bit halves, gk_device.h): the two-word protocol with 32-bit ds_cmpst
+__device__ __forceinline__ u32 lds_add_unbounded(CSlot *seg, u32 pos, Kmer<1> key) {
+    constexpr u32 smask = (1u << SegBits<1>::value) - 1u;
+    const u32 k0 = c_w0(key), k1 = c_w1(key);
+    u32 i = pos;
+    for (;;) {
+        const u32 c0 = atomicCAS(&seg[i].w0, KEY_EMPTY32, k0);
+        if (c0 == KEY_EMPTY32 || c0 == k0) {
+            const u32 c1 = atomicCAS(&seg[i].w1, KEY_EMPTY32, k1);
+            if (c1 == KEY_EMPTY32) return 1u;
+            if (c1 == k1) { atomicAdd(&seg[i].extra, 1u); return 0u; }
+        }
+        i = (i + 1) & smask;
+    }
+}
+__device__ __forceinline__ int lds_add_look(CSlot *seg, u32 pos, Kmer<1> key) {
+    constexpr u32 smask = (1u << SegBits<1>::value) - 1u;
+    const u32 k0 = c_w0(key), k1 = c_w1(key);
+    u32 i = pos;
+    for (u32 n = 0; n <= smask; ++n) {
+        u32 c0 = seg[i].w0;
+        if (c0 == KEY_EMPTY32) {
+            c0 = atomicCAS(&seg[i].w0, KEY_EMPTY32, k0);
+            if (c0 == KEY_EMPTY32) c0 = k0;
+        }
+        if (c0 == k0) {
+            u32 c1 = seg[i].w1;
+            if (c1 == KEY_EMPTY32) {
+                c1 = atomicCAS(&seg[i].w1, KEY_EMPTY32, k1);
+                if (c1 == KEY_EMPTY32) return 1;
+            }
+            if (c1 == k1) { atomicAdd(&seg[i].extra, 1u); return 0; }
+        }
+        i = (i + 1) & smask;
+    }
+    return -1;
+}
+
 #ifndef GK_P5_GRID_PER_CU
 #define GK_P5_GRID_PER_CU 24          // workgroups of k_seg_insert's persistent grid per CU (four are resident)
 #endif
@@ -991,15 +1030,15 @@ __device__ __forceinline__ int lds_add_look(Slot<2> *seg, u32 pos, Kmer<2> key) 
 #define GK_SBLOCK (GK_SEG_BITS1 <= 10 ? 256 : 512)
 #endif
 static constexpr int SBLOCK = GK_SBLOCK;               // threads per segment workgroup
-template <int W>
-__global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W> t, const u64 *__restrict__ keys, PartArrays a, int from_empty, Counters *ctr,
+template <int W, class ST>
+__global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W, ST> t, const u64 *__restrict__ keys, PartArrays a, int from_empty, Counters *ctr,
                                                           u64 seg_lo, u64 seg_hi /* this launch's segments: [seg_lo, seg_hi) */) {
     extern __shared__ uint4 lds_raw[];
     constexpr u32 S = 1u << SegBits<W>::value;
-    constexpr u32 NVEC = S * sizeof(Slot<W>) / 16;
+    constexpr u32 NVEC = S * sizeof(ST) / 16;
     constexpr int KPT = (int)(S / SBLOCK);                          // keys preloaded per thread
     constexpr u32 KBLK = (u32)SBLOCK * KPT;                         // keys per register block (= S)
-    Slot<W> *seg = reinterpret_cast<Slot<W> *>(lds_raw);
+    ST *seg = reinterpret_cast<ST *>(lds_raw);
     u32 *flags = reinterpret_cast<u32 *>(lds_raw + NVEC);         // [0] claims, [1] overflow, [2] free slots found while loading
     const u64 nseg = min(seg_hi, t.nseg());
     u32 wg_claims = 0;      // thread 0 only: ONE global atomic per workgroup at the end (a same-address
@@ -1035,21 +1074,21 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W> t, const u64 
         if (cnt == 0) {
             if (from_empty) {       // materialise the pending clear of a segment that gets no key
 #pragma unroll
-                for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) gseg[i] = empty_vec<W>(i);
+                for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) gseg[i] = empty_vec_of(seg, i);
             }
         } else {
             __syncthreads();
             if (threadIdx.x < 3) flags[threadIdx.x] = 0;
             if (from_empty) {
 #pragma unroll
-                for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) lds_raw[i] = empty_vec<W>(i);
+                for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) lds_raw[i] = empty_vec_of(seg, i);
             } else {
                 u32 nfree = 0;                                  // a slot is free iff its first key word is EMPTY
 #pragma unroll
                 for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) {
                     const uint4 v = gseg[i];
                     lds_raw[i] = v;
-                    nfree += empty_w0_in_vec<W>(i, v);
+                    nfree += empty_w0_in_vec_of(seg, i, v);
                 }
                 __syncthreads();                                // flags[2] = 0 is visible
                 for (int d = 32; d; d >>= 1) nfree += __shfl_down(nfree, d);
@@ -1092,7 +1131,7 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W> t, const u64 
                 // segment full: leave the HBM copy as it was (or EMPTY) and hand the bucket to the host,
                 // which grows the table and replays these keys through the direct path
                 if (from_empty)
-                    for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) gseg[i] = empty_vec<W>(i);
+                    for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) gseg[i] = empty_vec_of(seg, i);
                 if (threadIdx.x == 0) a.failed[atomicAdd(a.n_failed, 1u)] = (u32)s;
             } else {
 #pragma unroll
@@ -1280,7 +1319,9 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
     if (int rc = part_prepare_l1(m, ps, nkeys_bound, op1, &a)) return rc;
     const u32 nb1 = 1u << m->lnb1;
     const int cu8 = ctx->cu_count * 8;
-    const size_t lds = ((size_t)1 << SegBits<W>::value) * sizeof(Slot<W>) + 16;
+    // P5 holds one segment in LDS in the table's own slot type: 12-byte count slots (8-byte keys in a count table), else Slot<W>
+    const bool cslots = W == 1 && m->layout == LAYOUT_COUNT;
+    const size_t lds = ((size_t)1 << SegBits<W>::value) * slot_bytes(W, m->layout) + 16;
     if (!ps->lds_attr_set) {
         const int narrow_max = (int)std::min(ScatterLds<W>::bytes(MAX_NB2) + part_tables_bytes(MAXB1), LDS_BYTES_PER_CU);
         GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<W, false, PBLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, narrow_max));
@@ -1298,7 +1339,11 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
         }
         GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter1_keys<W>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)ScatterLds<W>::bytes(MAXB1)));
-        GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_seg_insert<W>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_seg_insert<W, Slot<W>>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(((size_t)1 << SegBits<W>::value) * sizeof(Slot<W>) + 16)));
+        if constexpr (W == 1)
+            GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_seg_insert<1, CSlot>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)(((size_t)1 << SegBits<1>::value) * sizeof(CSlot) + 16)));
         ps->lds_attr_set = true;
     }
     if (plan.estimate) { if (int rc = map_ensure_sample(m)) return rc; }
@@ -1618,7 +1663,14 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
     }
     auto launch_p5 = [&](hipStream_t st, u64 seg_lo, u64 seg_hi) {
         const int gseg = (int)std::min<u64>(seg_hi - seg_lo, (u64)ctx->cu_count * GK_P5_GRID_PER_CU);
-        hipLaunchKernelGGL(k_seg_insert<W>, dim3(gseg), dim3(SBLOCK), lds, st, t, fine_keys, a, from_empty ? 1 : 0, m->d_ctr, seg_lo, seg_hi);
+        if constexpr (W == 1) {
+            if (cslots) {
+                hipLaunchKernelGGL((k_seg_insert<1, CSlot>), dim3(gseg), dim3(SBLOCK), lds, st, Table<1, CSlot>{reinterpret_cast<CSlot *>(m->slots), t.nb2, t.lnb1, 0u, 0u}, fine_keys, a,
+                                   from_empty ? 1 : 0, m->d_ctr, seg_lo, seg_hi);
+                return;
+            }
+        }
+        hipLaunchKernelGGL((k_seg_insert<W, Slot<W>>), dim3(gseg), dim3(SBLOCK), lds, st, t, fine_keys, a, from_empty ? 1 : 0, m->d_ctr, seg_lo, seg_hi);
     };
     // Stripes (over-provisioned fine level): P4 is bound by its LDS sort and leaves half the memory system idle, P5 streams
     // the table and leaves the ALUs idle.  With the L1 buckets cut into stripes, P5 of stripe i runs on the second stream

@@ -70,8 +70,8 @@ __global__ __launch_bounds__(BLOCK) void k_shard_scatter(const uint8_t *__restri
 
 // how many live keys of a partition's table belong to ANOTHER owner under gk_owner_of (must be 0: PartitionedDNAMap.partition,
 // PartitionedDNAMap.scala:60-63, names exactly one partition per key)
-template <int W>
-__global__ __launch_bounds__(BLOCK) void k_count_foreign(Table<W> t, int k, int P, int p, unsigned long long *out) {
+template <int W, class S>
+__global__ __launch_bounds__(BLOCK) void k_count_foreign(Table<W, S> t, int k, int P, int p, unsigned long long *out) {
     unsigned long long bad = 0;
     const u64 ncap = t.capacity();
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < ncap; i += (u64)gridDim.x * BLOCK)
@@ -143,11 +143,8 @@ int gk_map_count_foreign(gk_map *m, int P, int p, uint64_t *foreign) {
     if (!d) return GK_E_CAPACITY;
     GK_HIP(ctx, hipMemsetAsync(d, 0, 8, ctx->stream));
     const int grid = (int)std::min<u64>(std::max<u64>((m->capacity + BLOCK - 1) / BLOCK, 1), (u64)ctx->cu_count * 8);
-    if (m->W == 1)
-        hipLaunchKernelGGL(k_count_foreign<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, Table<1>{(Slot<1> *)m->slots, m->nb2, m->lnb1, 0u}, m->k, P, p, d);
-    else
-        hipLaunchKernelGGL(k_count_foreign<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream,
-                           Table<2>{(Slot<2> *)m->slots, m->nb2, m->lnb1, m->k == 64 ? 1u : 0u}, m->k, P, p, d);
+    GK_BY_SLOT(m, hipLaunchKernelGGL((k_count_foreign<W, S>), dim3(grid), dim3(BLOCK), 0, ctx->stream,
+                                     Table<W, S>{(S *)m->slots, m->nb2, m->lnb1, m->k == 64 ? 1u : 0u}, m->k, P, p, d));
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));

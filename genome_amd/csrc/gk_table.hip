@@ -47,16 +47,11 @@ int hip_fail(const gk_ctx *ctx, hipError_t e, const char *what) {
 // ============================================================================================
 // kernels
 // ============================================================================================
-template <int W> __global__ __launch_bounds__(BLOCK) void k_clear(Slot<W> *slots, u64 n) {
-    u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x;
-    u64 stride = (u64)gridDim.x * BLOCK;
-    for (; i < n; i += stride) {
-        if constexpr (W == 1) {
-            slots[i] = Slot<1>{KEY_EMPTY, 0u, 0u};
-        } else {
-            slots[i] = Slot<2>{KEY_EMPTY, KEY_EMPTY, 0u, 0u};
-        }
-    }
+// every slot EMPTY, written as 16-byte vectors (n slots of any of the three slot types are a whole number of vectors per segment)
+template <class S> __global__ __launch_bounds__(BLOCK) void k_clear(S *slots, u64 n) {
+    uint4 *v = reinterpret_cast<uint4 *>(slots);
+    const u64 nvec = n * sizeof(S) / 16;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < nvec; i += (u64)gridDim.x * BLOCK) v[i] = empty_vec_of(slots, (u32)(i % 3072u));
 }
 
 // FreqFilter.add (FreqFilter.scala:28-36) for a stream of `.bin` records: one workgroup stages a
@@ -64,10 +59,10 @@ template <int W> __global__ __launch_bounds__(BLOCK) void k_clear(Slot<W> *slots
 // extract -> reverse complement -> hash rule -> insert-or-increment in the HBM table.
 //   offsets == nullptr : fixed stride records (record r at r*stride)
 //   offsets != nullptr : offsets[r] = byte offset of record r, offsets[nreads] = end
-template <int W>
+template <int W, class S>
 __global__ __launch_bounds__(BLOCK) void k_count_reads(const uint8_t *__restrict__ rec, u64 nreads,
                                                        const u32 *__restrict__ offsets, u32 stride, int k, int group, int max_len,
-                                                       Table<W> t, Counters *ctr) {
+                                                       Table<W, S> t, Counters *ctr) {
     __shared__ __attribute__((aligned(16))) u32 tile[TILE_WORDS];
     __shared__ u32 s_claimed, s_occ;
     if (threadIdx.x == 0) { s_claimed = 0; s_occ = 0; }
@@ -99,9 +94,9 @@ __global__ __launch_bounds__(BLOCK) void k_count_reads(const uint8_t *__restrict
 
 // DNAMap.update(key, c, _ + c) for keys already canonical and routed (owner-side insert of the
 // PartitionedDNAMap exchange; also partition merge).  keys: W words per key, interleaved.
-template <int W>
+template <int W, class S>
 __global__ __launch_bounds__(BLOCK) void k_add_keys(const u64 *__restrict__ keys, const i32 *__restrict__ counts,
-                                                    u64 n, Table<W> t, Counters *ctr, int check_canon_k /* 0: trusted keys */) {
+                                                    u64 n, Table<W, S> t, Counters *ctr, int check_canon_k /* 0: trusted keys */) {
     __shared__ u32 s_claimed;
     if (threadIdx.x == 0) s_claimed = 0;
     __syncthreads();
@@ -120,15 +115,15 @@ __global__ __launch_bounds__(BLOCK) void k_add_keys(const u64 *__restrict__ keys
 }
 
 // ArrayDNAMap.rescale (ArrayDNAMap.scala:217-230): move every live (key, count) into a new table.
-template <int W>
-__global__ __launch_bounds__(BLOCK) void k_rehash(const Slot<W> *__restrict__ old, u64 ncap, Table<W> t, Counters *ctr) {   // old and new share t.tagged
+template <int W, class SO, class SN>
+__global__ __launch_bounds__(BLOCK) void k_rehash(const SO *__restrict__ old, u64 ncap, Table<W, SN> t, Counters *ctr) {   // old and new share t.tagged
     u32 err = 0;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < ncap; i += (u64)gridDim.x * BLOCK) {
         if (!slot_live(&old[i])) continue;
         Kmer<W> key = slot_key(old, i, t.tagged);
         // every key of the old table is unique: one CAS claims its new slot, the count goes in with a plain store
         const u64 h = slot_hash(key);
-        Slot<W> *seg = t.slots + ((u64)seg_of(t, h) << SegBits<W>::value);
+        SN *seg = t.slots + ((u64)seg_of(t, h) << SegBits<W>::value);
         const i64 at = seg_claim_unique(seg, home_pos(t, h), key, t.tagged);
         if (at < 0) { err = 1; continue; }
         seg[at].extra = old[i].extra;
@@ -137,15 +132,15 @@ __global__ __launch_bounds__(BLOCK) void k_rehash(const Slot<W> *__restrict__ ol
 }
 
 // Container.deleteAll((k, v) => v < rounds) (ArrayDNAMap.scala:164-173): full scan, tombstone.
-template <int W>
-__global__ __launch_bounds__(BLOCK) void k_filter_lt(Slot<W> *slots, u64 ncap, i32 rounds, unsigned long long *removed) {
+template <class S>
+__global__ __launch_bounds__(BLOCK) void k_filter_lt(S *slots, u64 ncap, i32 rounds, unsigned long long *removed) {
     __shared__ u32 s_rm;
     if (threadIdx.x == 0) s_rm = 0;
     __syncthreads();
     u32 rm = 0;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < ncap; i += (u64)gridDim.x * BLOCK) {
         if (slot_live(&slots[i]) && (i32)slot_count(&slots[i]) < rounds) {
-            slots[i].w0 = KEY_TOMB;
+            slot_tomb(&slots[i]);
             rm++;
         }
     }
@@ -161,29 +156,60 @@ __global__ __launch_bounds__(BLOCK) void k_filter_lt(Slot<W> *slots, u64 ncap, i
 // writes it out whole: no tombstone writes, no clear of the new table, no random access to HBM.
 static constexpr int CBLOCK = 512;
 // live slots with count >= rounds in every `every`-th segment (sizes the new table; exact sizes come from k_compact_seg)
-template <int W>
-__global__ __launch_bounds__(BLOCK) void k_count_ge_sample(const Slot<W> *slots, u64 nseg, u32 every, i32 rounds, unsigned long long *out) {
+template <int W, class S>
+__global__ __launch_bounds__(BLOCK) void k_count_ge_sample(const S *slots, u64 nseg, u32 every, i32 rounds, unsigned long long *out) {
     __shared__ u32 s_n;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    constexpr u32 S = 1u << SegBits<W>::value;
+    constexpr u32 NS = 1u << SegBits<W>::value;
     u32 n = 0;
     for (u64 s = (u64)blockIdx.x * every; s < nseg; s += (u64)gridDim.x * every)
-        for (u32 i = threadIdx.x; i < S; i += BLOCK) {
-            const Slot<W> *p = &slots[(s << SegBits<W>::value) + i];
+        for (u32 i = threadIdx.x; i < NS; i += BLOCK) {
+            const S *p = &slots[(s << SegBits<W>::value) + i];
             if (slot_live(p) && (i32)slot_count(p) >= rounds) n++;
         }
     if (n) atomicAdd(&s_n, n);
     __syncthreads();
     if (threadIdx.x == 0 && s_n) atomicAdd(out, (unsigned long long)s_n);
 }
-template <int W>
-__global__ __launch_bounds__(CBLOCK) void k_compact_seg(Table<W> old, Table<W> nw, i32 rounds, Counters *ctr, unsigned long long *kept_total) {
+// claim a slot of a segment held in LDS for a key known to be absent (every key of the source table is unique): the slot's index,
+// or -1 if the segment is full.  Same slot protocols as gk_device.h, with the LDS forms of the atomics.
+__device__ __forceinline__ i64 lds_claim_unique(Slot<1> *seg, u32 pos, Kmer<1> key) {
+    constexpr u32 smask = (1u << SegBits<1>::value) - 1u;
+    u32 p = pos;
+    for (u32 n = 0; n <= smask; n++, p = (p + 1) & smask)
+        if (atomicCAS(reinterpret_cast<unsigned long long *>(&seg[p].w0), (unsigned long long)KEY_EMPTY, (unsigned long long)key.lo) == KEY_EMPTY) return (i64)p;
+    return -1;
+}
+__device__ __forceinline__ i64 lds_claim_unique(Slot<2> *seg, u32 pos, Kmer<2> key) {
+    constexpr u32 smask = (1u << SegBits<2>::value) - 1u;
+    const Stored<2> k = to_stored(key);
+    u32 p = pos;
+    for (u32 n = 0; n <= smask; n++, p = (p + 1) & smask) {
+        // (keys are unique: a slot whose w0 we claim — or that holds an equal w0 — is ours only if its w1 is free)
+        const unsigned long long c0 = atomicCAS(reinterpret_cast<unsigned long long *>(&seg[p].w0), (unsigned long long)KEY_EMPTY, (unsigned long long)k.w0);
+        if ((c0 == KEY_EMPTY || c0 == k.w0) &&
+            atomicCAS(reinterpret_cast<unsigned long long *>(&seg[p].w1), (unsigned long long)KEY_EMPTY, (unsigned long long)k.w1) == KEY_EMPTY) return (i64)p;
+    }
+    return -1;
+}
+__device__ __forceinline__ i64 lds_claim_unique(CSlot *seg, u32 pos, Kmer<1> key) {
+    constexpr u32 smask = (1u << SegBits<1>::value) - 1u;
+    const u32 k0 = c_w0(key), k1 = c_w1(key);
+    u32 p = pos;
+    for (u32 n = 0; n <= smask; n++, p = (p + 1) & smask) {
+        const u32 c0 = atomicCAS(&seg[p].w0, KEY_EMPTY32, k0);
+        if ((c0 == KEY_EMPTY32 || c0 == k0) && atomicCAS(&seg[p].w1, KEY_EMPTY32, k1) == KEY_EMPTY32) return (i64)p;
+    }
+    return -1;
+}
+// SO / SN: slot types of the old and the new table (a count table of 12-byte slots becomes a graph table of 16-byte slots here)
+template <int W, class SO, class SN>
+__global__ __launch_bounds__(CBLOCK) void k_compact_seg(Table<W, SO> old, Table<W, SN> nw, i32 rounds, Counters *ctr, unsigned long long *kept_total) {
     extern __shared__ uint4 cseg_raw[];
     constexpr u32 S = 1u << SegBits<W>::value;
-    constexpr u32 NVEC = S * sizeof(Slot<W>) / 16;
-    constexpr u32 smask = S - 1u;
-    Slot<W> *seg = reinterpret_cast<Slot<W> *>(cseg_raw);
+    constexpr u32 NVEC = S * sizeof(SN) / 16;
+    SN *seg = reinterpret_cast<SN *>(cseg_raw);
     __shared__ u32 s_kept, s_err;
     u32 wg_kept = 0;
     const u64 nseg_new = nw.nseg();
@@ -191,7 +217,7 @@ __global__ __launch_bounds__(CBLOCK) void k_compact_seg(Table<W> old, Table<W> n
         const u32 b1 = (u32)(sn / nw.nb2), fn = (u32)(sn % nw.nb2);
         __syncthreads();
         if (threadIdx.x == 0) { s_kept = 0; s_err = 0; }
-        for (u32 i = threadIdx.x; i < NVEC; i += CBLOCK) cseg_raw[i] = empty_vec<W>(i);
+        for (u32 i = threadIdx.x; i < NVEC; i += CBLOCK) cseg_raw[i] = empty_vec_of(seg, i);
         // the 32 hash bits x with seg_fine(nw, .) == fn: [xlo, xhi); the old fine buckets they fall into: f0 .. f1
         const u64 xlo = (((u64)fn << 32) + nw.nb2 - 1) / nw.nb2, xhi = ((((u64)fn + 1) << 32) + nw.nb2 - 1) / nw.nb2;
         const u32 f0 = (u32)((xlo * old.nb2) >> 32), f1 = (u32)(((xhi - 1) * old.nb2) >> 32);
@@ -199,33 +225,15 @@ __global__ __launch_bounds__(CBLOCK) void k_compact_seg(Table<W> old, Table<W> n
         u32 kept = 0;
         bool err = false;
         for (u32 f = f0; f <= f1; f++) {
-            const Slot<W> *src = old.slots + (((u64)b1 * old.nb2 + f) << SegBits<W>::value);
+            const SO *src = old.slots + (((u64)b1 * old.nb2 + f) << SegBits<W>::value);
             for (u32 i = threadIdx.x; i < S; i += CBLOCK) {
-                const Slot<W> sl = src[i];
-                if (sl.w0 == KEY_EMPTY || sl.w0 == KEY_TOMB || (i32)(sl.extra + 1u) < rounds) continue;
+                if (!slot_live(&src[i]) || (i32)slot_count(&src[i]) < rounds) continue;
                 const Kmer<W> key = slot_key(src, i, 0u);
                 const u64 h = slot_hash(key);
                 if (seg_fine(nw, h) != fn) continue;
-                u32 p = home_pos(nw, h);
-                bool placed = false;
-                for (u32 n = 0; n <= smask && !placed; n++, p = (p + 1) & smask) {
-                    if constexpr (W == 1) {
-                        if (atomicCAS(reinterpret_cast<unsigned long long *>(&seg[p].w0), (unsigned long long)KEY_EMPTY, (unsigned long long)sl.w0) == KEY_EMPTY) {
-                            seg[p].extra = sl.extra;
-                            placed = true;
-                        }
-                    } else {
-                        // (keys are unique: a slot whose w0 we claim — or that holds an equal w0 — is ours only if its w1 is free)
-                        unsigned long long c0 = atomicCAS(reinterpret_cast<unsigned long long *>(&seg[p].w0), (unsigned long long)KEY_EMPTY, (unsigned long long)sl.w0);
-                        if (c0 == KEY_EMPTY || c0 == sl.w0) {
-                            if (atomicCAS(reinterpret_cast<unsigned long long *>(&seg[p].w1), (unsigned long long)KEY_EMPTY, (unsigned long long)sl.w1) == KEY_EMPTY) {
-                                seg[p].extra = sl.extra;
-                                placed = true;
-                            }
-                        }
-                    }
-                }
-                if (placed) kept++; else err = true;
+                const i64 at = lds_claim_unique(seg, home_pos(nw, h), key);
+                if (at >= 0) { seg[at].extra = src[i].extra; kept++; }
+                else err = true;
             }
         }
         if (kept) atomicAdd(&s_kept, kept);
@@ -239,9 +247,9 @@ __global__ __launch_bounds__(CBLOCK) void k_compact_seg(Table<W> old, Table<W> n
 }
 
 // Container.apply (ArrayDNAMap.scala:90-101) for a batch of keys.
-template <int W>
+template <int W, class S>
 __global__ __launch_bounds__(BLOCK) void k_get(const u64 *__restrict__ lo, const u64 *__restrict__ hi, u64 n,
-                                               Table<W> t, i32 *counts, uint8_t *found) {
+                                               Table<W, S> t, i32 *counts, uint8_t *found) {
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
         Kmer<W> key;
         if constexpr (W == 1) key = Kmer<1>{lo[i]};
@@ -254,8 +262,8 @@ __global__ __launch_bounds__(BLOCK) void k_get(const u64 *__restrict__ lo, const
 
 // Self-check of the table's invariants (what `size` and the slot protocol promise): every live key is found again at
 // its own slot (a key stored twice, or in a segment its hash does not name, is not), counts add up.
-template <int W>
-__global__ __launch_bounds__(BLOCK) void k_verify(Table<W> t, unsigned long long *out /* live, duplicates or misplaced, sum of counts, checksum */) {
+template <int W, class S>
+__global__ __launch_bounds__(BLOCK) void k_verify(Table<W, S> t, unsigned long long *out /* live, duplicates or misplaced, sum of counts, checksum */) {
     unsigned long long live = 0, bad = 0, sum = 0, chk = 0;
     const u64 ncap = t.capacity();
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < ncap; i += (u64)gridDim.x * BLOCK) {
@@ -302,8 +310,8 @@ __device__ __forceinline__ u32 block_scan_flag(bool flag, u32 *total, u32 *lds4)
 
 // Container.iterator (ArrayDNAMap.scala:175-178): compact every live (key, count) to dense arrays.
 // One atomic per 256-slot group reserves the output range; order within a group is slot order.
-template <int W>
-__global__ __launch_bounds__(BLOCK) void k_export(const Slot<W> *__restrict__ slots, u64 ncap, u32 tagged, u64 *lo, u64 *hi, i32 *cnt,
+template <int W, class S>
+__global__ __launch_bounds__(BLOCK) void k_export(const S *__restrict__ slots, u64 ncap, u32 tagged, u64 *lo, u64 *hi, i32 *cnt,
                                                   unsigned long long *cursor) {
     __shared__ u32 lds4[BLOCK / 64];
     __shared__ unsigned long long s_base;
@@ -329,8 +337,8 @@ __global__ __launch_bounds__(BLOCK) void k_export(const Slot<W> *__restrict__ sl
 
 // live (key, count) of a RANGE of slots, packed: keys interleaved W words each (what k_add_keys takes), counts apart.
 // `first` = index of slots[0] in its table (a multiple of the segment size: a tagged slot's last base is its index mod 4).
-template <int W>
-__global__ __launch_bounds__(BLOCK) void k_export_packed(const Slot<W> *__restrict__ slots, u64 n, u64 first, u32 tagged, u64 *keys, i32 *cnt,
+template <int W, class S>
+__global__ __launch_bounds__(BLOCK) void k_export_packed(const S *__restrict__ slots, u64 n, u64 first, u32 tagged, u64 *keys, i32 *cnt,
                                                          unsigned long long *cursor) {
     __shared__ unsigned long long s_base;
     __shared__ u32 wsum[BLOCK / 64];
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(BLOCK) void k_export_packed(const Slot<W> *__restri
         if (threadIdx.x == 0 && tot) s_base = atomicAdd(cursor, (unsigned long long)tot);
         __syncthreads();
         if (live) {
-            const Kmer<W> key = from_stored(load_stored(&slots[i]), tagged ? (u32)((first + i) & 3u) : 0u);
+            const Kmer<W> key = slot_key_tag(slots, i, tagged ? (u32)((first + i) & 3u) : 0u);
             const u64 o = s_base + base + wprefix;
             if constexpr (W == 1) keys[o] = key.lo;
             else { keys[2 * o] = key.lo; keys[2 * o + 1] = key.hi; }
@@ -368,18 +376,38 @@ static inline int grid_for(const gk_ctx *ctx, u64 work_items, int per_block) {
     return (int)std::min(blocks, cap);
 }
 
-template <int W> static Table<W> table_of(const gk_map *m) {
-    return Table<W>{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u, 0u};
+template <int W, class S = Slot<W>> static Table<W, S> table_of(const gk_map *m) {
+    return Table<W, S>{reinterpret_cast<S *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u, 0u};
 }
 
-static int streaming_rebuild(gk_map *m, uint32_t nnb2, uint32_t nlnb1, uint64_t ncap, int32_t rounds, bool *done);     // (defined next to its kernel's host code)
-static int alloc_table(gk_ctx *ctx, int W, uint64_t cap, void **out) {
-    GK_HIP(ctx, hipMalloc(out, cap * slot_bytes(W)));
-    int grid = grid_for(ctx, cap, BLOCK * 4);
-    if (W == 1) hipLaunchKernelGGL(k_clear<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (Slot<1> *)*out, cap);
-    else hipLaunchKernelGGL(k_clear<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (Slot<2> *)*out, cap);
+static int streaming_rebuild(gk_map *m, uint32_t nnb2, uint32_t nlnb1, uint64_t ncap, int32_t rounds, int new_layout, bool *done);     // (defined next to its kernel's host code)
+static void launch_clear(gk_ctx *ctx, int W, int layout, void *slots, uint64_t cap) {
+    const int grid = grid_for(ctx, cap, BLOCK * 4);
+    if (W == 2) hipLaunchKernelGGL(k_clear<Slot<2>>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (Slot<2> *)slots, cap);
+    else if (layout == LAYOUT_GRAPH) hipLaunchKernelGGL(k_clear<Slot<1>>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (Slot<1> *)slots, cap);
+    else hipLaunchKernelGGL(k_clear<CSlot>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (CSlot *)slots, cap);
+}
+static int alloc_table(gk_ctx *ctx, int W, int layout, uint64_t cap, void **out) {
+    GK_HIP(ctx, hipMalloc(out, cap * slot_bytes(W, layout)));
+    launch_clear(ctx, W, layout, *out, cap);
     GK_HIP(ctx, hipGetLastError());
     return GK_OK;
+}
+// move every live (key, count) of `old` (layout lo) into the table `nslots` (geometry nnb2 / nlnb1, layout ln) with k_rehash
+static void launch_rehash(gk_map *m, int ln, void *nslots, uint32_t nnb2, uint32_t nlnb1) {
+    gk_ctx *ctx = m->ctx;
+    const int grid = grid_for(ctx, m->capacity, BLOCK);
+    const u32 tagged = m->k == 64 ? 1u : 0u;
+    if (m->W == 2)
+        hipLaunchKernelGGL((k_rehash<2, Slot<2>, Slot<2>>), dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots, m->capacity, Table<2>{(Slot<2> *)nslots, nnb2, nlnb1, tagged, 0u}, m->d_ctr);
+    else if (m->layout == LAYOUT_GRAPH && ln == LAYOUT_GRAPH)
+        hipLaunchKernelGGL((k_rehash<1, Slot<1>, Slot<1>>), dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, m->capacity, Table<1>{(Slot<1> *)nslots, nnb2, nlnb1, 0u, 0u}, m->d_ctr);
+    else if (m->layout == LAYOUT_GRAPH)
+        hipLaunchKernelGGL((k_rehash<1, Slot<1>, CSlot>), dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, m->capacity, Table<1, CSlot>{(CSlot *)nslots, nnb2, nlnb1, 0u, 0u}, m->d_ctr);
+    else if (ln == LAYOUT_GRAPH)
+        hipLaunchKernelGGL((k_rehash<1, CSlot, Slot<1>>), dim3(grid), dim3(BLOCK), 0, ctx->stream, (const CSlot *)m->slots, m->capacity, Table<1>{(Slot<1> *)nslots, nnb2, nlnb1, 0u, 0u}, m->d_ctr);
+    else
+        hipLaunchKernelGGL((k_rehash<1, CSlot, CSlot>), dim3(grid), dim3(BLOCK), 0, ctx->stream, (const CSlot *)m->slots, m->capacity, Table<1, CSlot>{(CSlot *)nslots, nnb2, nlnb1, 0u, 0u}, m->d_ctr);
 }
 
 namespace gk {
@@ -520,23 +548,17 @@ static int map_grow_to(gk_map *m, uint64_t want_slots, bool rehash, bool keep_ln
     if (rehash && m->k != 64 && nlnb1 == m->lnb1 && ctx->hook_filter_classic <= 0) {
         // same L1 fan-out: the keys move between neighbouring segments only — one streaming pass instead of a CAS per key
         bool done = false;
-        if (int rc = ::streaming_rebuild(m, nnb2, nlnb1, ncap, INT32_MIN, &done)) return rc;
+        if (int rc = ::streaming_rebuild(m, nnb2, nlnb1, ncap, INT32_MIN, m->layout, &done)) return rc;
         if (done) { m->grows++; return GK_OK; }
     }
     void *nslots = nullptr;
     if (!rehash) {
-        hipError_t e = hipMalloc(&nslots, ncap * slot_bytes(m->W));
+        hipError_t e = hipMalloc(&nslots, ncap * map_slot_bytes(m));
         if (e != hipSuccess) { (void)hipGetLastError(); return fail(ctx, GK_E_CAPACITY, "cannot grow table to " + std::to_string(ncap) + " slots: " + hipGetErrorString(e)); }
     } else {
-        int rc = alloc_table(ctx, m->W, ncap, &nslots);
+        int rc = alloc_table(ctx, m->W, m->layout, ncap, &nslots);
         if (rc) { if (nslots) (void)hipFree(nslots); return fail(ctx, GK_E_CAPACITY, "cannot grow table to " + std::to_string(ncap) + " slots: " + ctx->err); }
-        int grid = grid_for(ctx, m->capacity, BLOCK);
-        if (m->W == 1)
-            hipLaunchKernelGGL(k_rehash<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, m->capacity,
-                               Table<1>{(Slot<1> *)nslots, nnb2, nlnb1, 0u, 0u}, m->d_ctr);
-        else
-            hipLaunchKernelGGL(k_rehash<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots, m->capacity,
-                               Table<2>{(Slot<2> *)nslots, nnb2, nlnb1, m->k == 64 ? 1u : 0u, 0u}, m->d_ctr);
+        launch_rehash(m, m->layout, nslots, nnb2, nlnb1);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { (void)hipFree(nslots); return hip_fail(ctx, e, "table rehash"); }
@@ -585,9 +607,7 @@ int map_ensure_sample(gk_map *m) {
 int map_materialize(gk_map *m) {
     if (!m->pending_clear) return GK_OK;
     gk_ctx *ctx = m->ctx;
-    int grid = grid_for(ctx, m->capacity, BLOCK * 4);
-    if (m->W == 1) hipLaunchKernelGGL(k_clear<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (Slot<1> *)m->slots, m->capacity);
-    else hipLaunchKernelGGL(k_clear<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (Slot<2> *)m->slots, m->capacity);
+    launch_clear(ctx, m->W, m->layout, m->slots, m->capacity);
     GK_HIP(ctx, hipGetLastError());
     m->pending_clear = false;
     return GK_OK;
@@ -841,7 +861,8 @@ int gk_map_create(gk_ctx *ctx, int k, uint64_t capacity_hint, gk_map **out) {
     // saved, and its first batch takes the pipeline instead of paying the table in and out); anything else materialises it.
     int rc = GK_OK;
     {
-        hipError_t ea = hipMalloc(&m->slots, m->capacity * slot_bytes(m->W));
+        m->layout = LAYOUT_COUNT;        // (8-byte keys: 12-byte count slots; the graph phase's 16-byte layout is what deleteAll / the gather build)
+        hipError_t ea = hipMalloc(&m->slots, m->capacity * map_slot_bytes(m));
         if (ea != hipSuccess) rc = hip_fail(ctx, ea, "gk_map_create: table");
         m->pending_clear = true;
     }
@@ -909,6 +930,7 @@ int gk_map_clear(gk_map *m) {
     m->sample_dirty = false;
     m->est_distinct_last = 0;
     m->pending_clear = true;
+    m->layout = LAYOUT_COUNT;    // (the contents are void: the same allocation is read as 12-byte count slots from here on — same slot count, fewer bytes)
     m->size = 0;
     m->tombstones = 0;
     m->total_occurrences = 0;
@@ -939,12 +961,8 @@ static int launch_count(gk_map *m, const ReadSrc &src) {
     int grid = (int)std::min<u64>(std::max<u64>(ntiles, 1), (u64)ctx->cu_count * 8);
     if (int rc = stage_source(ctx, src)) return rc;
     GK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    if (m->W == 1)
-        hipLaunchKernelGGL(k_count_reads<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, src.rec, src.nreads, src.off, src.stride, m->k, src.group,
-                           src.max_len, table_of<1>(m), m->d_ctr);
-    else
-        hipLaunchKernelGGL(k_count_reads<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, src.rec, src.nreads, src.off, src.stride, m->k, src.group,
-                           src.max_len, table_of<2>(m), m->d_ctr);
+    GK_BY_SLOT(m, hipLaunchKernelGGL((k_count_reads<W, S>), dim3(grid), dim3(BLOCK), 0, ctx->stream, src.rec, src.nreads, src.off, src.stride, m->k, src.group,
+                                     src.max_len, table_of<W, S>(m), m->d_ctr));
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     if (int rc = map_sync_counters(m)) return rc;
@@ -959,6 +977,7 @@ static int launch_count(gk_map *m, const ReadSrc &src) {
 // bytes of `.bin` records one staging area holds at most: what one partitioned batch of 2^31 windows takes (150 bp reads, k = 31:
 // 17.9 M records of 39 bytes) — a host-fed count then cuts its stream where the device-resident one cuts its batches
 static constexpr size_t GK_MAX_STAGE_DEFAULT = 704u << 20;
+static constexpr size_t GK_FIRST_STAGE = 128u << 20;
 static inline size_t max_stage(const gk_ctx *ctx) { return ctx->hook_max_stage > 0 ? (size_t)ctx->hook_max_stage : GK_MAX_STAGE_DEFAULT; }
 static int reset_occ_counter(gk_map *m) {
     GK_HIP(m->ctx, hipMemsetAsync(&m->d_ctr->occurrences, 0, sizeof(unsigned long long), m->ctx->stream));
@@ -1036,7 +1055,7 @@ static bool use_partitioned(const gk_map *m, u64 occ) {
     if (m->insert_path == 2) return true;
     if (m->skewed) return false;          // this map's data has already defeated even the L1 regions once (one k-mer, millions of times)
     const PathCost &COST = path_cost(m->ctx);
-    const double tb = (double)m->capacity * (double)slot_bytes(m->W);
+    const double tb = (double)m->capacity * (double)map_slot_bytes(m);
     const double pass_us = tb / (COST.stream_tbps * 1e6);
     const double us_direct = (double)occ * COST.direct_ps * 1e-6 + (m->pending_clear ? pass_us : 0.0);
     const double per_key = (COST.p2_ps + COST.p4_ps + COST.p4_ps_per_nb2 * m->nb2 + COST.p5_ps + (m->repeats || !m->pending_clear ? COST.p3_ps : 0.0)) * m->W;
@@ -1346,7 +1365,10 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
             const size_t rb0 = 1 + (size_t)(len0 + 3) / 4;
             const u64 nk0 = len0 >= m->k ? (u64)(len0 - m->k + 1) : 0;
             u64 cap = std::min<u64>(nreads - r, (nbytes - pos) / rb0);
-            cap = std::min<u64>(cap, std::max<u64>(1, max_stage(ctx) / rb0));
+            // (the FIRST chunk of a long stream is short: its upload cannot hide behind anything — the L1 scatter runs at PCIe pace for
+            //  it — so it is kept to 128 MiB; from the second chunk on the upload runs beside the previous chunk's fine level)
+            const size_t stage_cap = pos == 0 && ctx->hook_max_stage <= 0 && nbytes > (size_t)4 * GK_FIRST_STAGE ? GK_FIRST_STAGE : max_stage(ctx);
+            cap = std::min<u64>(cap, std::max<u64>(1, stage_cap / rb0));
             if (nk0) cap = std::min<u64>(cap, std::max<u64>(1, occ_limit / nk0));
             const uint8_t *p0 = bin + pos;
             u64 run = 0;
@@ -1443,7 +1465,8 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
             src.off = (const u32 *)m->d_offsets;
             src.max_len = 255;             // the host has walked this framing: every length byte is what the offsets say
         }
-        const int brc = insert_batch(m, src, nullptr, 0, cur.occ);
+        // (grow_ahead: what the call still holds beyond this chunk, so that a table that has to grow leaves room for it)
+        const int brc = insert_batch(m, src, nullptr, 0, cur.occ, false, (double)(nreads - cur.r_begin) / (double)std::max<u64>(cur.reads, 1));
         if (brc == GK_OK) { if (int rc = map_fire_prefetch(m, nullptr)) return rc; }      // (still armed: the path that ran had no L1 scatter to gate it on)
         if (brc == PART_NOT_UNIFORM) {       // take the chunk again, this time walking its framing
             GK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));     // (a prefetch of the chunk after it may be in flight: it is simply dropped)
@@ -1470,12 +1493,8 @@ static int add_keys_dev(gk_map *m, const u64 *d_keys, const i32 *d_counts, u64 n
         u64 chunk = std::min(n - done, reads_per_launch(m, 1));
         if (int rc = map_reserve(m, chunk)) return rc;
         int grid = grid_for(ctx, chunk, BLOCK);
-        if (m->W == 1)
-            hipLaunchKernelGGL(k_add_keys<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_keys + done,
-                               d_counts ? d_counts + done : nullptr, chunk, table_of<1>(m), m->d_ctr, verbatim ? m->k : 0);
-        else
-            hipLaunchKernelGGL(k_add_keys<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_keys + 2 * done,
-                               d_counts ? d_counts + done : nullptr, chunk, table_of<2>(m), m->d_ctr, verbatim ? m->k : 0);
+        GK_BY_SLOT(m, hipLaunchKernelGGL((k_add_keys<W, S>), dim3(grid), dim3(BLOCK), 0, ctx->stream, d_keys + W * done,
+                                         d_counts ? d_counts + done : nullptr, chunk, table_of<W, S>(m), m->d_ctr, verbatim ? m->k : 0));
         GK_HIP(ctx, hipGetLastError());
         if (int rc = map_sync_counters(m)) return rc;
         done += chunk;
@@ -1499,10 +1518,8 @@ int map_export_range_dev(gk_map *m, uint64_t s0, uint64_t s1, uint64_t *d_keys, 
     if (int rc = map_materialize(m)) return rc;
     GK_HIP(ctx, hipMemsetAsync(d_cursor, 0, 8, ctx->stream));
     const int grid = grid_for(ctx, s1 - s0, BLOCK);
-    if (m->W == 1)
-        hipLaunchKernelGGL(k_export_packed<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots + s0, s1 - s0, s0, 0u, d_keys, d_cnt, d_cursor);
-    else
-        hipLaunchKernelGGL(k_export_packed<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots + s0, s1 - s0, s0, m->k == 64 ? 1u : 0u, d_keys, d_cnt, d_cursor);
+    GK_BY_SLOT(m, hipLaunchKernelGGL((k_export_packed<W, S>), dim3(grid), dim3(BLOCK), 0, ctx->stream, (const S *)m->slots + s0, s1 - s0, s0, m->k == 64 ? 1u : 0u, d_keys,
+                                     d_cnt, d_cursor));
     GK_HIP(ctx, hipGetLastError());
     unsigned long long n = 0;
     GK_HIP(ctx, hipMemcpyAsync(&n, d_cursor, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1516,7 +1533,16 @@ int map_create_for_graph(gk_ctx *ctx, int k, uint64_t keys, gk_map **out) {
     // gk_map_create sizes for its own target load: hand it the key count that gives the wanted number of slots
     gk_map probe; probe.k = k;
     const uint64_t hint = (uint64_t)((double)std::max<uint64_t>(keys, 1) / load * target_load(&probe)) + 1;
-    return gk_map_create(ctx, k, hint, out);
+    if (int rc = gk_map_create(ctx, k, hint, out)) return rc;
+    gk_map *m = *out;
+    if (m->W == 1) {            // the graph layout (16-byte slots with the annotation word): the table was allocated for 12-byte slots
+        GK_HIP(ctx, hipFree(m->slots));
+        m->slots = nullptr;
+        m->layout = LAYOUT_GRAPH;
+        hipError_t e = hipMalloc(&m->slots, m->capacity * map_slot_bytes(m));
+        if (e != hipSuccess) { const int rc = hip_fail(ctx, e, "gk_map_create_for_graph: table"); gk_map_destroy(m); *out = nullptr; return rc == GK_E_HIP ? fail(ctx, GK_E_CAPACITY, "cannot allocate table: " + ctx->err) : rc; }
+    }
+    return GK_OK;
 }
 }
 extern "C" {
@@ -1646,14 +1672,8 @@ static int map_compact(gk_map *m) {
     plan_segments(m->W, (uint64_t)((double)m->size / graph_load) + 1, &nnb2, &nlnb1, &ncap, (uint32_t)ctx->hook_min_lnb1);
     if (ncap > m->capacity) { nnb2 = m->nb2; nlnb1 = m->lnb1; ncap = m->capacity; }
     void *nslots = nullptr;
-    if (alloc_table(ctx, m->W, ncap, &nslots) != GK_OK) { if (nslots) (void)hipFree(nslots); return GK_OK; }   // keep tombstones if memory is short
-    int g2 = grid_for(ctx, m->capacity, BLOCK);
-    if (m->W == 1)
-        hipLaunchKernelGGL(k_rehash<1>, dim3(g2), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, m->capacity,
-                           Table<1>{(Slot<1> *)nslots, nnb2, nlnb1, 0u, 0u}, m->d_ctr);
-    else
-        hipLaunchKernelGGL(k_rehash<2>, dim3(g2), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots, m->capacity,
-                           Table<2>{(Slot<2> *)nslots, nnb2, nlnb1, m->k == 64 ? 1u : 0u, 0u}, m->d_ctr);
+    if (alloc_table(ctx, m->W, LAYOUT_GRAPH, ncap, &nslots) != GK_OK) { if (nslots) (void)hipFree(nslots); return GK_OK; }   // keep tombstones if memory is short
+    launch_rehash(m, LAYOUT_GRAPH, nslots, nnb2, nlnb1);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { (void)hipFree(nslots); return hip_fail(ctx, e, "table compaction"); }
@@ -1664,29 +1684,38 @@ static int map_compact(gk_map *m) {
     m->nb2 = nnb2;
     m->lnb1 = nlnb1;
     m->tombstones = 0;
+    m->layout = LAYOUT_GRAPH;
     return GK_OK;
 }
 
 // Move the live keys with count >= rounds into a new table of geometry (nnb2, nlnb1 == m->lnb1) with k_compact_seg and install
 // it; the old table stays (and *done stays false) if the new one cannot be allocated.  Not for k = 64.
-static int streaming_rebuild(gk_map *m, uint32_t nnb2, uint32_t nlnb1, uint64_t ncap, int32_t rounds, bool *done) {
+}  // extern "C"
+template <int W, class SO, class SN>
+static hipError_t launch_compact(gk_map *m, void *nslots, uint32_t nnb2, uint32_t nlnb1, int32_t rounds, int gc) {
+    gk_ctx *ctx = m->ctx;
+    const size_t lds = sizeof(SN) << SegBits<W>::value;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_compact_seg<W, SO, SN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) hipLaunchKernelGGL((k_compact_seg<W, SO, SN>), dim3(gc), dim3(CBLOCK), lds, ctx->stream, table_of<W, SO>(m), Table<W, SN>{(SN *)nslots, nnb2, nlnb1, 0u}, rounds,
+                                            m->d_ctr, &m->d_ctr->rebuild_kept);
+    return e;
+}
+extern "C" {
+static int streaming_rebuild(gk_map *m, uint32_t nnb2, uint32_t nlnb1, uint64_t ncap, int32_t rounds, int new_layout, bool *done) {
     gk_ctx *ctx = m->ctx;
     // (the counter lives in the map's Counters block, not in the pooled scratch: a caller further up — gk_map_add_counts through
     //  map_reserve — may be holding its keys there)
     unsigned long long h_kept = 0;
     GK_HIP(ctx, hipMemsetAsync(&m->d_ctr->rebuild_kept, 0, 8, ctx->stream));
     void *nslots = nullptr;
-    if (hipMalloc(&nslots, ncap * slot_bytes(m->W)) != hipSuccess) { (void)hipGetLastError(); return GK_OK; }    // (every slot is written below: no clear)
-    const size_t lds = (size_t)slot_bytes(m->W) << seg_bits_for(m->W);
+    if (hipMalloc(&nslots, ncap * slot_bytes(m->W, new_layout)) != hipSuccess) { (void)hipGetLastError(); return GK_OK; }    // (every slot is written below: no clear)
     const int gc = (int)std::min<u64>((u64)nnb2 << nlnb1, (u64)ctx->cu_count * 16);
     hipError_t e = hipSuccess;
-    if (m->W == 1) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_compact_seg<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) hipLaunchKernelGGL(k_compact_seg<1>, dim3(gc), dim3(CBLOCK), lds, ctx->stream, table_of<1>(m), Table<1>{(Slot<1> *)nslots, nnb2, nlnb1, 0u}, rounds, m->d_ctr, &m->d_ctr->rebuild_kept);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_compact_seg<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) hipLaunchKernelGGL(k_compact_seg<2>, dim3(gc), dim3(CBLOCK), lds, ctx->stream, table_of<2>(m), Table<2>{(Slot<2> *)nslots, nnb2, nlnb1, 0u}, rounds, m->d_ctr, &m->d_ctr->rebuild_kept);
-    }
+    if (m->W == 2) e = launch_compact<2, Slot<2>, Slot<2>>(m, nslots, nnb2, nlnb1, rounds, gc);
+    else if (m->layout == LAYOUT_GRAPH && new_layout == LAYOUT_GRAPH) e = launch_compact<1, Slot<1>, Slot<1>>(m, nslots, nnb2, nlnb1, rounds, gc);
+    else if (m->layout == LAYOUT_GRAPH) e = launch_compact<1, Slot<1>, CSlot>(m, nslots, nnb2, nlnb1, rounds, gc);
+    else if (new_layout == LAYOUT_GRAPH) e = launch_compact<1, CSlot, Slot<1>>(m, nslots, nnb2, nlnb1, rounds, gc);
+    else e = launch_compact<1, CSlot, CSlot>(m, nslots, nnb2, nlnb1, rounds, gc);
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(&h_kept, &m->d_ctr->rebuild_kept, 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1706,6 +1735,7 @@ static int streaming_rebuild(gk_map *m, uint32_t nnb2, uint32_t nlnb1, uint64_t 
     m->lnb1 = nlnb1;
     m->tombstones = 0;
     m->size = kept;
+    m->layout = new_layout;
     *done = true;
     return GK_OK;
 }
@@ -1724,8 +1754,7 @@ static int filter_compact_streaming(gk_map *m, int32_t rounds, bool *done) {
     // 1. survivors, estimated from every 16th segment (the hash spreads keys evenly: +-1 % at any size that matters)
     const u32 every = nseg >= 4096 ? 16u : 1u;
     const int gs = (int)std::min<u64>((nseg + every - 1) / every, (u64)ctx->cu_count * 8);
-    if (m->W == 1) hipLaunchKernelGGL(k_count_ge_sample<1>, dim3(gs), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, nseg, every, rounds, d2);
-    else hipLaunchKernelGGL(k_count_ge_sample<2>, dim3(gs), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots, nseg, every, rounds, d2);
+    GK_BY_SLOT(m, hipLaunchKernelGGL((k_count_ge_sample<W, S>), dim3(gs), dim3(BLOCK), 0, ctx->stream, (const S *)m->slots, nseg, every, rounds, d2));
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipMemcpyAsync(h2, d2, 8, hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1737,7 +1766,7 @@ static int filter_compact_streaming(gk_map *m, int32_t rounds, bool *done) {
     plan_segments(m->W, (uint64_t)((double)est / graph_load) + 1, &nnb2, &nlnb1, &ncap, (uint32_t)ctx->hook_min_lnb1);
     if (ncap > m->capacity) { nnb2 = m->nb2; nlnb1 = m->lnb1; ncap = m->capacity; }
     if (nlnb1 != m->lnb1) return GK_OK;                    // the L1 bucket of a key would change: not a segment-local move
-    return streaming_rebuild(m, nnb2, nlnb1, ncap, rounds, done);
+    return streaming_rebuild(m, nnb2, nlnb1, ncap, rounds, LAYOUT_GRAPH, done);
 }
 
 int gk_map_filter_lt(gk_map *m, int32_t rounds) {
@@ -1752,8 +1781,7 @@ int gk_map_filter_lt(gk_map *m, int32_t rounds) {
     if (!d_removed) return GK_E_CAPACITY;
     GK_HIP(ctx, hipMemsetAsync(d_removed, 0, sizeof(unsigned long long), ctx->stream));
     int grid = grid_for(ctx, m->capacity, BLOCK * 4);
-    if (m->W == 1) hipLaunchKernelGGL(k_filter_lt<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (Slot<1> *)m->slots, m->capacity, rounds, d_removed);
-    else hipLaunchKernelGGL(k_filter_lt<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (Slot<2> *)m->slots, m->capacity, rounds, d_removed);
+    GK_BY_SLOT(m, hipLaunchKernelGGL(k_filter_lt<S>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (S *)m->slots, m->capacity, rounds, d_removed));
     GK_HIP(ctx, hipGetLastError());
     unsigned long long removed = 0;
     GK_HIP(ctx, hipMemcpyAsync(&removed, d_removed, sizeof(removed), hipMemcpyDeviceToHost, ctx->stream));
@@ -1767,6 +1795,39 @@ int gk_map_filter_lt(gk_map *m, int32_t rounds) {
     // phase probes a clean, cache-friendlier table.
     return m->tombstones ? map_compact(m) : GK_OK;
 }
+
+}  // extern "C"
+namespace gk {
+int map_to_graph_layout(gk_map *m) {
+    if (m->W != 1 || m->layout == LAYOUT_GRAPH) return GK_OK;
+    gk_ctx *ctx = m->ctx;
+    // same geometry when the table is sparse enough for the graph phase already, else sized by graph_table_load; tombstones go either way
+    uint32_t nnb2 = m->nb2, nlnb1 = m->lnb1;
+    uint64_t ncap = m->capacity;
+    const double load = graph_table_load(ctx, m->k, m->size);
+    if ((double)m->size > load * (double)m->capacity) {
+        plan_segments(m->W, (uint64_t)((double)m->size / load) + 1, &nnb2, &nlnb1, &ncap, (uint32_t)ctx->hook_min_lnb1);
+        if (ncap < m->capacity) { nnb2 = m->nb2; nlnb1 = m->lnb1; ncap = m->capacity; }
+    }
+    if (nlnb1 == m->lnb1 && ctx->hook_filter_classic <= 0) {
+        bool done = false;
+        if (int rc = ::streaming_rebuild(m, nnb2, nlnb1, ncap, INT32_MIN, LAYOUT_GRAPH, &done)) return rc;
+        if (done) return GK_OK;
+    }
+    // (another L1 fan-out, or no memory for the streaming form's second table... the rehash form needs one too)
+    void *nslots = nullptr;
+    if (int rc = alloc_table(ctx, m->W, LAYOUT_GRAPH, ncap, &nslots)) { if (nslots) (void)hipFree(nslots); return fail(ctx, GK_E_CAPACITY, "cannot rebuild the table in the graph layout: " + ctx->err); }
+    launch_rehash(m, LAYOUT_GRAPH, nslots, nnb2, nlnb1);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { (void)hipFree(nslots); return hip_fail(ctx, e, "table rebuild (graph layout)"); }
+    if (int rc = map_sync_counters(m)) { (void)hipFree(nslots); return rc; }
+    GK_HIP(ctx, hipFree(m->slots));
+    m->slots = nslots; m->capacity = ncap; m->nb2 = nnb2; m->lnb1 = nlnb1; m->tombstones = 0; m->layout = LAYOUT_GRAPH;
+    return GK_OK;
+}
+}  // namespace gk
+extern "C" {
 
 int gk_map_get_batch(gk_map *m, const uint64_t *lo, const uint64_t *hi, uint64_t n, int32_t *counts_out, uint8_t *found_out) {
     if (int rc = check_map(m)) return rc;
@@ -1783,8 +1844,7 @@ int gk_map_get_batch(gk_map *m, const uint64_t *lo, const uint64_t *hi, uint64_t
     GK_HIP(ctx, hipMemcpyAsync(d_lo, lo, n * 8, hipMemcpyHostToDevice, ctx->stream));
     if (d_hi) GK_HIP(ctx, hipMemcpyAsync(d_hi, hi, n * 8, hipMemcpyHostToDevice, ctx->stream));
     int grid = grid_for(ctx, n, BLOCK);
-    if (m->W == 1) hipLaunchKernelGGL(k_get<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_lo, d_hi, n, table_of<1>(m), d_cnt, d_found);
-    else hipLaunchKernelGGL(k_get<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, d_lo, d_hi, n, table_of<2>(m), d_cnt, d_found);
+    GK_BY_SLOT(m, hipLaunchKernelGGL((k_get<W, S>), dim3(grid), dim3(BLOCK), 0, ctx->stream, d_lo, d_hi, n, table_of<W, S>(m), d_cnt, d_found));
     GK_HIP(ctx, hipGetLastError());
     if (counts_out) GK_HIP(ctx, hipMemcpyAsync(counts_out, d_cnt, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (found_out) GK_HIP(ctx, hipMemcpyAsync(found_out, d_found, n, hipMemcpyDeviceToHost, ctx->stream));
@@ -1808,8 +1868,7 @@ int gk_map_export(gk_map *m, uint64_t *lo, uint64_t *hi, int32_t *counts, uint64
     unsigned long long *d_cursor = (unsigned long long *)(base + 2 * b8 + b4);
     GK_HIP(ctx, hipMemsetAsync(d_cursor, 0, 8, ctx->stream));
     int grid = grid_for(ctx, m->capacity, BLOCK);
-    if (m->W == 1) hipLaunchKernelGGL(k_export<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<1> *)m->slots, m->capacity, 0u, d_lo, d_hi, d_cnt, d_cursor);
-    else hipLaunchKernelGGL(k_export<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, (const Slot<2> *)m->slots, m->capacity, m->k == 64 ? 1u : 0u, d_lo, d_hi, d_cnt, d_cursor);
+    GK_BY_SLOT(m, hipLaunchKernelGGL((k_export<W, S>), dim3(grid), dim3(BLOCK), 0, ctx->stream, (const S *)m->slots, m->capacity, m->k == 64 ? 1u : 0u, d_lo, d_hi, d_cnt, d_cursor));
     GK_HIP(ctx, hipGetLastError());
     unsigned long long written = 0;
     GK_HIP(ctx, hipMemcpyAsync(&written, d_cursor, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1828,8 +1887,7 @@ int gk_map_verify(gk_map *m, uint64_t *live, uint64_t *bad_slots, uint64_t *sum_
     if (!d) return GK_E_CAPACITY;
     GK_HIP(ctx, hipMemsetAsync(d, 0, 32, ctx->stream));
     int grid = grid_for(ctx, m->capacity, BLOCK);
-    if (m->W == 1) hipLaunchKernelGGL(k_verify<1>, dim3(grid), dim3(BLOCK), 0, ctx->stream, table_of<1>(m), d);
-    else hipLaunchKernelGGL(k_verify<2>, dim3(grid), dim3(BLOCK), 0, ctx->stream, table_of<2>(m), d);
+    GK_BY_SLOT(m, hipLaunchKernelGGL((k_verify<W, S>), dim3(grid), dim3(BLOCK), 0, ctx->stream, table_of<W, S>(m), d));
     GK_HIP(ctx, hipGetLastError());
     GK_HIP(ctx, hipMemcpyAsync(h, d, 32, hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1870,7 +1928,7 @@ int gk_map_stats(gk_map *m, char *json, size_t cap) {
                      "\"spilled_keys\":%llu,\"failed_segments\":%llu,\"retries_direct\":%llu,\"est_new_distinct_last_batch\":%llu,"
                      "\"noncanonical_keys\":%s,\"repeat_heavy\":%s,\"last_count_host_gap_ms\":%.4f,\"device\":%d,\"cu_count\":%d,"
                      "\"calib_copy_tbps\":%.4f,\"calib_cas_gps\":%.4f}",
-                     m->k, m->W, slot_bytes(m->W), (unsigned long long)m->capacity, (unsigned long long)m->size,
+                     m->k, m->W, map_slot_bytes(m), (unsigned long long)m->capacity, (unsigned long long)m->size,
                      (unsigned long long)m->tombstones, m->capacity ? (double)m->size / (double)m->capacity : 0.0,
                      (unsigned long long)m->total_occurrences, (unsigned long long)m->grows, m->last_count_ms,
                      (unsigned long long)m->last_count_occ, (unsigned long long)m->part_launches,

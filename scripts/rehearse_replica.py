@@ -54,7 +54,7 @@ def main():
     rep["count_s"] = time.perf_counter() - t0
     rep["windows"], rep["keys"] = occ, dm.size()
     ctx.free(d)
-    local_bytes = dm.local.slots() * (16 if k <= 31 else 24)
+    local_bytes = dm.local.slots() * dm.local.stats()["slot_bytes"]
     ctx.trim()
     base = ctx.mem_stats(reset_peak=True)["live"] - local_bytes
     t0 = time.perf_counter()
@@ -65,7 +65,7 @@ def main():
     assert full.verify_checksum() == dm.local.verify_checksum()
     rep["replica_slots"], rep["replica_load"] = full.slots(), rep["keys"] / full.slots()
     dm.close(); dist.close(); ctx.trim()
-    base = ctx.mem_stats(reset_peak=True)["live"] - full.slots() * (16 if k <= 31 else 24)
+    base = ctx.mem_stats(reset_peak=True)["live"] - full.slots() * full.stats()["slot_bytes"]
     print("gathered", rep, flush=True)
     out = {}
     modes = ((1, "walk"), (2, "pj")) if a.both else ((0, "auto"),)

@@ -281,7 +281,7 @@ def test_c5_one_rank_share_k63_partitioned_prefiltered(ctx):
     _share(ctx, k=63, n=250_000_000, G=387_500_000, e=0.002, cfg=5, chunk=25_000_000, with_plain=False, graph_stage="c5_share_k63")
 
 
-@pytest.mark.parametrize("k,L_,hint", [(31, 150, 1_500_000_000), (55, 150, 960_000_000)])
+@pytest.mark.parametrize("k,L_,hint", [(31, 150, 2_000_000_000), (55, 150, 960_000_000)])
 def test_table_beyond_34_gb_stays_on_the_partitioned_pipeline(ctx, k, L_, hint):
     """C4's and C5's per-rank tables are 50-100 GB.  256 L1 buckets x 4096 fine buckets x 32 KiB end at 34 GB: a table that
     needs more gets 512 or 1024 L1 buckets (plan_segments) and keeps the LDS segment build — which used to hand such tables to
