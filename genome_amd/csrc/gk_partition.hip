@@ -1030,15 +1030,52 @@ __device__ __forceinline__ int lds_add_look(CSlot *seg, u32 pos, Kmer<1> key) {
 #define GK_SBLOCK (GK_SEG_BITS1 <= 10 ? 256 : 512)
 #endif
 static constexpr int SBLOCK = GK_SBLOCK;               // threads per segment workgroup
+// ST = the table's slot type in HBM.  The segment is built in LDS in the type that probes fastest there — LT: for a count table
+// of 8-byte keys (ST = 12-byte CSlot) that is the 16-byte Slot<1> with its ONE 64-bit ds_cmpst per insert, not CSlot's two
+// 32-bit ones (measured: the two-CAS form in LDS cost P5 0.92 ms against 0.82 — more than the quarter fewer bytes gave back;
+// profiles/r03/bench_n1_run08_cslot_two_cas_LOSES.json) — and the HBM image is converted on the way in and out, four slots
+// (three 16-byte vectors) per thread.
+template <class ST> struct LdsSlotOf { typedef ST type; };
+template <> struct LdsSlotOf<CSlot> { typedef Slot<1> type; };
+// four 12-byte count slots (three vectors of the HBM image) <-> four 16-byte LDS slots
+__device__ __forceinline__ void cslots_to_lds(const uint4 *g3, Slot<1> *l4, u32 *nfree) {
+    const uint4 a = g3[0], b = g3[1], c = g3[2];
+    const u32 w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const u32 h0 = w[3 * q], h1 = w[3 * q + 1];
+        const bool special = h0 >= KEY_TOMB32;                  // EMPTY or TOMB: the same sentinel, widened
+        l4[q] = Slot<1>{special ? (h0 == KEY_EMPTY32 ? KEY_EMPTY : KEY_TOMB) : ((u64)h0 | ((u64)h1 << 31)), w[3 * q + 2], 0u};
+        *nfree += h0 == KEY_EMPTY32 ? 1u : 0u;
+    }
+}
+__device__ __forceinline__ void lds_to_cslots(const Slot<1> *l4, uint4 *g3) {
+    u32 w[12];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const u64 key = l4[q].w0;
+        const bool special = key >= KEY_TOMB;
+        w[3 * q] = special ? (key == KEY_EMPTY ? KEY_EMPTY32 : KEY_TOMB32) : (u32)key & 0x7fffffffu;
+        w[3 * q + 1] = special ? KEY_EMPTY32 : (u32)(key >> 31);
+        w[3 * q + 2] = l4[q].extra;
+    }
+    g3[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    g3[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    g3[2] = make_uint4(w[8], w[9], w[10], w[11]);
+}
 template <int W, class ST>
 __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W, ST> t, const u64 *__restrict__ keys, PartArrays a, int from_empty, Counters *ctr,
                                                           u64 seg_lo, u64 seg_hi /* this launch's segments: [seg_lo, seg_hi) */) {
     extern __shared__ uint4 lds_raw[];
+    typedef typename LdsSlotOf<ST>::type LT;
+    constexpr bool CONV = !std::is_same<ST, LT>::value;             // the HBM image is converted, not copied
     constexpr u32 S = 1u << SegBits<W>::value;
-    constexpr u32 NVEC = S * sizeof(ST) / 16;
+    constexpr u32 NVEC = S * sizeof(LT) / 16;                       // vectors of the LDS image
+    constexpr u32 GVEC = S * sizeof(ST) / 16;                       // ... of the HBM image
     constexpr int KPT = (int)(S / SBLOCK);                          // keys preloaded per thread
     constexpr u32 KBLK = (u32)SBLOCK * KPT;                         // keys per register block (= S)
-    ST *seg = reinterpret_cast<ST *>(lds_raw);
+    LT *seg = reinterpret_cast<LT *>(lds_raw);
+    const ST *gtype = nullptr;                                      // (only names the HBM slot type for the clear pattern)
     u32 *flags = reinterpret_cast<u32 *>(lds_raw + NVEC);         // [0] claims, [1] overflow, [2] free slots found while loading
     const u64 nseg = min(seg_hi, t.nseg());
     u32 wg_claims = 0;      // thread 0 only: ONE global atomic per workgroup at the end (a same-address
@@ -1074,7 +1111,7 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W, ST> t, const 
         if (cnt == 0) {
             if (from_empty) {       // materialise the pending clear of a segment that gets no key
 #pragma unroll
-                for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) gseg[i] = empty_vec_of(seg, i);
+                for (u32 i = threadIdx.x; i < GVEC; i += SBLOCK) gseg[i] = empty_vec_of(gtype, i);
             }
         } else {
             __syncthreads();
@@ -1084,11 +1121,15 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W, ST> t, const 
                 for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) lds_raw[i] = empty_vec_of(seg, i);
             } else {
                 u32 nfree = 0;                                  // a slot is free iff its first key word is EMPTY
+                if constexpr (CONV) {
+                    for (u32 g4 = threadIdx.x; g4 < S / 4; g4 += SBLOCK) cslots_to_lds(gseg + 3 * g4, seg + 4 * g4, &nfree);
+                } else {
 #pragma unroll
-                for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) {
-                    const uint4 v = gseg[i];
-                    lds_raw[i] = v;
-                    nfree += empty_w0_in_vec_of(seg, i, v);
+                    for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) {
+                        const uint4 v = gseg[i];
+                        lds_raw[i] = v;
+                        nfree += empty_w0_in_vec_of(seg, i, v);
+                    }
                 }
                 __syncthreads();                                // flags[2] = 0 is visible
                 for (int d = 32; d; d >>= 1) nfree += __shfl_down(nfree, d);
@@ -1131,11 +1172,15 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W, ST> t, const 
                 // segment full: leave the HBM copy as it was (or EMPTY) and hand the bucket to the host,
                 // which grows the table and replays these keys through the direct path
                 if (from_empty)
-                    for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) gseg[i] = empty_vec_of(seg, i);
+                    for (u32 i = threadIdx.x; i < GVEC; i += SBLOCK) gseg[i] = empty_vec_of(gtype, i);
                 if (threadIdx.x == 0) a.failed[atomicAdd(a.n_failed, 1u)] = (u32)s;
             } else {
+                if constexpr (CONV) {
+                    for (u32 g4 = threadIdx.x; g4 < S / 4; g4 += SBLOCK) lds_to_cslots(seg + 4 * g4, gseg + 3 * g4);
+                } else {
 #pragma unroll
-                for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) gseg[i] = lds_raw[i];
+                    for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) gseg[i] = lds_raw[i];
+                }
                 if (threadIdx.x == 0) wg_claims += flags[0];
             }
         }
@@ -1321,7 +1366,7 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
     const int cu8 = ctx->cu_count * 8;
     // P5 holds one segment in LDS in the table's own slot type: 12-byte count slots (8-byte keys in a count table), else Slot<W>
     const bool cslots = W == 1 && m->layout == LAYOUT_COUNT;
-    const size_t lds = ((size_t)1 << SegBits<W>::value) * slot_bytes(W, m->layout) + 16;
+    const size_t lds = ((size_t)1 << SegBits<W>::value) * sizeof(Slot<W>) + 16;        // (the LDS image is Slot<W> for every layout)
     if (!ps->lds_attr_set) {
         const int narrow_max = (int)std::min(ScatterLds<W>::bytes(MAX_NB2) + part_tables_bytes(MAXB1), LDS_BYTES_PER_CU);
         GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_part_scatter2<W, false, PBLOCK>), hipFuncAttributeMaxDynamicSharedMemorySize, narrow_max));
@@ -1343,7 +1388,7 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
                                         (int)(((size_t)1 << SegBits<W>::value) * sizeof(Slot<W>) + 16)));
         if constexpr (W == 1)
             GK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_seg_insert<1, CSlot>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)(((size_t)1 << SegBits<1>::value) * sizeof(CSlot) + 16)));
+                                            (int)(((size_t)1 << SegBits<1>::value) * sizeof(Slot<1>) + 16)));
         ps->lds_attr_set = true;
     }
     if (plan.estimate) { if (int rc = map_ensure_sample(m)) return rc; }

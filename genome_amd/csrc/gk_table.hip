@@ -226,14 +226,34 @@ __global__ __launch_bounds__(CBLOCK) void k_compact_seg(Table<W, SO> old, Table<
         bool err = false;
         for (u32 f = f0; f <= f1; f++) {
             const SO *src = old.slots + (((u64)b1 * old.nb2 + f) << SegBits<W>::value);
-            for (u32 i = threadIdx.x; i < S; i += CBLOCK) {
-                if (!slot_live(&src[i]) || (i32)slot_count(&src[i]) < rounds) continue;
-                const Kmer<W> key = slot_key(src, i, 0u);
-                const u64 h = slot_hash(key);
-                if (seg_fine(nw, h) != fn) continue;
-                const i64 at = lds_claim_unique(seg, home_pos(nw, h), key);
-                if (at >= 0) { seg[at].extra = src[i].extra; kept++; }
-                else err = true;
+            if constexpr (std::is_same<SO, CSlot>::value) {
+                // 12-byte source slots: four of them are three whole 16-byte vectors — read those, not 4-byte fields
+                const uint4 *sv = reinterpret_cast<const uint4 *>(src);
+                for (u32 g4 = threadIdx.x; g4 < S / 4; g4 += CBLOCK) {
+                    const uint4 a = sv[3 * g4], b = sv[3 * g4 + 1], c = sv[3 * g4 + 2];
+                    const u32 w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const u32 h0 = w[3 * q], h1 = w[3 * q + 1], ex = w[3 * q + 2];
+                        if (h0 >= KEY_TOMB32 || (i32)(ex + 1u) < rounds) continue;
+                        const Kmer<W> key = Kmer<1>{(u64)h0 | ((u64)h1 << 31)};
+                        const u64 h = slot_hash(key);
+                        if (seg_fine(nw, h) != fn) continue;
+                        const i64 at = lds_claim_unique(seg, home_pos(nw, h), key);
+                        if (at >= 0) { seg[at].extra = ex; kept++; }
+                        else err = true;
+                    }
+                }
+            } else {
+                for (u32 i = threadIdx.x; i < S; i += CBLOCK) {
+                    if (!slot_live(&src[i]) || (i32)slot_count(&src[i]) < rounds) continue;
+                    const Kmer<W> key = slot_key(src, i, 0u);
+                    const u64 h = slot_hash(key);
+                    if (seg_fine(nw, h) != fn) continue;
+                    const i64 at = lds_claim_unique(seg, home_pos(nw, h), key);
+                    if (at >= 0) { seg[at].extra = src[i].extra; kept++; }
+                    else err = true;
+                }
             }
         }
         if (kept) atomicAdd(&s_kept, kept);
@@ -1816,7 +1836,7 @@ int map_to_graph_layout(gk_map *m) {
     }
     // (another L1 fan-out, or no memory for the streaming form's second table... the rehash form needs one too)
     void *nslots = nullptr;
-    if (int rc = alloc_table(ctx, m->W, LAYOUT_GRAPH, ncap, &nslots)) { if (nslots) (void)hipFree(nslots); return fail(ctx, GK_E_CAPACITY, "cannot rebuild the table in the graph layout: " + ctx->err); }
+    if (alloc_table(ctx, m->W, LAYOUT_GRAPH, ncap, &nslots) != GK_OK) { if (nslots) (void)hipFree(nslots); return fail(ctx, GK_E_CAPACITY, "cannot rebuild the table in the graph layout: " + ctx->err); }
     launch_rehash(m, LAYOUT_GRAPH, nslots, nnb2, nlnb1);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
