@@ -979,18 +979,33 @@ __device__ __forceinline__ u32 cc_root(const u32 *parent, u32 v) {
 __global__ __launch_bounds__(BLOCK) void k_cc_init(GraphView g, u32 *parent) {
     for (u64 n = (u64)blockIdx.x * BLOCK + threadIdx.x; n < g.n_nodes; n += (u64)gridDim.x * BLOCK) parent[n] = (u32)n;
 }
-__global__ __launch_bounds__(BLOCK) void k_cc_hook(GraphView g, u32 *parent, u32 *changed) {
+// One pass over the edges: a lock-free union (the larger root is hooked under the smaller by a CAS on the root's own word; a
+// failed CAS hands back the word's true value and the walk continues from there) with path halving on the way up.  Pointers
+// only ever go to smaller ids, so there are no cycles, a stale read is an older ancestor (a longer walk, never a wrong one),
+// and the root a component ends with is its smallest node id — the label the round-2 form (min-label hooking + full
+// compression, repeated until nothing moved: 5-7 rounds of two kernels and a host round trip each, 7 ms at C3) converged to.
+__device__ __forceinline__ u32 cc_find_halve(u32 *parent, u32 v) {
+    u32 p = parent[v];
+    while (p != v) {
+        const u32 gp = parent[p];
+        if (gp == p) return p;
+        parent[v] = gp;                 // (v is not a root and never becomes one again: no CAS targets this word)
+        v = gp; p = parent[v];
+    }
+    return v;
+}
+__global__ __launch_bounds__(BLOCK) void k_cc_link(GraphView g, u32 *parent) {
     for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < g.n_edges; e += (u64)gridDim.x * BLOCK) {
         if (!g.e_alive[e]) continue;
-        u32 ru = cc_root(parent, g.e_start[e]), rv = cc_root(parent, g.e_end[e]);
-        if (ru == rv) continue;
-        u32 hi = ru > rv ? ru : rv, lo = ru > rv ? rv : ru;
-        atomicMin(&parent[hi], lo);
-        *changed = 1;
+        u32 ru = cc_find_halve(parent, g.e_start[e]), rv = cc_find_halve(parent, g.e_end[e]);
+        while (ru != rv) {
+            if (ru < rv) { const u32 x = ru; ru = rv; rv = x; }
+            const u32 old = atomicCAS(&parent[ru], ru, rv);
+            if (old == ru) break;
+            ru = cc_find_halve(parent, old);
+            rv = cc_find_halve(parent, rv);
+        }
     }
-}
-__global__ __launch_bounds__(BLOCK) void k_cc_compress(GraphView g, u32 *parent) {
-    for (u64 n = (u64)blockIdx.x * BLOCK + threadIdx.x; n < g.n_nodes; n += (u64)gridDim.x * BLOCK) parent[n] = cc_root(parent, (u32)n);
 }
 // Component sizes and summed edge lengths.  A giant component means millions of increments of ONE counter, and same-address
 // atomics retire at ~88 per microsecond chip-wide (143 ms of the 169 ms retain step at C3 in round 1; 7.7-10 ms in round 2
@@ -1018,7 +1033,9 @@ template <class T> struct CcTable {
         for (u32 i = threadIdx.x; i < CC_TAB; i += BLOCK) if (root[i] != NONE && sum[i]) atomicAdd(&global[root[i]], sum[i]);
     }
 };
-__global__ __launch_bounds__(BLOCK) void k_cc_sizes(GraphView g, const u32 *parent, u32 *size, unsigned long long *ncomp) {
+// (also the one compression pass after k_cc_link: every live node's word becomes its root — a walker that passes through a
+// word already compressed lands on the same root)
+__global__ __launch_bounds__(BLOCK) void k_cc_sizes(GraphView g, u32 *parent, u32 *size, unsigned long long *ncomp) {
     __shared__ CcTable<u32> tab;
     __shared__ u32 s_roots;
     if (threadIdx.x == 0) s_roots = 0;
@@ -1029,7 +1046,8 @@ __global__ __launch_bounds__(BLOCK) void k_cc_sizes(GraphView g, const u32 *pare
     for (u64 n0 = (u64)blockIdx.x * BLOCK + (threadIdx.x & ~63u); n0 < g.n_nodes; n0 += (u64)gridDim.x * BLOCK) {   // wave-uniform trip count
         const u64 n = n0 + lane;
         const bool active = n < g.n_nodes && g.node_alive[n];
-        const u32 root = active ? parent[n] : 0xffffffffu;
+        u32 root = 0xffffffffu;
+        if (active) { root = cc_root(parent, (u32)n); parent[n] = root; }
         unsigned long long todo = __ballot(active);
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
@@ -1117,9 +1135,10 @@ __global__ __launch_bounds__(BLOCK) void k_cc_max(GraphView g, const u32 *size, 
 }
 // among the components of maximal size pick the one holding the smallest k-mer: stage 0 min hi,
 // stage 1 min lo among those, stage 2 record its root (one atomic per wave, see k_cc_sizes)
-__global__ __launch_bounds__(BLOCK) void k_cc_pick(GraphView g, const u32 *parent, const u32 *size, u32 best, int stage,
+__global__ __launch_bounds__(BLOCK) void k_cc_pick(GraphView g, const u32 *parent, const u32 *size, const u32 *best_p, int stage,
                                                    unsigned long long *mins /* hi, lo */, u32 *winner) {
     unsigned long long m = ~0ull;
+    const u32 best = *best_p;                       // (k_cc_max's result: stays on the device)
     const unsigned long long min_hi = stage >= 1 ? mins[0] : 0ull, min_lo = stage == 2 ? mins[1] : 0ull;
     for (u64 n = (u64)blockIdx.x * BLOCK + threadIdx.x; n < g.n_nodes; n += (u64)gridDim.x * BLOCK) {
         if (!g.node_alive[n] || size[parent[n]] != best) continue;
@@ -1132,7 +1151,9 @@ __global__ __launch_bounds__(BLOCK) void k_cc_pick(GraphView g, const u32 *paren
         if ((threadIdx.x & 63) == 0 && m != ~0ull) atomicMin(&mins[stage], m);
     }
 }
-__global__ __launch_bounds__(BLOCK) void k_retain(GraphView g, const u32 *parent, u32 winner) {
+__global__ __launch_bounds__(BLOCK) void k_retain(GraphView g, const u32 *parent, const u32 *winner_p) {
+    const u32 winner = *winner_p;
+    if (winner == NONE) return;                     // (nothing selected: the host reports it, the graph stays as it was)
     const u64 tid = (u64)blockIdx.x * BLOCK + threadIdx.x, stride = (u64)gridDim.x * BLOCK;
     for (u64 e = tid; e < g.n_edges; e += stride)
         if (g.e_alive[e] && !(parent[g.e_start[e]] == winner && parent[g.e_end[e]] == winner)) g.e_alive[e] = 0;
@@ -1929,29 +1950,20 @@ int gk_graph_remove_edges(gk_graph *g, const uint64_t *start_lo, const uint64_t 
 static int graph_components(gk_graph *g, u32 **parent_out, u32 **size_out, u64 *ncomp) {
     gk_ctx *ctx = g->ctx;
     GraphView &v = g->v;
-    u32 *parent = nullptr, *size = nullptr, *d_changed = nullptr;
+    u32 *parent = nullptr, *size = nullptr;
     unsigned long long *d_ncomp = nullptr;
     auto bail = [&](int code) {
-        for (void *p : {(void *)parent, (void *)size, (void *)d_changed, (void *)d_ncomp}) if (p) (void)hipFree(p);
+        for (void *p : {(void *)parent, (void *)size, (void *)d_ncomp}) if (p) (void)hipFree(p);
         return code;
     };
     hipError_t e = hipMalloc((void **)&parent, std::max<u64>(v.n_nodes, 1) * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&size, std::max<u64>(v.n_nodes, 1) * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_changed, 4);
     if (e == hipSuccess) e = hipMalloc((void **)&d_ncomp, 8);
     if (e != hipSuccess) return bail(hip_fail(ctx, e, "graph components: alloc"));
     const int gn = ggrid(ctx, std::max<u64>(v.n_nodes, 1)), ge = ggrid(ctx, std::max<u64>(v.n_edges, 1));
     hipLaunchKernelGGL(k_cc_init, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, parent);
-    for (int it = 0; it < 100000; it++) {
-        u32 changed = 0;
-        e = hipMemsetAsync(d_changed, 0, 4, ctx->stream);
-        if (e != hipSuccess) break;
-        hipLaunchKernelGGL(k_cc_hook, dim3(ge), dim3(BLOCK), 0, ctx->stream, v, parent, d_changed);
-        hipLaunchKernelGGL(k_cc_compress, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, parent);
-        e = hipMemcpyAsync(&changed, d_changed, 4, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess || !changed) break;
-    }
+    hipLaunchKernelGGL(k_cc_link, dim3(ge), dim3(BLOCK), 0, ctx->stream, v, parent);
+    e = hipGetLastError();
     if (e != hipSuccess) return bail(hip_fail(ctx, e, "graph components: hooking"));
     unsigned long long h = 0;
     e = hipMemsetAsync(size, 0, std::max<u64>(v.n_nodes, 1) * 4, ctx->stream);
@@ -1963,7 +1975,7 @@ static int graph_components(gk_graph *g, u32 **parent_out, u32 **size_out, u64 *
     if (e == hipSuccess) e = hipMemcpyAsync(&h, d_ncomp, 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return bail(hip_fail(ctx, e, "graph components: sizes"));
-    (void)hipFree(d_changed); (void)hipFree(d_ncomp);
+    (void)hipFree(d_ncomp);
     *parent_out = parent; *size_out = size; *ncomp = h;
     return GK_OK;
 }
@@ -1997,20 +2009,16 @@ int gk_graph_retain_largest(gk_graph *g, uint64_t *kept_nodes, uint64_t *compone
     e = hipMemcpyAsync(d_u64, h64, 24, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_u32, h32, 12, hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_retain_largest"));
+    // max size -> smallest k-mer among the components of that size -> its root -> retain: four dependent steps, no host in between
     hipLaunchKernelGGL(k_cc_max, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, size, &d_u32[1]);
-    e = hipMemcpyAsync(h32, d_u32, 12, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_retain_largest: sizes"));
-    const u32 best = h32[1];
     for (int stage = 0; stage < 3; stage++)
-        hipLaunchKernelGGL(k_cc_pick, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, parent, size, best, stage, &d_u64[1], &d_u32[2]);
-    e = hipMemcpyAsync(h32, d_u32, 12, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_retain_largest: pick"));
-    if (h32[2] == NONE) return done(fail(ctx, GK_E_STATE, "no component selected"));
-    hipLaunchKernelGGL(k_retain, dim3(ggrid(ctx, std::max(v.n_nodes, v.n_edges))), dim3(BLOCK), 0, ctx->stream, v, parent, h32[2]);
+        hipLaunchKernelGGL(k_cc_pick, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, parent, size, &d_u32[1], stage, &d_u64[1], &d_u32[2]);
+    hipLaunchKernelGGL(k_retain, dim3(ggrid(ctx, std::max(v.n_nodes, v.n_edges))), dim3(BLOCK), 0, ctx->stream, v, parent, &d_u32[2]);
     e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h32, d_u32, 12, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_retain_largest: retain"));
+    if (h32[2] == NONE) return done(fail(ctx, GK_E_STATE, "no component selected"));
     if (components) *components = ncomp;
     int rc = graph_refresh_counts(g);
     if (rc == GK_OK && kept_nodes) *kept_nodes = g->live_nodes;

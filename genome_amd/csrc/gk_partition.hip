@@ -1037,31 +1037,38 @@ static constexpr int SBLOCK = GK_SBLOCK;               // threads per segment wo
 // (three 16-byte vectors) per thread.
 template <class ST> struct LdsSlotOf { typedef ST type; };
 template <> struct LdsSlotOf<CSlot> { typedef Slot<1> type; };
-// four 12-byte count slots (three vectors of the HBM image) <-> four 16-byte LDS slots
-__device__ __forceinline__ void cslots_to_lds(const uint4 *g3, Slot<1> *l4, u32 *nfree) {
-    const uint4 a = g3[0], b = g3[1], c = g3[2];
+// The conversion goes through LDS so that every HBM access stays a run of whole 16-byte vectors per wave (a thread reading or
+// writing "its" 48 bytes at a 48-byte stride is not: measured, the write-out then costs partial-line fills — P5 1.14 ms and
+// 0.55 GB of extra fetch; profiles/r03).  In: the 24-KiB image lands at the front of the 32-KiB LDS area, every thread takes
+// its four slots into registers, barrier, writes them back 16 bytes wide.  Out: the reverse.
+__device__ __forceinline__ void cslots_expand_in_lds(uint4 *lds_raw, u32 *nfree) {
+    Slot<1> *seg = reinterpret_cast<Slot<1> *>(lds_raw);
+    const uint4 a = lds_raw[3 * threadIdx.x], b = lds_raw[3 * threadIdx.x + 1], c = lds_raw[3 * threadIdx.x + 2];
+    __syncthreads();
     const u32 w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const u32 h0 = w[3 * q], h1 = w[3 * q + 1];
         const bool special = h0 >= KEY_TOMB32;                  // EMPTY or TOMB: the same sentinel, widened
-        l4[q] = Slot<1>{special ? (h0 == KEY_EMPTY32 ? KEY_EMPTY : KEY_TOMB) : ((u64)h0 | ((u64)h1 << 31)), w[3 * q + 2], 0u};
+        seg[4 * threadIdx.x + q] = Slot<1>{special ? (h0 == KEY_EMPTY32 ? KEY_EMPTY : KEY_TOMB) : ((u64)h0 | ((u64)h1 << 31)), w[3 * q + 2], 0u};
         *nfree += h0 == KEY_EMPTY32 ? 1u : 0u;
     }
 }
-__device__ __forceinline__ void lds_to_cslots(const Slot<1> *l4, uint4 *g3) {
+__device__ __forceinline__ void cslots_pack_in_lds(uint4 *lds_raw) {
+    const Slot<1> *seg = reinterpret_cast<const Slot<1> *>(lds_raw);
     u32 w[12];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const u64 key = l4[q].w0;
-        const bool special = key >= KEY_TOMB;
-        w[3 * q] = special ? (key == KEY_EMPTY ? KEY_EMPTY32 : KEY_TOMB32) : (u32)key & 0x7fffffffu;
-        w[3 * q + 1] = special ? KEY_EMPTY32 : (u32)(key >> 31);
-        w[3 * q + 2] = l4[q].extra;
+        const Slot<1> sl = seg[4 * threadIdx.x + q];
+        const bool special = sl.w0 >= KEY_TOMB;
+        w[3 * q] = special ? (sl.w0 == KEY_EMPTY ? KEY_EMPTY32 : KEY_TOMB32) : (u32)sl.w0 & 0x7fffffffu;
+        w[3 * q + 1] = special ? KEY_EMPTY32 : (u32)(sl.w0 >> 31);
+        w[3 * q + 2] = sl.extra;
     }
-    g3[0] = make_uint4(w[0], w[1], w[2], w[3]);
-    g3[1] = make_uint4(w[4], w[5], w[6], w[7]);
-    g3[2] = make_uint4(w[8], w[9], w[10], w[11]);
+    __syncthreads();
+    lds_raw[3 * threadIdx.x] = make_uint4(w[0], w[1], w[2], w[3]);
+    lds_raw[3 * threadIdx.x + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+    lds_raw[3 * threadIdx.x + 2] = make_uint4(w[8], w[9], w[10], w[11]);
 }
 template <int W, class ST>
 __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W, ST> t, const u64 *__restrict__ keys, PartArrays a, int from_empty, Counters *ctr,
@@ -1122,7 +1129,11 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W, ST> t, const 
             } else {
                 u32 nfree = 0;                                  // a slot is free iff its first key word is EMPTY
                 if constexpr (CONV) {
-                    for (u32 g4 = threadIdx.x; g4 < S / 4; g4 += SBLOCK) cslots_to_lds(gseg + 3 * g4, seg + 4 * g4, &nfree);
+                    static_assert(!CONV || S / 4 == SBLOCK, "one group of four slots per thread");
+#pragma unroll
+                    for (u32 i = threadIdx.x; i < GVEC; i += SBLOCK) lds_raw[i] = gseg[i];
+                    __syncthreads();
+                    cslots_expand_in_lds(lds_raw, &nfree);
                 } else {
 #pragma unroll
                     for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) {
@@ -1176,7 +1187,10 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W, ST> t, const 
                 if (threadIdx.x == 0) a.failed[atomicAdd(a.n_failed, 1u)] = (u32)s;
             } else {
                 if constexpr (CONV) {
-                    for (u32 g4 = threadIdx.x; g4 < S / 4; g4 += SBLOCK) lds_to_cslots(seg + 4 * g4, gseg + 3 * g4);
+                    cslots_pack_in_lds(lds_raw);
+                    __syncthreads();
+#pragma unroll
+                    for (u32 i = threadIdx.x; i < GVEC; i += SBLOCK) gseg[i] = lds_raw[i];
                 } else {
 #pragma unroll
                     for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) gseg[i] = lds_raw[i];
