@@ -1037,38 +1037,39 @@ static constexpr int SBLOCK = GK_SBLOCK;               // threads per segment wo
 // (three 16-byte vectors) per thread.
 template <class ST> struct LdsSlotOf { typedef ST type; };
 template <> struct LdsSlotOf<CSlot> { typedef Slot<1> type; };
-// The conversion goes through LDS so that every HBM access stays a run of whole 16-byte vectors per wave (a thread reading or
-// writing "its" 48 bytes at a 48-byte stride is not: measured, the write-out then costs partial-line fills — P5 1.14 ms and
-// 0.55 GB of extra fetch; profiles/r03).  In: the 24-KiB image lands at the front of the 32-KiB LDS area, every thread takes
-// its four slots into registers, barrier, writes them back 16 bytes wide.  Out: the reverse.
+// Both directions keep every HBM access a run of whole 16-byte vectors per wave and need few registers (the kernel lives at 64
+// VGPRs, 8 waves per SIMD: the first cuts of this conversion — every thread moving "its" four slots as three vectors — spilled
+// 36 bytes per lane, and scratch traffic is HBM traffic: P5 1.11-1.14 ms with 1.5 GB fetched instead of 0.98,
+// profiles/r03/bench_n1_run09_*, pmc_pipeline_r3v4.json).
+//   out: vector v of the packed image holds words 4v .. 4v+3 = fields of slots s0 = v + v/3 and s0 + 1: read those two LDS
+//        slots, pick by v % 3, store — no staging, no barrier;
+//   in:  the 24-KiB image is staged at the END of the 32-KiB area (bytes 8192 ..), then expanded slot by slot in four rounds of
+//        512 slots, ascending: expanded slot s lands on bytes 16s .., which hold raw slots below 4s/3 - 681 only — consumed in an
+//        earlier round or, within the round, before the barrier that separates its reads from its writes.
+__device__ __forceinline__ u32 cfield(const Slot<1> &x, u32 f) {
+    const bool special = x.w0 >= KEY_TOMB;
+    if (f == 0u) return special ? (x.w0 == KEY_EMPTY ? KEY_EMPTY32 : KEY_TOMB32) : (u32)x.w0 & 0x7fffffffu;
+    if (f == 1u) return special ? KEY_EMPTY32 : (u32)(x.w0 >> 31);
+    return x.extra;
+}
+__device__ __forceinline__ uint4 cslot_vec_from_lds(const Slot<1> *seg, u32 v) {
+    const u32 q = v / 3u, r = v - 3u * q, s0 = v + q;
+    const Slot<1> A = seg[s0], B = seg[s0 + 1u];            // (s0 + 1 <= S - 1: the image's last vector has r == 2)
+    const u32 a0 = cfield(A, 0), a1 = cfield(A, 1), a2 = A.extra, b0 = cfield(B, 0), b1 = cfield(B, 1), b2 = B.extra;
+    return r == 0u ? make_uint4(a0, a1, a2, b0) : r == 1u ? make_uint4(a1, a2, b0, b1) : make_uint4(a2, b0, b1, b2);
+}
+template <u32 S_>
 __device__ __forceinline__ void cslots_expand_in_lds(uint4 *lds_raw, u32 *nfree) {
     Slot<1> *seg = reinterpret_cast<Slot<1> *>(lds_raw);
-    const uint4 a = lds_raw[3 * threadIdx.x], b = lds_raw[3 * threadIdx.x + 1], c = lds_raw[3 * threadIdx.x + 2];
-    __syncthreads();
-    const u32 w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const u32 h0 = w[3 * q], h1 = w[3 * q + 1];
+    const u32 *raw = reinterpret_cast<const u32 *>(lds_raw) + (S_ * 4u) / 4u;       // byte S_*4 = 8192 for S_ = 2048
+#pragma unroll 1
+    for (u32 s = threadIdx.x; s < S_; s += SBLOCK) {
+        const u32 h0 = raw[3u * s], h1 = raw[3u * s + 1u], ex = raw[3u * s + 2u];
+        __syncthreads();
         const bool special = h0 >= KEY_TOMB32;                  // EMPTY or TOMB: the same sentinel, widened
-        seg[4 * threadIdx.x + q] = Slot<1>{special ? (h0 == KEY_EMPTY32 ? KEY_EMPTY : KEY_TOMB) : ((u64)h0 | ((u64)h1 << 31)), w[3 * q + 2], 0u};
+        seg[s] = Slot<1>{special ? (h0 == KEY_EMPTY32 ? KEY_EMPTY : KEY_TOMB) : ((u64)h0 | ((u64)h1 << 31)), ex, 0u};
         *nfree += h0 == KEY_EMPTY32 ? 1u : 0u;
     }
-}
-__device__ __forceinline__ void cslots_pack_in_lds(uint4 *lds_raw) {
-    const Slot<1> *seg = reinterpret_cast<const Slot<1> *>(lds_raw);
-    u32 w[12];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const Slot<1> sl = seg[4 * threadIdx.x + q];
-        const bool special = sl.w0 >= KEY_TOMB;
-        w[3 * q] = special ? (sl.w0 == KEY_EMPTY ? KEY_EMPTY32 : KEY_TOMB32) : (u32)sl.w0 & 0x7fffffffu;
-        w[3 * q + 1] = special ? KEY_EMPTY32 : (u32)(sl.w0 >> 31);
-        w[3 * q + 2] = sl.extra;
-    }
-    __syncthreads();
-    lds_raw[3 * threadIdx.x] = make_uint4(w[0], w[1], w[2], w[3]);
-    lds_raw[3 * threadIdx.x + 1] = make_uint4(w[4], w[5], w[6], w[7]);
-    lds_raw[3 * threadIdx.x + 2] = make_uint4(w[8], w[9], w[10], w[11]);
 }
 template <int W, class ST>
 __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W, ST> t, const u64 *__restrict__ keys, PartArrays a, int from_empty, Counters *ctr,
@@ -1107,6 +1108,16 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W, ST> t, const 
             kk[j] = load_key<W>(keys, nk ? b + first + (i < nk ? i : nk - 1) : 0);
         }
     };
+    // an EMPTY segment image to HBM.  (The 12-byte pattern depends on the vector's index mod 3: left alone, the compiler keeps a
+    // thread's three pattern vectors in 12 VGPRs for the whole kernel — and spills them; the opaque move makes it compute them here.)
+    auto clear_gseg = [&](uint4 *gseg) {
+#pragma unroll
+        for (u32 i = threadIdx.x; i < GVEC; i += SBLOCK) {
+            u32 ii = i;
+            if constexpr (CONV) asm volatile("" : "+v"(ii));
+            gseg[i] = empty_vec_of(gtype, ii);
+        }
+    };
     u64 kb, kbn; u32 cnt, cntn;
     // one segment; `cur` holds its first key block (requested one step earlier), `nxt` receives the next segment's.
     // The two register sets swap roles from step to step (a copy would have to wait for the loads).
@@ -1116,24 +1127,26 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W, ST> t, const 
         request_keys(nxt, kbn, cntn, 0u);                             // one ahead: its first keys
         uint4 *gseg = reinterpret_cast<uint4 *>(t.slots + (s << SegBits<W>::value));
         if (cnt == 0) {
-            if (from_empty) {       // materialise the pending clear of a segment that gets no key
-#pragma unroll
-                for (u32 i = threadIdx.x; i < GVEC; i += SBLOCK) gseg[i] = empty_vec_of(gtype, i);
-            }
+            if (from_empty) clear_gseg(gseg);       // materialise the pending clear of a segment that gets no key
         } else {
             __syncthreads();
             if (threadIdx.x < 3) flags[threadIdx.x] = 0;
             if (from_empty) {
+                u32 z = 0;
+                if constexpr (CONV) asm volatile("" : "+v"(z));        // (keeps the pattern out of long-lived registers: see clear_gseg)
 #pragma unroll
-                for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) lds_raw[i] = empty_vec_of(seg, i);
+                for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) {
+                    uint4 e = empty_vec_of(seg, i);
+                    e.x ^= z; e.y ^= z; e.z ^= z; e.w ^= z;
+                    lds_raw[i] = e;
+                }
             } else {
                 u32 nfree = 0;                                  // a slot is free iff its first key word is EMPTY
                 if constexpr (CONV) {
-                    static_assert(!CONV || S / 4 == SBLOCK, "one group of four slots per thread");
 #pragma unroll
-                    for (u32 i = threadIdx.x; i < GVEC; i += SBLOCK) lds_raw[i] = gseg[i];
+                    for (u32 i = threadIdx.x; i < GVEC; i += SBLOCK) lds_raw[(NVEC - GVEC) + i] = gseg[i];
                     __syncthreads();
-                    cslots_expand_in_lds(lds_raw, &nfree);
+                    cslots_expand_in_lds<S>(lds_raw, &nfree);
                 } else {
 #pragma unroll
                     for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) {
@@ -1182,15 +1195,12 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W, ST> t, const 
             if (flags[1]) {
                 // segment full: leave the HBM copy as it was (or EMPTY) and hand the bucket to the host,
                 // which grows the table and replays these keys through the direct path
-                if (from_empty)
-                    for (u32 i = threadIdx.x; i < GVEC; i += SBLOCK) gseg[i] = empty_vec_of(gtype, i);
+                if (from_empty) clear_gseg(gseg);
                 if (threadIdx.x == 0) a.failed[atomicAdd(a.n_failed, 1u)] = (u32)s;
             } else {
                 if constexpr (CONV) {
-                    cslots_pack_in_lds(lds_raw);
-                    __syncthreads();
-#pragma unroll
-                    for (u32 i = threadIdx.x; i < GVEC; i += SBLOCK) gseg[i] = lds_raw[i];
+#pragma unroll 1
+                    for (u32 i = threadIdx.x; i < GVEC; i += SBLOCK) gseg[i] = cslot_vec_from_lds(seg, i);
                 } else {
 #pragma unroll
                     for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) gseg[i] = lds_raw[i];
