@@ -1035,6 +1035,12 @@ static constexpr int SBLOCK = GK_SBLOCK;               // threads per segment wo
 // 32-bit ones (measured: the two-CAS form in LDS cost P5 0.92 ms against 0.82 — more than the quarter fewer bytes gave back;
 // profiles/r03/bench_n1_run08_cslot_two_cas_LOSES.json) — and the HBM image is converted on the way in and out, four slots
 // (three 16-byte vectors) per thread.
+#ifndef GK_ABL_P5
+#define GK_ABL_P5 0                     // timing-only ablations of k_seg_insert (variant builds; never in the product library)
+#endif
+#ifndef GK_P5_MIN_WAVES
+#define GK_P5_MIN_WAVES 8
+#endif
 template <class ST> struct LdsSlotOf { typedef ST type; };
 template <> struct LdsSlotOf<CSlot> { typedef Slot<1> type; };
 // Both directions keep every HBM access a run of whole 16-byte vectors per wave and need few registers (the kernel lives at 64
@@ -1072,7 +1078,7 @@ __device__ __forceinline__ void cslots_expand_in_lds(uint4 *lds_raw, u32 *nfree)
     }
 }
 template <int W, class ST>
-__global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W, ST> t, const u64 *__restrict__ keys, PartArrays a, int from_empty, Counters *ctr,
+__global__ __launch_bounds__(SBLOCK, GK_P5_MIN_WAVES) void k_seg_insert(Table<W, ST> t, const u64 *__restrict__ keys, PartArrays a, int from_empty, Counters *ctr,
                                                           u64 seg_lo, u64 seg_hi /* this launch's segments: [seg_lo, seg_hi) */) {
     extern __shared__ uint4 lds_raw[];
     typedef typename LdsSlotOf<ST>::type LT;
@@ -1175,6 +1181,9 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W, ST> t, const 
                     if (r < 0) overflow = true; else claims += (u32)r;
                 }
             };
+#if GK_ABL_P5 == 1                      // timing-only: no inserts (the segment goes out EMPTY)
+            if (cnt == 0xffffffffu)
+#endif
             insert_block(cur, min(cnt, KBLK));
             if (cnt > KBLK) {                                   // heavy segments (repeats): further blocks, each requested a block ahead
                 Kmer<W> ta[KPT], tb[KPT];
@@ -1198,9 +1207,17 @@ __global__ __launch_bounds__(SBLOCK, 8) void k_seg_insert(Table<W, ST> t, const 
                 if (from_empty) clear_gseg(gseg);
                 if (threadIdx.x == 0) a.failed[atomicAdd(a.n_failed, 1u)] = (u32)s;
             } else {
+#if GK_ABL_P5 == 2                      // timing-only: no write-out
+                if (cnt == 0xffffffffu)
+#endif
                 if constexpr (CONV) {
+#if GK_ABL_P5 == 3                      // timing-only: the write-out without the conversion (the LDS image's first 24 KiB as they are)
+#pragma unroll
+                    for (u32 i = threadIdx.x; i < GVEC; i += SBLOCK) gseg[i] = lds_raw[i];
+#else
 #pragma unroll 1
                     for (u32 i = threadIdx.x; i < GVEC; i += SBLOCK) gseg[i] = cslot_vec_from_lds(seg, i);
+#endif
                 } else {
 #pragma unroll
                     for (u32 i = threadIdx.x; i < NVEC; i += SBLOCK) gseg[i] = lds_raw[i];

@@ -997,7 +997,6 @@ static int launch_count(gk_map *m, const ReadSrc &src) {
 // bytes of `.bin` records one staging area holds at most: what one partitioned batch of 2^31 windows takes (150 bp reads, k = 31:
 // 17.9 M records of 39 bytes) — a host-fed count then cuts its stream where the device-resident one cuts its batches
 static constexpr size_t GK_MAX_STAGE_DEFAULT = 704u << 20;
-static constexpr size_t GK_FIRST_STAGE = 128u << 20;
 static inline size_t max_stage(const gk_ctx *ctx) { return ctx->hook_max_stage > 0 ? (size_t)ctx->hook_max_stage : GK_MAX_STAGE_DEFAULT; }
 static int reset_occ_counter(gk_map *m) {
     GK_HIP(m->ctx, hipMemsetAsync(&m->d_ctr->occurrences, 0, sizeof(unsigned long long), m->ctx->stream));
@@ -1385,9 +1384,10 @@ int gk_map_count_reads(gk_map *m, const uint8_t *bin, size_t nbytes, uint64_t nr
             const size_t rb0 = 1 + (size_t)(len0 + 3) / 4;
             const u64 nk0 = len0 >= m->k ? (u64)(len0 - m->k + 1) : 0;
             u64 cap = std::min<u64>(nreads - r, (nbytes - pos) / rb0);
-            // (the FIRST chunk of a long stream is short: its upload cannot hide behind anything — the L1 scatter runs at PCIe pace for
-            //  it — so it is kept to 128 MiB; from the second chunk on the upload runs beside the previous chunk's fine level)
-            const size_t stage_cap = pos == 0 && ctx->hook_max_stage <= 0 && nbytes > (size_t)4 * GK_FIRST_STAGE ? GK_FIRST_STAGE : max_stage(ctx);
+            // (A short FIRST chunk — its upload cannot hide behind anything — was tried and lost: 128 MiB first, C3 from host memory
+            //  129 ms against 107-116 with equal chunks: one more batch, i.e. one more pass over the table, costs more than the
+            //  2 ms of exposed upload it saves; profiles/r03/c3_host_fed_variants.txt)
+            const size_t stage_cap = max_stage(ctx);
             cap = std::min<u64>(cap, std::max<u64>(1, stage_cap / rb0));
             if (nk0) cap = std::min<u64>(cap, std::max<u64>(1, occ_limit / nk0));
             const uint8_t *p0 = bin + pos;
