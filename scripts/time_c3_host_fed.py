@@ -1,6 +1,6 @@
 """C3's count from pinned host memory under the streaming switches, beside the device-resident count (same map, same reads):
 where the host-fed call's extra time goes.  usage: python scripts/time_c3_host_fed.py [reads=50000000]
-Variants: default (first chunk 128 MiB, then 704 MiB chunks, each uploaded beside the previous chunk's fine level),
+Variants: default (704 MiB chunks, each uploaded beside the previous chunk's fine level),
 host_prefetch=0 (every chunk piece-wise under its own L1 scatter), max_stage = 704 / 352 / 1408 MiB (an explicit max_stage
 also switches the short first chunk off)."""
 import json, os, sys, time
@@ -40,7 +40,7 @@ def run(label, f, reps=2):
 
 
 run("device-resident", lambda: m.count_reads_dev(d, N, L), reps=3)
-variants = [("host default", {}), ("host_prefetch=0", {"host_prefetch": 0}), ("max_stage=704MiB (no short first chunk)", {"test_max_stage": 704 << 20}),
+variants = [("host default", {}), ("host_prefetch=0", {"host_prefetch": 0}), ("host default again", {}), ("max_stage=704MiB", {"test_max_stage": 704 << 20}),
             ("max_stage=352MiB", {"test_max_stage": 352 << 20}), ("max_stage=1408MiB", {"test_max_stage": 1408 << 20}),
             ("max_stage=704MiB, host_prefetch=0", {"test_max_stage": 704 << 20, "host_prefetch": 0})]
 for label, opts in variants:
