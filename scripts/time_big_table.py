@@ -13,10 +13,17 @@ ctx = Context(0)
 d = ctx.alloc(n * synth.record_stride(L) + 64)
 ctx.synth_reads(d, n, L, "U", 9, 0, 0, 0.0)
 out = {"reads": n, "k": k, "windows": n * nk}
-for path in ("partitioned", "direct"):
+# "partitioned_one_batch": gk_map_set_max_batch_keys lifts the default cap on a batch's key scratch (16 GiB per buffer) so that the
+# whole call is ONE batch — the table is then streamed once (written from empty) instead of once per batch (in and out again)
+for path in ("partitioned", "partitioned_one_batch", "direct"):
     m = HipDNAMap(ctx, k, int(n * nk * 1.05))
     st = m.stats()
-    m.set_insert_path(path)
+    m.set_insert_path("partitioned" if path.startswith("partitioned") else path)
+    if path == "partitioned_one_batch":
+        if n * nk * (8 if k <= 31 else 16) <= (16 << 30):
+            m.close()
+            continue                                    # (already one batch)
+        m.set_max_batch_keys(n * nk)
     res = []
     for rep in range(2):
         m.clear()
