@@ -109,6 +109,8 @@ SIGNATURES = {
     "gk_dist_last_ms": (C.c_int, [vp, C.POINTER(C.c_float)]),
     "gk_dist_size": (C.c_int, [vp, vp, u64p]),
     "gk_dist_gather_map": (C.c_int, [vp, vp, C.POINTER(vp)]),
+    "gk_dist_gather_classified_map": (C.c_int, [vp, vp, C.POINTER(vp)]),
+    "gk_dist_classify_queries": (C.c_int, [vp, u64p]),
     "gk_vmap_create": (C.c_int, [vp, C.c_int, C.c_uint64, C.POINTER(vp)]),
     "gk_vmap_destroy": (None, [vp]),
     "gk_vmap_k": (C.c_int, [vp]),
@@ -144,6 +146,7 @@ SIGNATURES = {
     "gk_graph_component_stats": (C.c_int, [vp, C.POINTER(C.c_uint32), u64p, C.c_uint64, u64p]),
     "gk_graph_checksum": (C.c_int, [vp, u64p, u64p]),
     "gk_graph_bucketed_table_stats": (C.c_int, [vp, C.POINTER(C.c_float), u64p]),
+    "gk_graph_classified_by_owners": (C.c_int, [vp, C.POINTER(C.c_int)]),
     "gk_graph_build_stats": (C.c_int, [vp, C.POINTER(C.c_float), u64p, C.POINTER(C.c_int)]),
     "gk_graph_export_nodes": (C.c_int, [vp, u64p, u64p, C.c_uint64, u64p]),
     "gk_graph_export_edges": (C.c_int, [vp, u64p, u64p, u64p, u64p, i64p, i64p, C.c_uint64, u64p, u8p, C.c_uint64, u64p]),

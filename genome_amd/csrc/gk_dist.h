@@ -76,6 +76,7 @@ struct gk_dist {
     unsigned long long *d_cnt = nullptr;             // [8 x 64]: (records, k-mers, status) per peer to send [0, 3 x 64), as received [3 x 64, 6 x 64), scalars behind
     unsigned long long *h_cnt = nullptr;             // pinned mirror
     float last_ms[4] = {0, 0, 0, 0};                 // route, exchange, owner count, total (wall)
+    gk::u64 classify_queries = 0;                    // neighbour lookups this rank asked of other ranks (classified gathers, since creation)
     float last_helper_ms = 0;                        // host time of the exchange that ran beside the last owner count
     // ONE helper thread per handle, started on first use: it runs the exchange of the next batch beside the owner count
     // (a std::thread per step was 30-50 us of clone + join each).  It never touches the context's error string, its

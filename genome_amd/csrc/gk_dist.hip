@@ -355,6 +355,7 @@ int gk_dist_route_begin(gk_dist *d, int k, const void *dev_records, uint64_t nre
     // A failure from here on is THIS RANK'S ALONE, and its peers are going to exchange this batch: the batch is begun all the
     // same, carrying the failure, and gk_dist_count_routed tells everybody (status word of the counts exchange).
     int rc = dist_grow(ctx, &d->d_sendbuf[b], &d->send_cap[b], want, slot);
+    ctx->copy_other_pending = true;
     if (!rc) rc = skm_route_launch(ctx, ctx->copy_stream, d->d_route_cnt + b * SKM_COUNT_WORDS, d->h_route_cnt + b * SKM_COUNT_WORDS, k, dev_records, nreads,
                                    read_len, P, d->d_sendbuf[b], d->send_cap[b]);
     if (rc) { rt.settled = true; rt.local_rc = rc; rt.local_err = ctx->err; (void)hipGetLastError(); }
@@ -382,6 +383,7 @@ static void route_settle(gk_dist *d, int b, float *ms) {
         const u64 want = std::max<u64>(d->send_cap[b] * 2, (worst + worst / 8 + 1024) * P);
         if ((e = hipStreamSynchronize(ctx->copy_stream)) != hipSuccess) { rrc = hip_fail(ctx, e, "gk_dist: re-route"); break; }   // (later routes share the stream)
         if ((rrc = dist_grow(ctx, &d->d_sendbuf[b], &d->send_cap[b], want, slot)) != GK_OK) break;
+        ctx->copy_other_pending = true;
         if ((rrc = skm_route_launch(ctx, ctx->copy_stream, d_rc, h_rc, k, rt.records, rt.nreads, rt.read_len, P, d->d_sendbuf[b], d->send_cap[b])) != GK_OK) break;
         if ((e = hipStreamSynchronize(ctx->copy_stream)) != hipSuccess) { rrc = hip_fail(ctx, e, "gk_dist: re-route"); break; }
         rrc = skm_route_finish(ctx, h_rc, true, P, d->send_cap[b], rt.recs, rt.kmers);
@@ -568,7 +570,15 @@ int gk_dist_last_ms(gk_dist *d, float *ms4) {
 // receive), the parts are exchanged and inserted, and the staging is reused: 0.67 GB to send and P x that to receive whatever
 // the table's size (until round 3 the whole set was staged at 20 B per key — 62 GB at C5 — beside the table being built).
 // The new table is sized the way the graph phase wants it (graph_table_load).
-int gk_dist_gather_map(gk_dist *d, gk_map *local, gk_map **full) {
+//
+// CLASSIFIED form (gk_dist_gather_classified_map; SURVEY.md 8(e) "beyond counting", Graph.scala:320-329 through
+// PartitionedDNAMap.mapReduce :55-58): before a chunk's keys travel, their owner classifies them — neighbours it owns itself
+// are looked up in its own partition, the others are asked of THEIR owners (one all-to-all of canonical keys, one of answer
+// bytes: k_dc_* in gk_graph.hip) — and the 8-bit (incoming, outcoming) mask travels with each key into the replica's annotation
+// word.  gk_graph_build on the gathered table then derives terminal / secondary from the masks in one streaming pass instead of
+// eight random lookups per key on EVERY rank: the classify's work is divided by the number of ranks.  A partition that holds
+// verbatim non-canonical keys (dirty) on any rank turns the form off for everybody (plain gather).
+static int dist_gather(gk_dist *d, gk_map *local, gk_map **full, bool classify) {
     if (int rc = dist_check(d)) return rc;
     gk_ctx *ctx = d->ctx;
     if (!local || !full || local->ctx != ctx) return fail(ctx, GK_E_INVALID, "gk_dist_gather_map: bad argument");
@@ -576,33 +586,48 @@ int gk_dist_gather_map(gk_dist *d, gk_map *local, gk_map **full) {
     if (int rc = dist_quiesce(d)) return rc;
     if (int rc = map_materialize(local)) return rc;
     const int P = d->world, W = local->W;
+    // (the masks live in the annotation word: a partition that still counts in 12-byte slots is rebuilt first — a local step,
+    //  whose failure is announced with the first chunk's word like any other)
+    int pre_rc = GK_OK;
+    std::string pre_err;
+    if (classify) { pre_rc = map_to_graph_layout(local); if (pre_rc) pre_err = ctx->err; }
     constexpr u64 CHS = 1ull << 25;
     // live keys of every rank, and the number of chunks of the rank with the largest table
-    unsigned long long mine[2] = {local->size, (local->capacity + CHS - 1) / CHS};
-    GK_HIP(ctx, hipMemcpyAsync(d->d_cnt + 2 * 64, mine, 16, hipMemcpyHostToDevice, ctx->stream));
+    unsigned long long mine[3] = {local->size, (local->capacity + CHS - 1) / CHS, (classify && !local->dirty) ? 0ull : 1ull};
+    GK_HIP(ctx, hipMemcpyAsync(d->d_cnt + 2 * 64, mine, 24, hipMemcpyHostToDevice, ctx->stream));
     GK_NCCL(ctx, xAllGather(d, d->d_cnt + 2 * 64, d->d_cnt, 1, ncclUint64, ctx->stream));
     GK_NCCL(ctx, xAllReduce(d, d->d_cnt + 2 * 64 + 1, d->d_cnt + 64, 1, ncclUint64, ncclMax, ctx->stream));
-    GK_HIP(ctx, hipMemcpyAsync(d->h_cnt, d->d_cnt, (64 + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    GK_NCCL(ctx, xAllReduce(d, d->d_cnt + 2 * 64 + 2, d->d_cnt + 65, 1, ncclUint64, ncclMax, ctx->stream));
+    GK_HIP(ctx, hipMemcpyAsync(d->h_cnt, d->d_cnt, (64 + 2) * 8, hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     u64 total = 0;
     const u64 nchunks = d->h_cnt[64];
+    classify = classify && d->h_cnt[65] == 0;          // (every rank takes the same decision: the word is a maximum over all of them)
     for (int p = 0; p < P; p++) total += d->h_cnt[p];
     if (d->h_cnt[d->rank] != mine[0]) return fail(ctx, GK_E_COMM, "gk_dist_gather_map: size exchange is inconsistent");
     gk_map *m = nullptr;
     u64 *d_send_k = nullptr, *d_recv_k = nullptr;
     i32 *d_send_c = nullptr, *d_recv_c = nullptr;
     unsigned long long *d_cur = nullptr;
+    uint8_t *d_send_m = nullptr, *d_recv_m = nullptr;                  // classified form: the masks beside the keys
+    unsigned long long *d_dc = nullptr;                                // [5][64]: counts to send | counts received | remote counts | region offsets | cursors
+    u32 *d_err = nullptr;
+    u64 *d_qk = nullptr, *d_qref = nullptr, *d_rk = nullptr;           // queries out (keys, who asked), queries in
+    uint8_t *d_ans_in = nullptr, *d_ans_out = nullptr;                 // answers to my queries, my answers to the others'
+    u64 q_out_cap = 0, q_in_cap = 0;
     // every rank's chunk holds at most CHS keys: the receive staging is allocated ONCE, before anything is agreed — no allocation,
     // hence no local failure, between a chunk's size exchange and its sends and receives
     const u64 recv_cap = std::max<u64>(std::min<u64>(total, (u64)P * CHS), 1);
     auto done = [&](int code) {
-        for (void *p : {(void *)d_send_k, (void *)d_send_c, (void *)d_recv_k, (void *)d_recv_c, (void *)d_cur}) if (p) (void)hipFree(p);
+        for (void *p : {(void *)d_send_k, (void *)d_send_c, (void *)d_recv_k, (void *)d_recv_c, (void *)d_cur, (void *)d_send_m, (void *)d_recv_m, (void *)d_dc, (void *)d_err,
+                        (void *)d_qk, (void *)d_qref, (void *)d_rk, (void *)d_ans_in, (void *)d_ans_out}) if (p) (void)hipFree(p);
         if (code != GK_OK && m) { gk_map_destroy(m); m = nullptr; }
         return code;
     };
     // a local failure must not leave the peers in a receive: it is announced in the chunk's size word and everybody stops
-    int my_rc = map_create_for_graph(ctx, local->k, total, &m);
-    std::string my_err = my_rc ? ctx->err : std::string();
+    int my_rc = pre_rc;
+    std::string my_err = pre_err;
+    if (!my_rc) { my_rc = map_create_for_graph(ctx, local->k, total, &m); if (my_rc) my_err = ctx->err; }
     const u64 send_cap = std::min<u64>(CHS, local->capacity);
     if (!my_rc) {
         hipError_t e = hipMalloc((void **)&d_send_k, std::max<u64>(send_cap, 1) * 8 * W);
@@ -610,13 +635,118 @@ int gk_dist_gather_map(gk_dist *d, gk_map *local, gk_map **full) {
         if (e == hipSuccess) e = hipMalloc((void **)&d_cur, 8);
         if (e == hipSuccess) e = hipMalloc((void **)&d_recv_k, recv_cap * 8 * W);
         if (e == hipSuccess) e = hipMalloc((void **)&d_recv_c, recv_cap * 4);
+        if (e == hipSuccess && classify) e = hipMalloc((void **)&d_send_m, std::max<u64>(send_cap, 1));
+        if (e == hipSuccess && classify) e = hipMalloc((void **)&d_recv_m, recv_cap);
+        if (e == hipSuccess && classify) e = hipMalloc((void **)&d_dc, 5 * 64 * 8);
+        if (e == hipSuccess && classify) e = hipMalloc((void **)&d_err, 4);
+        if (e == hipSuccess && classify) e = hipMemsetAsync(d_err, 0, 4, ctx->stream);
         if (e != hipSuccess) { my_rc = hip_fail(ctx, e, "gk_dist_gather_map: staging"); my_err = ctx->err; }
     }
 #define HIPD(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return done(hip_fail(ctx, e__, #call)); } while (0)
     for (u64 c = 0; c < nchunks; c++) {
         uint64_t n_mine = 0;
+        if (classify && P > 1) {
+            // ---- the owners' classify of this chunk's slots: count -> sizes round -> queries -> answers -> masks --------------
+            unsigned long long h_send[64] = {0}, h_recv[64] = {0}, h_off[64] = {0};
+            if (!my_rc) {
+                my_rc = dclass_count(local, d->rank, P, c * CHS, (c + 1) * CHS, d_dc + 2 * 64);
+                if (!my_rc) {
+                    hipError_t e = hipMemcpyAsync(h_send, d_dc + 2 * 64, P * 8, hipMemcpyDeviceToHost, ctx->stream);
+                    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                    if (e != hipSuccess) my_rc = hip_fail(ctx, e, "gk_dist_gather_map: classify counts");
+                }
+                if (my_rc) my_err = ctx->err;
+            }
+            // what I will ask of every peer (or ~0: I failed, nobody goes on), against what every peer will ask of me
+            unsigned long long words[64];
+            for (int p = 0; p < P; p++) words[p] = my_rc ? ~0ull : h_send[p];
+            unsigned long long *d_w_out = d->d_cnt + 4 * 64, *d_w_in = d->d_cnt + 5 * 64;      // (the handle's own words: they exist whatever failed above)
+            HIPD(hipMemcpyAsync(d_w_out, words, P * 8, hipMemcpyHostToDevice, ctx->stream));
+            {
+                int grc = xGroupStart(d);
+                for (int p = 0; p < P; p++) {
+                    if (p == d->rank) continue;
+                    if (grc == ncclSuccess) grc = xSend(d, d_w_out + p, 1, ncclUint64, p, ctx->stream);
+                    if (grc == ncclSuccess) grc = xRecv(d, d_w_in + p, 1, ncclUint64, p, ctx->stream);
+                }
+                const int gend = xGroupEnd(d);
+                if (grc == ncclSuccess) grc = gend;
+                if (grc != ncclSuccess) return done(fail(ctx, GK_E_COMM, std::string("gk_dist_gather_map: ") + comm_error_text(grc)));
+            }
+            HIPD(hipMemcpyAsync(h_recv, d_w_in, P * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPD(hipStreamSynchronize(ctx->stream));
+            h_recv[d->rank] = 0;
+            bool peer_failed = false;
+            for (int p = 0; p < P; p++) if (p != d->rank && h_recv[p] == ~0ull) peer_failed = true;
+            // (a rank that failed told EVERY peer so: all of them are here, none has posted a payload receive)
+            if (my_rc || peer_failed) return done(my_rc ? fail(ctx, my_rc, my_err) : fail(ctx, GK_E_COMM, "gk_dist_gather_map: another rank failed; the gather was abandoned on every rank"));
+            u64 nq_out = 0, nq_in = 0;
+            unsigned long long r_off[64] = {0};
+            for (int p = 0; p < P; p++) { h_off[p] = nq_out; nq_out += h_send[p]; r_off[p] = nq_in; nq_in += h_recv[p]; }
+            // room for both directions; a failure here is agreed on before anybody posts a receive
+            if (ctx->hook_dist_fail_classify) {       // test hook: this rank alone cannot stage its queries
+                ctx->hook_dist_fail_classify = 0;
+                my_rc = fail(ctx, GK_E_CAPACITY, "injected failure (test_dist_fail_classify)");
+                my_err = ctx->err;
+            }
+            if (!my_rc && nq_out > q_out_cap) {
+                for (void *q : {(void *)d_qk, (void *)d_qref, (void *)d_ans_in}) if (q) (void)hipFree(q);
+                d_qk = d_qref = nullptr; d_ans_in = nullptr; q_out_cap = 0;
+                hipError_t e = hipMalloc((void **)&d_qk, nq_out * 8 * W);
+                if (e == hipSuccess) e = hipMalloc((void **)&d_qref, nq_out * 8);
+                if (e == hipSuccess) e = hipMalloc((void **)&d_ans_in, nq_out);
+                if (e != hipSuccess) { my_rc = hip_fail(ctx, e, "gk_dist_gather_map: query staging"); my_err = ctx->err; } else q_out_cap = nq_out;
+            }
+            if (!my_rc && nq_in > q_in_cap) {
+                for (void *q : {(void *)d_rk, (void *)d_ans_out}) if (q) (void)hipFree(q);
+                d_rk = nullptr; d_ans_out = nullptr; q_in_cap = 0;
+                hipError_t e = hipMalloc((void **)&d_rk, nq_in * 8 * W);
+                if (e == hipSuccess) e = hipMalloc((void **)&d_ans_out, nq_in);
+                if (e != hipSuccess) { my_rc = hip_fail(ctx, e, "gk_dist_gather_map: query staging"); my_err = ctx->err; } else q_in_cap = nq_in;
+            }
+            {
+                unsigned long long word = my_rc ? 1ull : 0ull;
+                HIPD(hipMemcpyAsync(d->d_cnt + 2 * 64, &word, 8, hipMemcpyHostToDevice, ctx->stream));
+                const int g = xAllReduce(d, d->d_cnt + 2 * 64, d->d_cnt + 2 * 64, 1, ncclUint64, ncclMax, ctx->stream);
+                if (g != ncclSuccess) return done(fail(ctx, GK_E_COMM, "gk_dist_gather_map: " + comm_error_text(g)));
+                HIPD(hipMemcpyAsync(&word, d->d_cnt + 2 * 64, 8, hipMemcpyDeviceToHost, ctx->stream));
+                HIPD(hipStreamSynchronize(ctx->stream));
+                if (my_rc) return done(fail(ctx, my_rc, my_err));
+                if (word) return done(fail(ctx, GK_E_COMM, "gk_dist_gather_map: another rank failed; the gather was abandoned on every rank"));
+            }
+            HIPD(hipMemcpyAsync(d_dc + 3 * 64, h_off, P * 8, hipMemcpyHostToDevice, ctx->stream));
+            if (nq_out) { if (int rc = dclass_fill(local, d->rank, P, c * CHS, (c + 1) * CHS, d_dc + 3 * 64, d_dc + 4 * 64, d_qk, d_qref)) return done(rc); }
+            {
+                int grc = xGroupStart(d);
+                for (int p = 0; p < P; p++) {
+                    if (p == d->rank) continue;
+                    if (h_send[p] && grc == ncclSuccess) grc = xSend(d, d_qk + h_off[p] * W, (size_t)h_send[p] * W, ncclUint64, p, ctx->stream);
+                    if (h_recv[p] && grc == ncclSuccess) grc = xRecv(d, d_rk + r_off[p] * W, (size_t)h_recv[p] * W, ncclUint64, p, ctx->stream);
+                }
+                const int gend = xGroupEnd(d);
+                if (grc == ncclSuccess) grc = gend;
+                if (grc != ncclSuccess) return done(fail(ctx, GK_E_COMM, std::string("gk_dist_gather_map: ") + comm_error_text(grc)));
+            }
+            if (int rc = dclass_answer(local, d_rk, nq_in, d_ans_out)) return done(rc);
+            {
+                int grc = xGroupStart(d);
+                for (int p = 0; p < P; p++) {
+                    if (p == d->rank) continue;
+                    if (h_recv[p] && grc == ncclSuccess) grc = xSend(d, d_ans_out + r_off[p], (size_t)h_recv[p], ncclUint8, p, ctx->stream);
+                    if (h_send[p] && grc == ncclSuccess) grc = xRecv(d, d_ans_in + h_off[p], (size_t)h_send[p], ncclUint8, p, ctx->stream);
+                }
+                const int gend = xGroupEnd(d);
+                if (grc == ncclSuccess) grc = gend;
+                if (grc != ncclSuccess) return done(fail(ctx, GK_E_COMM, std::string("gk_dist_gather_map: ") + comm_error_text(grc)));
+            }
+            if (int rc = dclass_apply(local, d_qref, d_ans_in, nq_out)) return done(rc);
+            d->classify_queries += nq_out;
+        } else if (classify && !my_rc) {
+            my_rc = dclass_count(local, d->rank, P, c * CHS, (c + 1) * CHS, d_dc + 2 * 64);       // one rank: every neighbour is local
+            if (my_rc) my_err = ctx->err;
+        }
         if (!my_rc && c * CHS < local->capacity) {
-            my_rc = map_export_range_dev(local, c * CHS, (c + 1) * CHS, d_send_k, d_send_c, d_cur, &n_mine);
+            my_rc = map_export_range_dev(local, c * CHS, (c + 1) * CHS, d_send_k, d_send_c, d_cur, &n_mine, classify ? d_send_m : nullptr);
             if (my_rc) my_err = ctx->err;
         }
         unsigned long long word = my_rc ? ~0ull : n_mine;
@@ -637,6 +767,7 @@ int gk_dist_gather_map(gk_dist *d, gk_map *local, gk_map **full) {
         if (n_mine) {
             HIPD(hipMemcpyAsync(d_recv_k + my_off * W, d_send_k, n_mine * 8 * W, hipMemcpyDeviceToDevice, ctx->stream));
             HIPD(hipMemcpyAsync(d_recv_c + my_off, d_send_c, n_mine * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            if (classify) HIPD(hipMemcpyAsync(d_recv_m + my_off, d_send_m, n_mine, hipMemcpyDeviceToDevice, ctx->stream));
         }
         if (P > 1) {
             int grc = xGroupStart(d);
@@ -646,8 +777,10 @@ int gk_dist_gather_map(gk_dist *d, gk_map *local, gk_map **full) {
                 if (p != d->rank) {
                     if (n_mine && grc == ncclSuccess) grc = xSend(d, d_send_k, (size_t)n_mine * W, ncclUint64, p, ctx->stream);
                     if (n_mine && grc == ncclSuccess) grc = xSend(d, d_send_c, (size_t)n_mine * 4, ncclUint8, p, ctx->stream);
+                    if (classify && n_mine && grc == ncclSuccess) grc = xSend(d, d_send_m, (size_t)n_mine, ncclUint8, p, ctx->stream);
                     if (n && grc == ncclSuccess) grc = xRecv(d, d_recv_k + off * W, (size_t)n * W, ncclUint64, p, ctx->stream);
                     if (n && grc == ncclSuccess) grc = xRecv(d, d_recv_c + off, (size_t)n * 4, ncclUint8, p, ctx->stream);
+                    if (classify && n && grc == ncclSuccess) grc = xRecv(d, d_recv_m + off, (size_t)n, ncclUint8, p, ctx->stream);
                 }
                 off += n;
             }
@@ -657,7 +790,14 @@ int gk_dist_gather_map(gk_dist *d, gk_map *local, gk_map **full) {
         }
         // one table holding every partition's keys (each key has exactly one owner: nothing merges)
         my_rc = map_add_counted_keys_dev(m, d_recv_k, d_recv_c, tot_c);
+        if (!my_rc && classify) my_rc = map_set_masks_dev(m, d_recv_k, d_recv_m, tot_c, d_err);
         if (my_rc) my_err = ctx->err;
+    }
+    if (classify && !my_rc) {           // a mask whose key the replica does not hold: cannot happen after the inserts above succeeded
+        u32 h_err = 0;
+        HIPD(hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPD(hipStreamSynchronize(ctx->stream));
+        if (h_err) { my_rc = GK_E_STATE; my_err = "gk_dist_gather_map: a gathered key is missing from the replica"; }
     }
     // the last chunk's insert may have failed after its word went out: agree on the outcome once more
     {
@@ -673,9 +813,19 @@ int gk_dist_gather_map(gk_dist *d, gk_map *local, gk_map **full) {
     if (int rc = map_sync_counters(m)) return done(rc);
     if (m->size != total) return done(fail(ctx, GK_E_STATE, "gk_dist_gather_map: gathered " + std::to_string(m->size) + " keys, the partitions hold " + std::to_string(total)));
     m->dirty = local->dirty;
+    m->masks_valid = classify;           // (set after the last map_sync_counters of this table: any later change of its contents clears it)
     *full = m;
     return done(GK_OK);
 }
+#undef HIPD
+int gk_dist_gather_map(gk_dist *d, gk_map *local, gk_map **full) { return dist_gather(d, local, full, false); }
+int gk_dist_gather_classified_map(gk_dist *d, gk_map *local, gk_map **full) { return dist_gather(d, local, full, true); }
+int gk_dist_classify_queries(gk_dist *d, uint64_t *n) {
+    if (!d || !n) return fail(nullptr, GK_E_INVALID, "gk_dist_classify_queries: null argument");
+    *n = d->classify_queries;
+    return GK_OK;
+}
+#define HIPD(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return hip_fail(ctx, e__, #call); } while (0)
 #undef HIPD
 
 }  // extern "C"

@@ -58,6 +58,7 @@ struct gk_graph {
     float build_ms[6] = {0, 0, 0, 0, 0, 0};
     u64 walked_bases = 0;        // bases emitted by the unitig construction (= total edge length at build time)
     int used_pj = 0;
+    int used_masks = 0;          // the classify came with the table (masks computed by the keys' owners, gk_dist_gather_map): no k_classify ran
     float mbt_ms = 0;            // building the minimizer-bucketed copy of the table, when the build used one ("graph_mbt")
     u64 mbt_slots = 0;
     // host snapshot of the edge arrays for the paired-end walks, valid while `epoch` (bumped by every edit) has not moved:

@@ -91,6 +91,77 @@ __device__ __forceinline__ u32 mmer_score(u32 w, int m) {
     return hash32(w < r ? w : r);
 }
 
+// incoming | outcoming << 4 of the stored k-mer y (Graph.scala:270-282): the eight neighbour lookups of the classify; a neighbour
+// whose bit is set in `skip` is not looked up here and counts as absent (the distributed classify asks its owner instead)
+template <int W, class TT>
+__device__ __forceinline__ u32 neighbour_masks(const TT &t, int k, Kmer<W> y, u32 skip) {
+    u32 in = 0, out = 0;
+    // The 8 lookups are independent, but each is a dependent chain that starts with a cold random
+    // sector; done one after the other a lane has ONE miss in flight (168 ms for 1.5e8 16-byte keys).
+    // So: prepare all 8 (canonical orientation, segment, start slot), touch the 8 first sectors
+    // back to back, then resolve — the later probes of a lookup mostly stay in the sector it opened.
+    // The first probed slot's key word is KEPT (eight registers): with 16 waves x 64 lanes x 8 lookups in flight per
+    // CU the touched lines (0.5 MB) do not survive in the 32 KiB L1 — nor, 32 CUs to an XCD, in its 4 MiB L2 — until the
+    // resolve loop comes back to them, and re-reading them there fetched most sectors from memory TWICE.
+    Kmer<W> q[8];
+    ProbeAt<W> pa[8];
+    u64 w0v[8];
+    u32 ties = 0;
+    // (minimizer-bucketed table: the candidates' buckets from ONE pass over this k-mer's m-mers — a candidate shares k - 1
+    //  bases with it, so its minimizer is the minimum of the shared windows' scores and of its one new window)
+    u32 base_succ = 0xffffffffu, base_pred = 0xffffffffu;
+    const int mm_ = k < 11 ? k : 11;
+    if constexpr (is_mb<TT>::value) {
+        const int nwin = k - mm_ + 1;
+        u32 mid = 0xffffffffu, s_first = 0xffffffffu, s_last = 0xffffffffu;
+        for (int wdw = 0; wdw < nwin; wdw++) {
+            const u32 sc = mmer_score((u32)window_bits(y, 2 * wdw) & (u32)low_mask(2 * mm_), mm_);
+            if (wdw == 0) s_first = sc;
+            if (wdw == nwin - 1) s_last = sc;
+            if (wdw != 0 && wdw != nwin - 1) mid = min(mid, sc);
+        }
+        base_succ = nwin > 1 ? min(mid, s_last) : 0xffffffffu;          // windows 1 .. nwin-1 of y = windows 0 .. nwin-2 of a successor
+        base_pred = nwin > 1 ? min(mid, s_first) : 0xffffffffu;         // windows 0 .. nwin-2 of y = windows 1 .. nwin-1 of a predecessor
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (skip >> j & 1u) { w0v[j] = KEY_EMPTY; continue; }            // (asked elsewhere: reads as "not here")
+        const Kmer<W> x = (j & 1) ? append_base(y, j >> 1, k) : prepend_base(j >> 1, y, k);
+        const Kmer<W> rc = revcomp(x, k);
+        const i32 hx = ref_hash(x), hr = ref_hash(rc);
+        if ((hx == hr || t.both) && !(x == rc)) ties |= 1u << j;   // both strands may be stored: slow path below
+        q[j] = hx < hr ? x : rc;
+        if constexpr (is_mb<TT>::value) {
+            const u32 neww = (u32)window_bits(x, (j & 1) ? 2 * (k - mm_) : 0) & (u32)low_mask(2 * mm_);
+            const u32 score = min((j & 1) ? base_succ : base_pred, mmer_score(neww, mm_));
+            pa[j] = probe_at_bucket(t, q[j], (u32)(((u64)hash32(score ^ 0x5bd1e995u) * (u64)t.nb) >> 32));
+        } else {
+            pa[j] = probe_at(t, q[j], k);
+        }
+        w0v[j] = pa[j].reg[pa[j].pos].w0;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        bool hit;
+        if (ties >> j & 1u) {
+            bool f;
+            const Kmer<W> x = (j & 1) ? append_base(y, j >> 1, k) : prepend_base(j >> 1, y, k);
+            hit = table_find_either(t, x, k, &f) >= 0;
+        } else {
+            // first slot from the register; only a slot that is occupied by ANOTHER key sends the probe on (to memory)
+            if (w0v[j] == KEY_EMPTY) hit = false;
+            else {
+                bool first_is_it;
+                if constexpr (W == 1) first_is_it = w0v[j] == q[j].lo;
+                else { const Stored<2> sk = to_stored(q[j]); first_is_it = w0v[j] == sk.w0 && pa[j].reg[pa[j].pos].w1 == sk.w1; }
+                hit = first_is_it || probe_find(pa[j], q[j], true) >= 0;
+            }
+        }
+        if (hit) { if (j & 1) out |= 1u << (j >> 1); else in |= 1u << (j >> 1); }
+    }
+    return in | (out << 4);
+}
+
 // op1 of Graph.buildGraph (Graph.scala:320-329) for every live stored key: incoming/outcoming
 // through `contains` on both strands (:270-282), 8 lookups per key; result kept in the slot.
 template <int W, class TT>
@@ -126,69 +197,8 @@ __global__ __launch_bounds__(BLOCK) void k_classify(TT t, int k, unsigned long l
         const u64 i = base + s_idx[li];
         Slot<W> *s = &t.slots[i];
         Kmer<W> y = slot_key(t, i);
-        u32 in = 0, out = 0;
-        // The 8 lookups are independent, but each is a dependent chain that starts with a cold random
-        // sector; done one after the other a lane has ONE miss in flight (168 ms for 1.5e8 16-byte keys).
-        // So: prepare all 8 (canonical orientation, segment, start slot), touch the 8 first sectors
-        // back to back, then resolve — the later probes of a lookup mostly stay in the sector it opened.
-        // The first probed slot's key word is KEPT (eight registers): with 16 waves x 64 lanes x 8 lookups in flight per
-        // CU the touched lines (0.5 MB) do not survive in the 32 KiB L1 — nor, 32 CUs to an XCD, in its 4 MiB L2 — until the
-        // resolve loop comes back to them, and re-reading them there fetched most sectors from memory TWICE.
-        Kmer<W> q[8];
-        ProbeAt<W> pa[8];
-        u64 w0v[8];
-        u32 ties = 0;
-        // (minimizer-bucketed table: the candidates' buckets from ONE pass over this k-mer's m-mers — a candidate shares k - 1
-        //  bases with it, so its minimizer is the minimum of the shared windows' scores and of its one new window)
-        u32 base_succ = 0xffffffffu, base_pred = 0xffffffffu;
-        const int mm_ = k < 11 ? k : 11;
-        if constexpr (is_mb<TT>::value) {
-            const int nwin = k - mm_ + 1;
-            u32 mid = 0xffffffffu, s_first = 0xffffffffu, s_last = 0xffffffffu;
-            for (int wdw = 0; wdw < nwin; wdw++) {
-                const u32 sc = mmer_score((u32)window_bits(y, 2 * wdw) & (u32)low_mask(2 * mm_), mm_);
-                if (wdw == 0) s_first = sc;
-                if (wdw == nwin - 1) s_last = sc;
-                if (wdw != 0 && wdw != nwin - 1) mid = min(mid, sc);
-            }
-            base_succ = nwin > 1 ? min(mid, s_last) : 0xffffffffu;          // windows 1 .. nwin-1 of y = windows 0 .. nwin-2 of a successor
-            base_pred = nwin > 1 ? min(mid, s_first) : 0xffffffffu;         // windows 0 .. nwin-2 of y = windows 1 .. nwin-1 of a predecessor
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const Kmer<W> x = (j & 1) ? append_base(y, j >> 1, k) : prepend_base(j >> 1, y, k);
-            const Kmer<W> rc = revcomp(x, k);
-            const i32 hx = ref_hash(x), hr = ref_hash(rc);
-            if ((hx == hr || t.both) && !(x == rc)) ties |= 1u << j;   // both strands may be stored: slow path below
-            q[j] = hx < hr ? x : rc;
-            if constexpr (is_mb<TT>::value) {
-                const u32 neww = (u32)window_bits(x, (j & 1) ? 2 * (k - mm_) : 0) & (u32)low_mask(2 * mm_);
-                const u32 score = min((j & 1) ? base_succ : base_pred, mmer_score(neww, mm_));
-                pa[j] = probe_at_bucket(t, q[j], (u32)(((u64)hash32(score ^ 0x5bd1e995u) * (u64)t.nb) >> 32));
-            } else {
-                pa[j] = probe_at(t, q[j], k);
-            }
-            w0v[j] = pa[j].reg[pa[j].pos].w0;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            bool hit;
-            if (ties >> j & 1u) {
-                bool f;
-                const Kmer<W> x = (j & 1) ? append_base(y, j >> 1, k) : prepend_base(j >> 1, y, k);
-                hit = table_find_either(t, x, k, &f) >= 0;
-            } else {
-                // first slot from the register; only a slot that is occupied by ANOTHER key sends the probe on (to memory)
-                if (w0v[j] == KEY_EMPTY) hit = false;
-                else {
-                    bool first_is_it;
-                    if constexpr (W == 1) first_is_it = w0v[j] == q[j].lo;
-                    else { const Stored<2> sk = to_stored(q[j]); first_is_it = w0v[j] == sk.w0 && pa[j].reg[pa[j].pos].w1 == sk.w1; }
-                    hit = first_is_it || probe_find(pa[j], q[j], true) >= 0;
-                }
-            }
-            if (hit) { if (j & 1) out |= 1u << (j >> 1); else in |= 1u << (j >> 1); }
-        }
+        const u32 io = neighbour_masks<W>(t, k, y, 0u);
+        const u32 in = io & 15u, out = io >> 4;
         const int ni = __popc(in), no = __popc(out);
         u32 aux = in | (out << 4);
         const bool term = (ni != 1 || no != 1) && (ni != 0 || no != 0);     // Graph.scala:323
@@ -204,6 +214,148 @@ __global__ __launch_bounds__(BLOCK) void k_classify(TT t, int k, unsigned long l
     }
     }
     __syncthreads();
+    if (cnt) atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) atomicAdd(n_term, (unsigned long long)s_cnt);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The classify over a PartitionedDNAMap (SURVEY.md 8(e) "beyond counting"; the reference ships the classify closure to every
+// partition, Graph.scala:320-329 through PartitionedDNAMap.mapReduce :55-58).  Every rank classifies ITS keys: a neighbour
+// whose owner (gk::owner_of: the strand-symmetric minimizer, so x and rc(x) agree) is this rank is looked up here, the others
+// are asked of their owners — one query all-to-all of canonical keys, one answer all-to-all of bytes (gk_dist.hip) — and the
+// 8-bit (incoming, outcoming) mask of every key ends in its slot's annotation word, to travel with the key in the gather.
+//   k_dc_scan<W, false>: slots [s0, s1): local lookups -> aux = mask of the local hits; remote neighbours counted per owner
+//   k_dc_scan<W, true> : the same enumeration; every remote neighbour's canonical key goes to its owner's region of `qkeys`
+//                        and (slot << 3 | j) to the same position of `qref`
+//   k_dc_answer        : `contains` for every received key
+//   k_dc_apply         : answers back in query order: aux |= bit
+// A neighbour shares k - 1 bases with the k-mer, so its minimizer is the minimum over the shared m-mers and its one new m-mer
+// (the same trick as the minimizer-bucketed table's classify above).
+// ---------------------------------------------------------------------------------------------
+template <int W, bool FILL>
+__global__ __launch_bounds__(BLOCK) void k_dc_scan(Table<W> t, int k, int rank, int P, u64 s0, u64 s1, unsigned long long *cnt /* [P]: totals (count) / cursors (fill) */,
+                                                   const unsigned long long *off /* [P] first query of each owner's region */, u64 *qkeys, u64 *qref) {
+    __shared__ u32 s_cnt[64];
+    __shared__ unsigned long long s_base[64];
+    const int mm_ = k < 11 ? k : 11;
+    const int nwin = k - mm_ + 1;
+    const u64 per_round = (u64)gridDim.x * BLOCK;
+    const u64 nrounds = (s1 - s0 + per_round - 1) / per_round;          // the same for every workgroup: the barriers below are uniform
+    for (u64 r = 0; r < nrounds; r++) {
+        const u64 i = s0 + r * per_round + (u64)blockIdx.x * BLOCK + threadIdx.x;
+        __syncthreads();
+        if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        const bool live = i < s1 && slot_live(&t.slots[i]);
+        u32 remote = 0;                 // bit j: neighbour j lives on another rank
+        u64 owners = 0;                 // 6 bits per neighbour
+        Kmer<W> y{};
+        if (live) {
+            y = slot_key(t, i);
+            u32 mid = 0xffffffffu, s_first = 0xffffffffu, s_last = 0xffffffffu;
+            for (int wdw = 0; wdw < nwin; wdw++) {
+                const u32 sc = mmer_score((u32)window_bits(y, 2 * wdw) & (u32)low_mask(2 * mm_), mm_);
+                if (wdw == 0) s_first = sc;
+                if (wdw == nwin - 1) s_last = sc;
+                if (wdw != 0 && wdw != nwin - 1) mid = min(mid, sc);
+            }
+            const u32 base_succ = nwin > 1 ? min(mid, s_last) : 0xffffffffu, base_pred = nwin > 1 ? min(mid, s_first) : 0xffffffffu;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const Kmer<W> x = (j & 1) ? append_base(y, j >> 1, k) : prepend_base(j >> 1, y, k);
+                const u32 neww = (u32)window_bits(x, (j & 1) ? 2 * (k - mm_) : 0) & (u32)low_mask(2 * mm_);
+                const u32 score = min((j & 1) ? base_succ : base_pred, mmer_score(neww, mm_));
+                const u32 o = (u32)(((u64)hash32(score ^ 0x5bd1e995u) * (u64)P) >> 32);          // == gk::owner_of(x, k, P)
+                if ((int)o != rank) { remote |= 1u << j; owners |= (u64)o << (6 * j); }
+            }
+        }
+        u32 posv[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            posv[j] = 0;
+            if (remote >> j & 1u) posv[j] = atomicAdd(&s_cnt[(owners >> (6 * j)) & 63u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < P && s_cnt[threadIdx.x]) {
+            const unsigned long long b = atomicAdd(&cnt[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+            if (FILL) s_base[threadIdx.x] = b;
+        }
+        if constexpr (!FILL) {
+            if (live) t.slots[i].aux = neighbour_masks<W>(t, k, y, remote);
+        } else {
+            __syncthreads();
+            if (live) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    if (!(remote >> j & 1u)) continue;
+                    const u32 o = (u32)(owners >> (6 * j)) & 63u;
+                    const Kmer<W> x = (j & 1) ? append_base(y, j >> 1, k) : prepend_base(j >> 1, y, k);
+                    const Kmer<W> rc = revcomp(x, k);
+                    const Kmer<W> q = ref_hash(x) < ref_hash(rc) ? x : rc;          // the orientation a counting table stores
+                    const u64 at = off[o] + s_base[o] + posv[j];
+                    if constexpr (W == 1) qkeys[at] = q.lo;
+                    else { qkeys[2 * at] = q.lo; qkeys[2 * at + 1] = q.hi; }
+                    qref[at] = (i << 3) | (u64)j;
+                }
+            }
+        }
+    }
+}
+// `contains` (Graph.scala:270-272) of canonical keys another rank asks about
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_dc_answer(Table<W> t, int k, const u64 *__restrict__ keys, u64 n, uint8_t *ans) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        Kmer<W> x;
+        if constexpr (W == 1) x = Kmer<1>{keys[i]};
+        else x = Kmer<2>{keys[2 * i], keys[2 * i + 1]};
+        bool f;
+        ans[i] = table_find_either(t, x, k, &f) >= 0 ? 1 : 0;
+    }
+}
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_dc_apply(Table<W> t, const u64 *__restrict__ qref, const uint8_t *__restrict__ ans, u64 n) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        if (!ans[i]) continue;
+        const u64 ref = qref[i];
+        const int j = (int)(ref & 7u);
+        atomicOr(&t.slots[ref >> 3].aux, (j & 1) ? 16u << (j >> 1) : 1u << (j >> 1));
+    }
+}
+// the replica: every gathered key's annotation word := the mask its owner computed
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_set_masks(Table<W> t, int k, const u64 *__restrict__ keys, const uint8_t *__restrict__ masks, u64 n, u32 *err) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        Kmer<W> x;
+        if constexpr (W == 1) x = Kmer<1>{keys[i]};
+        else x = Kmer<2>{keys[2 * i], keys[2 * i + 1]};
+        const i64 s = table_find(t, x, k);
+        if (s < 0) { *err = 1; continue; }
+        t.slots[s].aux = masks[i];
+    }
+}
+// ... and what k_classify derives from the masks (terminal, the SECONDARY mark of a hash-rule tie, the count of terminal k-mers)
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_finish_masks(Table<W> t, int k, unsigned long long *n_term) {
+    __shared__ u32 s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    u32 cnt = 0;
+    const u64 ncap = t.capacity();
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < ncap; i += (u64)gridDim.x * BLOCK) {
+        if (!slot_live(&t.slots[i])) continue;
+        u32 aux = t.slots[i].aux & 0xffu;
+        const int ni = __popc(aux & 15u), no = __popc(aux >> 4);
+        const bool term = (ni != 1 || no != 1) && (ni != 0 || no != 0);     // Graph.scala:323
+        if (term) aux |= AUX_TERMINAL;
+        const Kmer<W> y = slot_key(t, i);
+        const Kmer<W> rc = revcomp(y, k);
+        bool secondary = false;
+        if ((t.both || ref_hash(y) == ref_hash(rc)) && !(y == rc) && kmer_less(rc, y) && table_find(t, rc, k) >= 0) secondary = true;
+        if (secondary) aux |= AUX_SECONDARY;
+        t.slots[i].aux = aux;
+        if (term && !secondary) cnt++;
+    }
     if (cnt) atomicAdd(&s_cnt, cnt);
     __syncthreads();
     if (threadIdx.x == 0 && s_cnt) atomicAdd(n_term, (unsigned long long)s_cnt);
@@ -1520,7 +1672,7 @@ int graph_build_index(gk_graph *g) {
 }
 
 // TT: the table the graph phase reads — the map's own hashed table, or the minimizer-bucketed copy built from it (graph_build_entry)
-template <int W, class TT> static int graph_build_impl(gk_map *m, gk_graph *g, TT t) {
+template <int W, class TT> static int graph_build_impl(gk_map *m, gk_graph *g, TT t, bool masks_valid = false) {
     gk_ctx *ctx = m->ctx;
     const int k = m->k;
     const u64 tcap = t.capacity();
@@ -1547,8 +1699,15 @@ template <int W, class TT> static int graph_build_impl(gk_map *m, gk_graph *g, T
         g->build_ms[i] += std::chrono::duration<float, std::milli>(now - t_prev).count();
         t_prev = now;
     };
-    // 1. degree classification of every live key
-    hipLaunchKernelGGL((k_classify<W, TT>), dim3(ggrid(ctx, tcap)), dim3(BLOCK), 0, ctx->stream, t, k, &d_cnt[0]);
+    // 1. degree classification of every live key — or, on a table gathered WITH its owners' masks (gk_dist_gather_map in its
+    //    classified form), only what follows from the masks: one streaming pass, no neighbour lookups
+    bool from_masks = false;
+    if constexpr (!is_mb<TT>::value) from_masks = masks_valid;
+    if constexpr (!is_mb<TT>::value) {
+        if (from_masks) hipLaunchKernelGGL((k_finish_masks<W>), dim3(ggrid(ctx, tcap)), dim3(BLOCK), 0, ctx->stream, t, k, &d_cnt[0]);
+    }
+    if (!from_masks) hipLaunchKernelGGL((k_classify<W, TT>), dim3(ggrid(ctx, tcap)), dim3(BLOCK), 0, ctx->stream, t, k, &d_cnt[0]);
+    g->used_masks = from_masks ? 1 : 0;
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1744,14 +1903,14 @@ template <int W> __global__ __launch_bounds__(BLOCK) void k_mb_fill(Table<W> src
     }
 }
 
-template <int W> static int graph_build_entry(gk_map *m, gk_graph *g) {
+template <int W> static int graph_build_entry(gk_map *m, gk_graph *g, bool masks_valid) {
     gk_ctx *ctx = m->ctx;
     // (m->dirty: keys were inserted verbatim and at least one was not its k-mer's hash-rule orientation — the reference's
     //  `contains` probes both strands unconditionally, Graph.scala:270; so does every lookup below then)
     Table<W> t{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u, m->dirty ? 1u : 0u};
     // "graph_mbt" = 1: classify and walk on a minimizer-bucketed COPY of the table (A/B, profiles/r03); never for k = 64 (tagged slots)
     const bool use_mb = ctx->hook_graph_mbt > 0 && m->k != 64 && m->size >= 4096;
-    if (!use_mb) return graph_build_impl<W, Table<W>>(m, g, t);
+    if (!use_mb) return graph_build_impl<W, Table<W>>(m, g, t, masks_valid);
     const auto t0 = std::chrono::steady_clock::now();
     const u32 nb = (u32)std::min<u64>(std::max<u64>(m->size / (u64)std::max(ctx->hook_graph_mbt_keys, 16), 1), 1u << 30);
     u32 *d_cnt = nullptr, *d_bucket = nullptr, *d_err = nullptr;
@@ -1816,7 +1975,10 @@ int gk_graph_build(gk_map *m, gk_graph **out) {
     g->ctx = m->ctx;
     g->k = m->k;
     g->W = m->W;
-    int rc = m->W == 1 ? graph_build_entry<1>(m, g) : graph_build_entry<2>(m, g);
+    // (the build re-uses the annotation word — a terminal slot's becomes its node — so owner-computed masks serve ONE build)
+    const bool masks_valid = m->masks_valid;
+    m->masks_valid = false;
+    int rc = m->W == 1 ? graph_build_entry<1>(m, g, masks_valid) : graph_build_entry<2>(m, g, masks_valid);
     if (rc != GK_OK) {
         graph_free_arrays(g);
         delete g;
@@ -1944,6 +2106,63 @@ int gk_graph_remove_edges(gk_graph *g, const uint64_t *start_lo, const uint64_t 
 }
 
 }  // extern "C"
+
+// ---- host side of the classify over a PartitionedDNAMap (kernels k_dc_* above; the exchanges are gk_dist.hip's) ----------------
+namespace gk {
+template <int W> static Table<W> graph_table_of(gk_map *m) {
+    return Table<W>{reinterpret_cast<Slot<W> *>(m->slots), m->nb2, m->lnb1, m->k == 64 ? 1u : 0u, m->dirty ? 1u : 0u};
+}
+// slots [s0, s1) of a GRAPH-layout table: local neighbour lookups into the annotation word, remote neighbours counted per owner in d_cnt[P] (zeroed here)
+int dclass_count(gk_map *m, int rank, int P, u64 s0, u64 s1, unsigned long long *d_cnt) {
+    gk_ctx *ctx = m->ctx;
+    GK_HIP(ctx, hipMemsetAsync(d_cnt, 0, 64 * 8, ctx->stream));
+    if (s1 > m->capacity) s1 = m->capacity;
+    if (s0 >= s1) return GK_OK;
+    const int grid = ggrid(ctx, s1 - s0);
+    if (m->W == 1) hipLaunchKernelGGL((k_dc_scan<1, false>), dim3(grid), dim3(BLOCK), 0, ctx->stream, graph_table_of<1>(m), m->k, rank, P, s0, s1, d_cnt, nullptr, nullptr, nullptr);
+    else hipLaunchKernelGGL((k_dc_scan<2, false>), dim3(grid), dim3(BLOCK), 0, ctx->stream, graph_table_of<2>(m), m->k, rank, P, s0, s1, d_cnt, nullptr, nullptr, nullptr);
+    GK_HIP(ctx, hipGetLastError());
+    return GK_OK;
+}
+// the same slots again: the remote neighbours' canonical keys into their owners' regions (d_off[p] = first query for owner p; d_cur[P] zeroed here)
+int dclass_fill(gk_map *m, int rank, int P, u64 s0, u64 s1, const unsigned long long *d_off, unsigned long long *d_cur, u64 *d_qkeys, u64 *d_qref) {
+    gk_ctx *ctx = m->ctx;
+    GK_HIP(ctx, hipMemsetAsync(d_cur, 0, 64 * 8, ctx->stream));
+    if (s1 > m->capacity) s1 = m->capacity;
+    if (s0 >= s1) return GK_OK;
+    const int grid = ggrid(ctx, s1 - s0);
+    if (m->W == 1) hipLaunchKernelGGL((k_dc_scan<1, true>), dim3(grid), dim3(BLOCK), 0, ctx->stream, graph_table_of<1>(m), m->k, rank, P, s0, s1, d_cur, d_off, d_qkeys, d_qref);
+    else hipLaunchKernelGGL((k_dc_scan<2, true>), dim3(grid), dim3(BLOCK), 0, ctx->stream, graph_table_of<2>(m), m->k, rank, P, s0, s1, d_cur, d_off, d_qkeys, d_qref);
+    GK_HIP(ctx, hipGetLastError());
+    return GK_OK;
+}
+int dclass_answer(gk_map *m, const u64 *d_keys, u64 n, uint8_t *d_ans) {
+    gk_ctx *ctx = m->ctx;
+    if (!n) return GK_OK;
+    if (m->W == 1) hipLaunchKernelGGL((k_dc_answer<1>), dim3(ggrid(ctx, n)), dim3(BLOCK), 0, ctx->stream, graph_table_of<1>(m), m->k, d_keys, n, d_ans);
+    else hipLaunchKernelGGL((k_dc_answer<2>), dim3(ggrid(ctx, n)), dim3(BLOCK), 0, ctx->stream, graph_table_of<2>(m), m->k, d_keys, n, d_ans);
+    GK_HIP(ctx, hipGetLastError());
+    return GK_OK;
+}
+int dclass_apply(gk_map *m, const u64 *d_qref, const uint8_t *d_ans, u64 n) {
+    gk_ctx *ctx = m->ctx;
+    if (!n) return GK_OK;
+    if (m->W == 1) hipLaunchKernelGGL((k_dc_apply<1>), dim3(ggrid(ctx, n)), dim3(BLOCK), 0, ctx->stream, graph_table_of<1>(m), d_qref, d_ans, n);
+    else hipLaunchKernelGGL((k_dc_apply<2>), dim3(ggrid(ctx, n)), dim3(BLOCK), 0, ctx->stream, graph_table_of<2>(m), d_qref, d_ans, n);
+    GK_HIP(ctx, hipGetLastError());
+    return GK_OK;
+}
+// the replica's side: annotation word of every key in d_keys := its mask.  d_err: 4 bytes of device scratch, zeroed by the caller, set
+// when a key is not in the table (cannot happen after a successful insert of the same keys)
+int map_set_masks_dev(gk_map *m, const u64 *d_keys, const uint8_t *d_masks, u64 n, u32 *d_err) {
+    gk_ctx *ctx = m->ctx;
+    if (!n) return GK_OK;
+    if (m->W == 1) hipLaunchKernelGGL((k_set_masks<1>), dim3(ggrid(ctx, n)), dim3(BLOCK), 0, ctx->stream, graph_table_of<1>(m), m->k, d_keys, d_masks, n, d_err);
+    else hipLaunchKernelGGL((k_set_masks<2>), dim3(ggrid(ctx, n)), dim3(BLOCK), 0, ctx->stream, graph_table_of<2>(m), m->k, d_keys, d_masks, n, d_err);
+    GK_HIP(ctx, hipGetLastError());
+    return GK_OK;
+}
+}  // namespace gk
 
 // Graph.components (Graph.scala:54-72): label every live node with its component's root (min-label hooking + pointer
 // jumping) and count nodes per root.  *parent / *size are hipMalloc'ed here ([n_nodes] each); the caller frees them.
@@ -2083,6 +2302,12 @@ int gk_graph_build_stats(gk_graph *g, float *phase_ms6, uint64_t *walked_bases, 
     if (phase_ms6) for (int i = 0; i < 6; i++) phase_ms6[i] = g->build_ms[i];
     if (walked_bases) *walked_bases = g->walked_bases;
     if (pointer_jumping) *pointer_jumping = g->used_pj;
+    return GK_OK;
+}
+
+int gk_graph_classified_by_owners(gk_graph *g, int *flag) {
+    if (int rc = check_graph(g)) return rc;
+    if (flag) *flag = g->used_masks;
     return GK_OK;
 }
 

@@ -18,6 +18,7 @@ struct gk_ctx {
     hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // phase boundaries of the partitioned path
     hipEvent_t gev2 = nullptr;                    // joins the second stream back into the first (striped P4/P5)
     hipEvent_t gev = nullptr;                     // "the host is back": the fine level's first launch (the GPU idles from pev[2] to here)
+    bool copy_other_pending = false;              // the copy stream carries work that touches POOLED blocks (not just uploads into staging areas): pool_free waits for it
     hipStream_t copy_stream = nullptr;            // host -> device copies that overlap kernels on `stream` (host-fed inserts)
     hipEvent_t cev[16] = {};                      // "sub-chunk j has landed" (round robin; 8..15: "piece j is scattered")
     hipStream_t aux_stream = nullptr;             // P4 of the pieces of a pipelined batch, beside the next piece's scatter on `stream`
@@ -35,6 +36,7 @@ struct gk_ctx {
                                      // a batch that outgrows the fan-out between its levels can be staged with a small table
     int hook_min_lnb1 = 0;           // test hook: tables of enough segments get at least 2^this L1 buckets (9, 10: the fan-out of tables beyond 34 GB)
     int hook_dist_small_send = 0;    // test hook: the next gk_dist_route_begin on this context gets a send buffer of so many records (forces the in-place re-route)
+    int hook_dist_fail_classify = 0; // test hook: this context's next classified gather cannot stage its queries (GK_E_CAPACITY after the sizes round)
     int hook_dist_fail = 0;          // test hook: this context's next exchange fails locally with this code before anything is posted (the peers must drop the batch too)
     int hook_dist_ahead = -1;        // gk_dist_count_routed with three batches begun: 0 = do not post the next batch's exchange ahead (every rank alike)
     int hook_p24_pieces = -1;        // pipelined batch (both levels over-provisioned): pieces whose P4 overlaps the next piece's scatter (-1: default, 0/1: off)
@@ -129,6 +131,9 @@ struct gk_map {
     bool skewed = false;         // a batch overflowed the pipeline's L1 regions and spill list (pathological skew): auto mode stays on the direct path
     bool dirty = false;          // the table may hold keys that are not the hash-rule orientation of their k-mer (verbatim inserts):
                                  // Graph.buildGraph's `contains` then probes both strands, as the reference does (Graph.scala:270)
+    bool masks_valid = false;    // every live slot's annotation word holds the (incoming, outcoming) mask its OWNER computed (gk_dist_gather_map,
+                                 // classified form): gk_graph_build then skips the neighbour lookups.  Any change of the contents clears it
+                                 // (map_sync_counters, gk_map_clear), and so does the build that consumes it.
     bool sample_dirty = false;   // the distinct-key sample holds keys: gk_map_clear must reset it
     void *d_scratch = nullptr;   // pooled device scratch of the point-query / scan entry points (get_batch, filter_lt, export)
     size_t scratch_bytes = 0;
@@ -223,11 +228,17 @@ inline size_t map_slot_bytes(const gk_map *m) { return slot_bytes(m->W, m->layou
 // table ops used across translation units
 int map_reserve(gk_map *m, uint64_t extra_keys);     // grow so that size+extra stays under the load limit
 int map_sync_counters(gk_map *m);                    // refresh m->size, detect device-side error flag
+// the classify over a PartitionedDNAMap (gk_graph.hip: k_dc_*; driven by gk_dist.hip)
+int dclass_count(gk_map *m, int rank, int P, uint64_t s0, uint64_t s1, unsigned long long *d_cnt);
+int dclass_fill(gk_map *m, int rank, int P, uint64_t s0, uint64_t s1, const unsigned long long *d_off, unsigned long long *d_cur, uint64_t *d_qkeys, uint64_t *d_qref);
+int dclass_answer(gk_map *m, const uint64_t *d_keys, uint64_t n, uint8_t *d_ans);
+int dclass_apply(gk_map *m, const uint64_t *d_qref, const uint8_t *d_ans, uint64_t n);
+int map_set_masks_dev(gk_map *m, const uint64_t *d_keys, const uint8_t *d_masks, uint64_t n, uint32_t *d_err);
 int map_materialize(gk_map *m);                      // run a deferred clear so that the slots are valid
 int map_add_keys_direct(gk_map *m, const uint64_t *d_keys, uint64_t n);   // k_add_keys on device keys (W words each)
 int map_insert_keys_dev(gk_map *m, const uint64_t *d_keys, uint64_t n, bool verbatim);
 int map_add_counted_keys_dev(gk_map *m, const uint64_t *d_keys, const int32_t *d_counts, uint64_t n);   // update(key, c, _ + c), canonical device keys   // update(key, 1, _+1) for device keys, either path
-int map_export_range_dev(gk_map *m, uint64_t s0, uint64_t s1, uint64_t *d_keys, int32_t *d_cnt, unsigned long long *d_cursor, uint64_t *n_out);
+int map_export_range_dev(gk_map *m, uint64_t s0, uint64_t s1, uint64_t *d_keys, int32_t *d_cnt, unsigned long long *d_cursor, uint64_t *n_out, uint8_t *d_masks = nullptr);
 int map_to_graph_layout(gk_map *m);                  // 8-byte keys in 12-byte count slots -> 16-byte graph slots (streaming rebuild); no-op otherwise
 int map_create_for_graph(gk_ctx *ctx, int k, uint64_t keys, gk_map **out);      // a new map sized the way the graph phase wants it
 void *map_scratch(gk_map *m, size_t bytes);          // pooled scratch (grown, never shrunk); nullptr + error set on failure

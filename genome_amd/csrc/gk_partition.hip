@@ -1791,6 +1791,7 @@ static int part_run(gk_map *m, PartScratch *ps, const ReadSrc &src, const u64 *d
             hipEvent_t ev = ctx->cev[s % 16];
             GK_HIP(ctx, hipEventRecord(ev, ctx->stream));
             GK_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ev, 0));
+            ctx->copy_other_pending = true;
             launch_p5(ctx->copy_stream, (u64)s * per * m->nb2, (u64)(s + 1) * per * m->nb2);
             GK_HIP(ctx, hipGetLastError());
         }

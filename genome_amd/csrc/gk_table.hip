@@ -359,7 +359,7 @@ __global__ __launch_bounds__(BLOCK) void k_export(const S *__restrict__ slots, u
 // `first` = index of slots[0] in its table (a multiple of the segment size: a tagged slot's last base is its index mod 4).
 template <int W, class S>
 __global__ __launch_bounds__(BLOCK) void k_export_packed(const S *__restrict__ slots, u64 n, u64 first, u32 tagged, u64 *keys, i32 *cnt,
-                                                         unsigned long long *cursor) {
+                                                         unsigned long long *cursor, uint8_t *masks = nullptr /* the annotation word's low byte (graph layout only) */) {
     __shared__ unsigned long long s_base;
     __shared__ u32 wsum[BLOCK / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -382,6 +382,7 @@ __global__ __launch_bounds__(BLOCK) void k_export_packed(const S *__restrict__ s
             if constexpr (W == 1) keys[o] = key.lo;
             else { keys[2 * o] = key.lo; keys[2 * o + 1] = key.hi; }
             cnt[o] = (i32)slot_count(&slots[i]);
+            if constexpr (!std::is_same<S, CSlot>::value) { if (masks) masks[o] = (uint8_t)slots[i].aux; }
         }
     }
 }
@@ -471,8 +472,11 @@ hipError_t pool_free(gk_ctx *ctx, void *p) {
     ctx->pool_live -= std::min(ctx->pool_live, bytes);
     // (hipFree waits for the device; a parked block may be handed out again at once, so wait for this context's work here:
     //  all three of its streams — the pipelined pieces of a batch run on the auxiliary one)
+    // The copy stream only when it carries work on pooled blocks (a route of gk_dist, a striped P5): the uploads of a host-fed
+    // count go to STAGING areas, which stage_reserve / gk_map_destroy wait for themselves — a table replaced between a batch's two
+    // levels must not wait here for the next chunk's 0.7 GB to arrive over PCIe (12 ms of C3's host-fed count, measured).
     hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess && ctx->copy_stream) e = hipStreamSynchronize(ctx->copy_stream);
+    if (e == hipSuccess && ctx->copy_stream && ctx->copy_other_pending) { e = hipStreamSynchronize(ctx->copy_stream); ctx->copy_other_pending = false; }
     if (e == hipSuccess && ctx->aux_stream) e = hipStreamSynchronize(ctx->aux_stream);
     if (e != hipSuccess || ctx->pool_held + bytes > ctx->pool_limit) {
         ctx->pool_sizes.erase(it);
@@ -524,6 +528,7 @@ int map_sync_counters(gk_map *m) {
     const Counters c = *hc;
     m->size = c.size;
     m->occ_cached = c.occurrences;
+    m->masks_valid = false;              // (every path that changes the contents ends here)
     if (c.noncanon) m->dirty = true;
     if (c.error || c.format) {
         GK_HIP(m->ctx, hipMemsetAsync(&m->d_ctr->error, 0, 2 * sizeof(u32), m->ctx->stream));
@@ -955,6 +960,7 @@ int gk_map_clear(gk_map *m) {
     m->tombstones = 0;
     m->total_occurrences = 0;
     m->dirty = false;
+    m->masks_valid = false;
     return GK_OK;
 }
 
@@ -1292,7 +1298,10 @@ static int stage_reserve(gk_map *m, int slot, size_t bytes) {
     gk_ctx *ctx = m->ctx;
     gk_map::StageSlot &st = m->stage[slot];
     if (st.cap >= bytes) return GK_OK;
-    if (st.d) GK_HIP(ctx, hipFree(st.d));
+    if (st.d) {
+        GK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));        // (an upload into this area may be in flight: pool_free does not wait for those)
+        GK_HIP(ctx, hipFree(st.d));
+    }
     st.d = nullptr; st.cap = 0;
     GK_HIP(ctx, hipMalloc(&st.d, bytes));
     st.cap = bytes;
@@ -1530,16 +1539,17 @@ int map_add_counted_keys_dev(gk_map *m, const uint64_t *d_keys, const int32_t *d
     return n ? add_keys_dev(m, d_keys, d_counts, n) : GK_OK;
 }
 // the live (key, count) of slots [s0, s1) of m, packed into d_keys (W words per key) / d_cnt; d_cursor: 8 bytes of device scratch
-int map_export_range_dev(gk_map *m, uint64_t s0, uint64_t s1, uint64_t *d_keys, int32_t *d_cnt, unsigned long long *d_cursor, uint64_t *n_out) {
+int map_export_range_dev(gk_map *m, uint64_t s0, uint64_t s1, uint64_t *d_keys, int32_t *d_cnt, unsigned long long *d_cursor, uint64_t *n_out, uint8_t *d_masks) {
     gk_ctx *ctx = m->ctx;
     *n_out = 0;
+    if (d_masks && m->W == 1 && m->layout != LAYOUT_GRAPH) return fail(ctx, GK_E_STATE, "masks of a count-layout table");
     if (s1 > m->capacity) s1 = m->capacity;
     if (s0 >= s1) return GK_OK;
     if (int rc = map_materialize(m)) return rc;
     GK_HIP(ctx, hipMemsetAsync(d_cursor, 0, 8, ctx->stream));
     const int grid = grid_for(ctx, s1 - s0, BLOCK);
     GK_BY_SLOT(m, hipLaunchKernelGGL((k_export_packed<W, S>), dim3(grid), dim3(BLOCK), 0, ctx->stream, (const S *)m->slots + s0, s1 - s0, s0, m->k == 64 ? 1u : 0u, d_keys,
-                                     d_cnt, d_cursor));
+                                     d_cnt, d_cursor, d_masks));
     GK_HIP(ctx, hipGetLastError());
     unsigned long long n = 0;
     GK_HIP(ctx, hipMemcpyAsync(&n, d_cursor, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1792,6 +1802,7 @@ static int filter_compact_streaming(gk_map *m, int32_t rounds, bool *done) {
 int gk_map_filter_lt(gk_map *m, int32_t rounds) {
     if (int rc = check_map(m)) return rc;
     gk_ctx *ctx = m->ctx;
+    m->masks_valid = false;
     {
         bool done = false;
         if (int rc = filter_compact_streaming(m, rounds, &done)) return rc;

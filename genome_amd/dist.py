@@ -113,8 +113,17 @@ class DistDNAMap:
     def deleteAll_lt(self, rounds: int):                      # :49-51 — local on every rank
         self.local.deleteAll_lt(rounds)
 
-    def gathered(self) -> HipDNAMap:
-        """every partition's survivors in one table on this rank (what Graph.buildGraph needs)"""
+    def gathered(self, classified: bool = False) -> HipDNAMap:
+        """every partition's survivors in one table on this rank (what Graph.buildGraph needs).  classified: the keys' owners
+        classify them first (Graph.scala:320-329 on every partition, PartitionedDNAMap.scala:55-58: local lookups + one query
+        all-to-all) and the degree masks travel with the keys — buildGraph on the result then skips its neighbour lookups."""
         h = L.vp()
-        L.check(L.lib().gk_dist_gather_map(self.dist.h, self.local.h, C.byref(h)), self.ctx.h)
+        f = L.lib().gk_dist_gather_classified_map if classified else L.lib().gk_dist_gather_map
+        L.check(f(self.dist.h, self.local.h, C.byref(h)), self.ctx.h)
         return HipDNAMap.adopt(self.ctx, self.k, h)
+
+    def classify_queries(self) -> int:
+        """neighbour lookups this rank has asked of other ranks in classified gathers"""
+        n = C.c_uint64()
+        L.check(L.lib().gk_dist_classify_queries(self.dist.h, C.byref(n)), self.ctx.h)
+        return n.value

@@ -90,8 +90,10 @@ class HipGraph:
         names = ("classify", "make_nodes", "unitig_measure", "reserve_pool", "unitig_emit", "index_counts")
         mb_ms, mb_slots = C.c_float(), C.c_uint64()
         L.check(L.lib().gk_graph_bucketed_table_stats(self.h, C.byref(mb_ms), C.byref(mb_slots)), self.ctx.h)
+        by_owners = C.c_int()
+        L.check(L.lib().gk_graph_classified_by_owners(self.h, C.byref(by_owners)), self.ctx.h)
         return {"phase_ms": {n_: float(x) for n_, x in zip(names, ms)}, "walked_bases": bases.value, "pointer_jumping": bool(pj.value),
-                "bucketed_table": {"build_ms": float(mb_ms.value), "slots": mb_slots.value}}
+                "bucketed_table": {"build_ms": float(mb_ms.value), "slots": mb_slots.value}, "classified_by_owners": bool(by_owners.value)}
 
     # ---- GraphSimplifier's tools: the position map, ids, point edits ----------------------------
     def getGraphMap(self, capacity_hint: int = 0):         # Graph.scala:90-119

@@ -291,6 +291,17 @@ int gk_dist_size(gk_dist *d, gk_map *local, uint64_t *total);         /* Partiti
  * that to receive), into a NEW map (*full, caller destroys it) sized the way the graph phase wants it.  A rank that fails
  * says so in the chunk's size word: every rank then returns an error for the same chunk and nobody waits in a receive. */
 int gk_dist_gather_map(gk_dist *d, gk_map *local, gk_map **full);
+/* The same gather with the classify of Graph.buildGraph done by the keys' OWNERS first (Graph.scala:320-329 shipped to every
+ * partition, PartitionedDNAMap.scala:55-58; SURVEY.md section 8e "beyond counting"): every rank looks up the neighbours it owns
+ * in its own partition and asks the other neighbours of their owners (per chunk: one all-to-all of canonical keys, one of answer
+ * bytes), and each key's (incoming, outcoming) mask travels with it into *full.  gk_graph_build on *full then derives the
+ * terminal k-mers from the masks in one streaming pass — the eight lookups per key are done once in the whole job instead of once
+ * per rank.  The masks serve the FIRST gk_graph_build on *full; any change of its contents drops them (plain classify again).
+ * Partitions that hold verbatim non-canonical keys on any rank: plain gather on every rank.  `local` is left in the graph
+ * layout; its contents are unchanged.  Same failure behaviour as gk_dist_gather_map. */
+int gk_dist_gather_classified_map(gk_dist *d, gk_map *local, gk_map **full);
+/* neighbour lookups this rank has asked of other ranks in classified gathers since the handle was created */
+int gk_dist_classify_queries(gk_dist *d, uint64_t *n);
 
 /* ---- Graph: S/data/graph/Graph.scala ------------------------------------------------------- */
 /* Graph.buildGraph(k, kmersFreq) (:269-382): degree classification of every live key through
@@ -322,6 +333,9 @@ int gk_graph_build_stats(gk_graph *g, float *phase_ms6, uint64_t *walked_bases, 
 /* When gk_graph_build ran on a minimizer-bucketed copy of the table (gk_ctx_set_option "graph_mbt" = 1): wall ms of building the
  * copy and its slots; 0 / 0 otherwise.  Diagnostics of an A/B switch. */
 int gk_graph_bucketed_table_stats(gk_graph *g, float *build_ms, uint64_t *slots);
+/* *flag = 1 when gk_graph_build took the degree masks that came with the table (gk_dist_gather_classified_map) instead of
+ * running the neighbour lookups itself */
+int gk_graph_classified_by_owners(gk_graph *g, int *flag);
 /* Graph.getGraphMap (Graph.scala:90-119): putNew of every node's k-mer -> NodeGraphPosition(node id) and of the k-mers at
  * distance 1 .. len-1 along every edge -> EdgeGraphPosition(edge id, dist) into `vm` (same k, same context).  *entries =
  * number of entries added = sum of edge lengths + nodes - edges (the reference prints both side by side, :117; here the

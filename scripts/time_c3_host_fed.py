@@ -25,13 +25,15 @@ names = ["hist1", "P2", "P3", "P4", "P5"]
 keys = ("partitioned_launches", "direct_launches", "grows", "slots")
 
 
-def run(label, f, reps=2):
+def run(label, f, reps=2, filter_first=False):
     best = None
     for _ in range(reps):
+        if filter_first:
+            m.deleteAll_lt(3)          # what bench.py's legs do between counts: the table is rebuilt for the survivors, the next count re-creates it
         m.clear(); ctx.sync()
         t0 = time.perf_counter(); f(); ctx.sync(); ms = (time.perf_counter() - t0) * 1e3
         st = m.stats()
-        row = {"what": label, "count_ms": round(ms, 2), "phases_ms": dict(zip(names, [round(x, 2) for x in m.last_phase_ms()])),
+        row = {"what": label, "count_ms": round(ms, 2), "phases_ms": dict(zip(names, [round(x, 2) for x in m.last_phase_ms()])), "gap_ms": st.get("gap_ms"),
                **{k_: st[k_] for k_ in keys if k_ in st}}
         if best is None or ms < best["count_ms"]:
             best = row
@@ -49,3 +51,6 @@ for label, opts in variants:
     run(label, lambda: m.count_reads(hbuf, N))
     for name in opts:
         ctx.set_option(name, -1 if name == "host_prefetch" else 0)
+run("device-resident after filter_lt", lambda: m.count_reads_dev(d, N, L), reps=3, filter_first=True)
+run("host default after filter_lt", lambda: m.count_reads(hbuf, N), reps=3, filter_first=True)
+print(json.dumps(ctx.mem_stats()))

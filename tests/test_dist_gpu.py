@@ -283,3 +283,91 @@ def test_a_send_region_that_is_too_small_is_routed_again_in_place():
         assert tot == [float(occ), float(occ)]
         for a, b in zip(items, want):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("world,k,L_", [(1, 31, 150), (2, 31, 150), (3, 55, 150), (8, 21, 100), (2, 64, 150)])
+def test_classify_by_the_owners_gives_the_same_graph(world, k, L_):
+    """SURVEY.md 8(e) "beyond counting" (Graph.scala:320-329 through PartitionedDNAMap.mapReduce :55-58): in the classified
+    gather every rank classifies ITS keys — own neighbours looked up locally, the others asked of their owners in one query
+    all-to-all per chunk — and the masks travel with the keys.  On every rank: the gathered table is the oracle's, buildGraph on
+    it takes the masks (no neighbour lookups: classified_by_owners), and the graph is the oracle's node for node and base for
+    base, the same as from the plain gather; ranks > 1 did ask their peers."""
+    n = 12000
+    rec = synth.reads_mode_g(n * world, L_, 30000 * world, 0.01, config_id=1100 + k)
+    stride = rec.shape[1]
+    ref = O.PMap(k, 1)
+    ref.count_reads(rec.tobytes(), n * world)
+    ref.delete_lt(2)
+    want = ref.export_sorted()
+    want_graph = oracle_canonical(O.Graph(ref))
+
+    def body(rank, c, hd):
+        pm = DistDNAMap(hd, k, 1 << 10)
+        d = c.alloc(n * stride + 64)
+        c.upload(d, rec[rank * n:(rank + 1) * n])
+        pm.count_reads_dev(d, n, L_)
+        pm.deleteAll_lt(2)
+        local_items = pm.local.sorted_items()
+        full = pm.gathered(classified=True)
+        assert all(np.array_equal(a, b) for a, b in zip(pm.local.sorted_items(), local_items))      # the partition is unchanged
+        items = full.sorted_items()
+        g = buildGraph(k, full)
+        st = g.buildStats()
+        canon, chk = g.canonical(), (g.counts(), g.checksum())
+        g2 = buildGraph(k, full)                          # the masks served one build: this one classifies by itself
+        st2 = g2.buildStats()
+        chk2 = (g2.counts(), g2.checksum())
+        plain = pm.gathered()
+        g3 = buildGraph(k, plain)
+        res = (items, canon, chk, chk2, (g3.counts(), g3.checksum()), st["classified_by_owners"], st2["classified_by_owners"],
+               g3.buildStats()["classified_by_owners"], pm.classify_queries(), pm.local.size())
+        g.close(); g2.close(); g3.close(); full.close(); plain.close(); pm.close(); c.free(d)
+        return res
+
+    out = _run_ranks(world, body)
+    assert sum(o[9] for o in out) == len(want[0])
+    for items, canon, chk, chk2, chk3, by_owners, by_owners2, by_owners3, queries, _ in out:
+        for a, b in zip(items, want):
+            assert np.array_equal(a, b)
+        assert canon == want_graph
+        assert chk == chk2 == chk3
+        assert by_owners and not by_owners2 and not by_owners3
+        assert (queries > 0) == (world > 1)
+    if world > 1:          # most neighbours share their k-mer's minimizer, hence its owner: far fewer than 8 questions per key
+        assert sum(o[8] for o in out) < 4 * len(want[0])
+
+
+def test_classified_gather_when_one_rank_cannot_stage_its_queries():
+    """A failure on ONE rank inside the classified gather (injected: the staging of its queries cannot be allocated) is agreed
+    on before anybody posts a receive: every rank returns an error from the same call, nobody hangs, and a plain gather right
+    after it works."""
+    world, k, L_, n = 3, 31, 120, 9000
+    rec = synth.reads_mode_g(n * world, L_, 40000, 0.01, config_id=1177)
+    stride = rec.shape[1]
+    ref = O.PMap(k, 1)
+    ref.count_reads(rec.tobytes(), n * world)
+    want = ref.export_sorted()
+
+    def body(rank, c, hd):
+        pm = DistDNAMap(hd, k, 1 << 10)
+        d = c.alloc(n * stride + 64)
+        c.upload(d, rec[rank * n:(rank + 1) * n])
+        pm.count_reads_dev(d, n, L_)
+        if rank == 2:
+            c.set_option("test_dist_fail_classify", 1)
+        err = None
+        try:
+            pm.gathered(classified=True).close()
+        except L.GkError as e:
+            err = (e.code, str(e))
+        full = pm.gathered()
+        items = full.sorted_items()
+        full.close(); pm.close(); c.free(d)
+        return err, items
+
+    for rank, (err, items) in enumerate(_run_ranks(world, body)):
+        assert err is not None, rank
+        assert ("injected" in err[1]) == (rank == 2), (rank, err)
+        assert err[0] == (L.GK_E_CAPACITY if rank == 2 else L.GK_E_COMM)
+        for a, b in zip(items, want):
+            assert np.array_equal(a, b)
