@@ -1136,26 +1136,30 @@ __global__ __launch_bounds__(BLOCK) void k_cc_init(GraphView g, u32 *parent) {
 // only ever go to smaller ids, so there are no cycles, a stale read is an older ancestor (a longer walk, never a wrong one),
 // and the root a component ends with is its smallest node id — the label the round-2 form (min-label hooking + full
 // compression, repeated until nothing moved: 5-7 rounds of two kernels and a host round trip each, 7 ms at C3) converged to.
-__device__ __forceinline__ u32 cc_find_halve(u32 *parent, u32 v) {
+// V = how a find shortens the paths it walks (A/B, "cc_find": 0 = path halving, every hop writes; 1 = nothing is written;
+// 2 = only the node the find started from is pointed at the root it found)
+template <int V> __device__ __forceinline__ u32 cc_find(u32 *parent, u32 v) {
+    const u32 v0 = v;
     u32 p = parent[v];
     while (p != v) {
         const u32 gp = parent[p];
-        if (gp == p) return p;
-        parent[v] = gp;                 // (v is not a root and never becomes one again: no CAS targets this word)
+        if (gp == p) { v = p; break; }
+        if (V == 0) parent[v] = gp;     // (v is not a root and never becomes one again: no CAS targets this word)
         v = gp; p = parent[v];
     }
+    if (V == 2 && v != v0 && parent[v0] != v) parent[v0] = v;
     return v;
 }
-__global__ __launch_bounds__(BLOCK) void k_cc_link(GraphView g, u32 *parent) {
+template <int V> __global__ __launch_bounds__(BLOCK) void k_cc_link(GraphView g, u32 *parent) {
     for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < g.n_edges; e += (u64)gridDim.x * BLOCK) {
         if (!g.e_alive[e]) continue;
-        u32 ru = cc_find_halve(parent, g.e_start[e]), rv = cc_find_halve(parent, g.e_end[e]);
+        u32 ru = cc_find<V>(parent, g.e_start[e]), rv = cc_find<V>(parent, g.e_end[e]);
         while (ru != rv) {
             if (ru < rv) { const u32 x = ru; ru = rv; rv = x; }
             const u32 old = atomicCAS(&parent[ru], ru, rv);
             if (old == ru) break;
-            ru = cc_find_halve(parent, old);
-            rv = cc_find_halve(parent, rv);
+            ru = cc_find<V>(parent, old);
+            rv = cc_find<V>(parent, rv);
         }
     }
 }
@@ -2181,7 +2185,9 @@ static int graph_components(gk_graph *g, u32 **parent_out, u32 **size_out, u64 *
     if (e != hipSuccess) return bail(hip_fail(ctx, e, "graph components: alloc"));
     const int gn = ggrid(ctx, std::max<u64>(v.n_nodes, 1)), ge = ggrid(ctx, std::max<u64>(v.n_edges, 1));
     hipLaunchKernelGGL(k_cc_init, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, parent);
-    hipLaunchKernelGGL(k_cc_link, dim3(ge), dim3(BLOCK), 0, ctx->stream, v, parent);
+    if (ctx->hook_cc_find == 1) hipLaunchKernelGGL(k_cc_link<1>, dim3(ge), dim3(BLOCK), 0, ctx->stream, v, parent);
+    else if (ctx->hook_cc_find == 2) hipLaunchKernelGGL(k_cc_link<2>, dim3(ge), dim3(BLOCK), 0, ctx->stream, v, parent);
+    else hipLaunchKernelGGL(k_cc_link<0>, dim3(ge), dim3(BLOCK), 0, ctx->stream, v, parent);
     e = hipGetLastError();
     if (e != hipSuccess) return bail(hip_fail(ctx, e, "graph components: hooking"));
     unsigned long long h = 0;

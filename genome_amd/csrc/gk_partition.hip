@@ -1052,10 +1052,11 @@ template <> struct LdsSlotOf<CSlot> { typedef Slot<1> type; };
 //   in:  the 24-KiB image is staged at the END of the 32-KiB area (bytes 8192 ..), then expanded slot by slot in four rounds of
 //        512 slots, ascending: expanded slot s lands on bytes 16s .., which hold raw slots below 4s/3 - 681 only — consumed in an
 //        earlier round or, within the round, before the barrier that separates its reads from its writes.
+// field f of the 12-byte form of a 16-byte slot.  No branches: a key is below 2^62, EMPTY / TOMB are ~0 and ~0 - 1, so bit 63
+// tells them apart — their low word IS the 32-bit sentinel and (w0 >> 31) truncates to ~0
 __device__ __forceinline__ u32 cfield(const Slot<1> &x, u32 f) {
-    const bool special = x.w0 >= KEY_TOMB;
-    if (f == 0u) return special ? (x.w0 == KEY_EMPTY ? KEY_EMPTY32 : KEY_TOMB32) : (u32)x.w0 & 0x7fffffffu;
-    if (f == 1u) return special ? KEY_EMPTY32 : (u32)(x.w0 >> 31);
+    if (f == 0u) return (u32)x.w0 & ((u32)((i32)(x.w0 >> 32) >> 31) | 0x7fffffffu);
+    if (f == 1u) return (u32)(x.w0 >> 31);
     return x.extra;
 }
 __device__ __forceinline__ uint4 cslot_vec_from_lds(const Slot<1> *seg, u32 v) {

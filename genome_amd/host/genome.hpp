@@ -217,10 +217,11 @@ class PartitionedDNAMap {
         return n;
     }
     void deleteAll(ValueLessThan p) { local_.deleteAll(p); }      // :49-51 — every partition filters its own keys
-    // every partition's keys in one table on this rank: what Graph.buildGraph needs
-    DNAMap gathered() {
+    // every partition's keys in one table on this rank: what Graph.buildGraph needs.  classified: the keys' owners
+    // classify them first (Graph.scala:320-329 on every partition, :55-58) and the degree masks travel with the keys
+    DNAMap gathered(bool classified = false) {
         gk_map *full = nullptr;
-        check(gk_dist_gather_map(d_, local_.handle(), &full), ctx_.handle());
+        check(classified ? gk_dist_gather_classified_map(d_, local_.handle(), &full) : gk_dist_gather_map(d_, local_.handle(), &full), ctx_.handle());
         return DNAMap(ctx_, local_.k(), full);
     }
     void barrier() { check(gk_dist_barrier(d_), ctx_.handle()); }
