@@ -156,8 +156,18 @@ def _graph_stage(ctx, pm, k, budget, tag):
         dist = HipDist(ctx, 0, 1, unique_id())
         dm = DistDNAMap.__new__(DistDNAMap)
         dm.dist, dm.ctx, dm.k, dm.local = dist, ctx, k, pm.parts[0]
-        own = dm.gathered()
+        #      in its CLASSIFIED form: the partition's keys are classified by their owner (here: all by this rank) and the masks travel
+        #      with them; the graph buildGraph derives from the masks must be the graph it derives by its own neighbour lookups
+        own = dm.gathered(classified=True)
         assert own.verify_checksum() == pm.parts[0].verify_checksum()
+        g1 = buildGraph(k, own)
+        assert g1.buildStats()["classified_by_owners"]
+        by_masks = (g1.counts(), g1.checksum())
+        g1.close()
+        g2 = buildGraph(k, own)                                   # (the masks served one build)
+        assert not g2.buildStats()["classified_by_owners"]
+        assert by_masks == (g2.counts(), g2.checksum()) and by_masks[0][0] > 0
+        g2.close()
         own.close(); dist.close(); ctx.trim()
         ctx.mem_stats(reset_peak=True)
         # ---- the replica: every partition's survivors in one table sized for the graph phase
