@@ -371,3 +371,49 @@ def test_classified_gather_when_one_rank_cannot_stage_its_queries():
         assert err[0] == (L.GK_E_CAPACITY if rank == 2 else L.GK_E_COMM)
         for a, b in zip(items, want):
             assert np.array_equal(a, b)
+
+
+def test_classified_gather_steps_back_when_a_partition_holds_noncanonical_keys():
+    """Verbatim inserts (gk_map_update_inc) may leave a key that is not the hash-rule orientation of its k-mer in ONE rank's
+    partition: `contains` must then probe both strands everywhere (Graph.scala:270), which the owners' masks do not promise.
+    Every rank takes the same decision — plain gather, buildGraph classifies by itself — and the graph is the oracle's for the
+    same table."""
+    world, k, L_, n = 2, 31, 120, 8000
+    rec = synth.reads_mode_g(n * world, L_, 30000, 0.01, config_id=1190)
+    stride = rec.shape[1]
+    ref = O.PMap(k, 1)
+    ref.count_reads(rec.tobytes(), n * world)
+    ref.delete_lt(2)
+    lo, hi, _ = ref.export_sorted()
+    # the reverse complements of a few keys that rank 1 owns (x and rc(x) share their owner), inserted verbatim there
+    flip = []
+    for a, b in zip(lo.tolist(), hi.tolist()):
+        if L.lib().gk_owner_of(k, a, b, world) == 1:
+            s = dna.unpack(a, b, k)
+            if dna.rev_complement(s) != s:
+                flip.append(dna.rev_complement(s))
+        if len(flip) == 40:
+            break
+    for s in flip:
+        plo, phi = dna.pack(s)
+        ref.update_inc(plo, phi)
+    want_graph = oracle_canonical(O.Graph(ref))
+
+    def body(rank, c, hd):
+        pm = DistDNAMap(hd, k, 1 << 10)
+        d = c.alloc(n * stride + 64)
+        c.upload(d, rec[rank * n:(rank + 1) * n])
+        pm.count_reads_dev(d, n, L_)
+        pm.deleteAll_lt(2)
+        if rank == 1:
+            pm.local.update_inc(flip)
+            assert pm.local.stats()["noncanonical_keys"] is True
+        full = pm.gathered(classified=True)
+        g = buildGraph(k, full)
+        res = (g.buildStats()["classified_by_owners"], g.canonical(), full.stats()["noncanonical_keys"])
+        g.close(); full.close(); pm.close(); c.free(d)
+        return res
+
+    for by_owners, canon, dirty in _run_ranks(world, body):
+        assert not by_owners and dirty
+        assert canon == want_graph
