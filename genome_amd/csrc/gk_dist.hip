@@ -593,16 +593,21 @@ static int dist_gather(gk_dist *d, gk_map *local, gk_map **full, bool classify) 
     if (classify) { pre_rc = map_to_graph_layout(local); if (pre_rc) pre_err = ctx->err; }
     constexpr u64 CHS = 1ull << 25;
     // live keys of every rank, and the number of chunks of the rank with the largest table
-    unsigned long long mine[3] = {local->size, (local->capacity + CHS - 1) / CHS, (classify && !local->dirty) ? 0ull : 1ull};
-    GK_HIP(ctx, hipMemcpyAsync(d->d_cnt + 2 * 64, mine, 24, hipMemcpyHostToDevice, ctx->stream));
+    // (one maximum over all ranks carries both: the number of chunks in its low 32 bits, "some partition holds verbatim
+    //  non-canonical keys" above them — the replica holds every partition's keys, so it is dirty if ANY of them is)
+    unsigned long long mine[2] = {local->size, ((local->capacity + CHS - 1) / CHS) | (local->dirty ? 1ull << 40 : 0ull)};
+    GK_HIP(ctx, hipMemcpyAsync(d->d_cnt + 2 * 64, mine, 16, hipMemcpyHostToDevice, ctx->stream));
     GK_NCCL(ctx, xAllGather(d, d->d_cnt + 2 * 64, d->d_cnt, 1, ncclUint64, ctx->stream));
     GK_NCCL(ctx, xAllReduce(d, d->d_cnt + 2 * 64 + 1, d->d_cnt + 64, 1, ncclUint64, ncclMax, ctx->stream));
+    unsigned long long chunks_only = (local->capacity + CHS - 1) / CHS;
+    GK_HIP(ctx, hipMemcpyAsync(d->d_cnt + 2 * 64 + 2, &chunks_only, 8, hipMemcpyHostToDevice, ctx->stream));
     GK_NCCL(ctx, xAllReduce(d, d->d_cnt + 2 * 64 + 2, d->d_cnt + 65, 1, ncclUint64, ncclMax, ctx->stream));
     GK_HIP(ctx, hipMemcpyAsync(d->h_cnt, d->d_cnt, (64 + 2) * 8, hipMemcpyDeviceToHost, ctx->stream));
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     u64 total = 0;
-    const u64 nchunks = d->h_cnt[64];
-    classify = classify && d->h_cnt[65] == 0;          // (every rank takes the same decision: the word is a maximum over all of them)
+    const u64 nchunks = d->h_cnt[65];
+    const bool any_dirty = (d->h_cnt[64] >> 40) != 0;
+    classify = classify && !any_dirty;                 // (every rank takes the same decision: the word is a maximum over all of them)
     for (int p = 0; p < P; p++) total += d->h_cnt[p];
     if (d->h_cnt[d->rank] != mine[0]) return fail(ctx, GK_E_COMM, "gk_dist_gather_map: size exchange is inconsistent");
     gk_map *m = nullptr;
@@ -812,7 +817,7 @@ static int dist_gather(gk_dist *d, gk_map *local, gk_map **full, bool classify) 
     }
     if (int rc = map_sync_counters(m)) return done(rc);
     if (m->size != total) return done(fail(ctx, GK_E_STATE, "gk_dist_gather_map: gathered " + std::to_string(m->size) + " keys, the partitions hold " + std::to_string(total)));
-    m->dirty = local->dirty;
+    m->dirty = any_dirty;
     m->masks_valid = classify;           // (set after the last map_sync_counters of this table: any later change of its contents clears it)
     *full = m;
     return done(GK_OK);

@@ -1143,11 +1143,14 @@ static u64 reads_per_launch(gk_map *m, u64 nk) {
 // next to what is free in HBM — half of it at most — and by 16 GiB of keys per buffer (gk_map_set_max_batch_keys changes
 // that).  Big batches pay: every batch after the first streams the whole table in and out again
 static u64 part_batch_keys(gk_map *m) {
-    // (default: key buffers of 16 GiB — hipMalloc of much larger ones takes seconds: 54 GB measured at ~1 s)
+    // (default: key buffers of 16 GiB — hipMalloc of much larger ones takes seconds the first time — OR scratch as large as
+    //  the table itself, whichever is more: behind a 74 GB table every further batch of a call streams those 74 GB in and out
+    //  again, 25 ms each; k = 55, 1.9e9 windows: 101 ms in two batches, 70 in one — profiles/r03/big_table_74GB_k55.json)
+    const double per_key = 8.0 * m->W * (1.125 + 1.0 + 1.0 / 16) + 1.0;      // bufA + bufB + spill (+ range matrix, bounded above)
     u64 cap = m->max_batch_keys ? m->max_batch_keys : (1ull << 31) / (u64)m->W;
+    if (!m->max_batch_keys) cap = std::max<u64>(cap, (u64)((double)m->capacity * (double)map_slot_bytes(m) / per_key));
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-        const double per_key = 8.0 * m->W * (1.125 + 1.0 + 1.0 / 16) + 1.0;      // bufA + bufB + spill (+ range matrix, bounded above)
         // the scratch a previous batch left allocated is reused, so it counts as available: approximate by a share of the whole card
         // (a caller-set memory budget replaces the card's size)
         const double whole = m->ctx->mem_budget ? (double)m->ctx->mem_budget : (double)total_b;
