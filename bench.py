@@ -204,14 +204,14 @@ def c3_object(ctx):
                                               "time also holds the rebuild into a table sized for the survivors); 80 B/live key classify; 9.25 B/walked base"}}
     # what the memory system carried for the graph kernels, from the committed PMC passes over this same flow (every read request is
     # a 128-byte line, also for a 16-byte random probe: the algorithmic fractions above understate how busy HBM is)
-    pmc = os.path.join(ROOT, "profiles", "r03", "pmc_c3.json")
-    if not os.path.exists(pmc):
-        pmc = os.path.join(ROOT, "profiles", "r02", "pmc_c3_v11.json")
+    import glob as _glob
+    cands = sorted(_glob.glob(os.path.join(ROOT, "profiles", "r03", "pmc_c3_*.json")))
+    pmc = cands[-1] if cands else os.path.join(ROOT, "profiles", "r02", "pmc_c3_v11.json")
     if res is not None and os.path.exists(pmc):
         k_ = json.load(open(pmc))["kernels"]
         res["roofline"]["moved_by_pmc"] = {name: {"fetch_bytes": k_[name]["fetch_bytes"], "write_bytes": k_[name]["write_bytes"], "ms": k_[name]["total_ms"],
                                                    "frac_of_hbm_peak": k_[name]["moved_frac_of_hbm_peak"]}
-                                            for name in ("k_classify<1>", "k_walk_q<1>", "k_filter_lt<1>", "k_rehash<1>") if name in k_}
+                                            for name in ("k_classify<1>", "k_walk_q<1>", "k_compact_seg<1>", "k_filter_lt<1>", "k_rehash<1>", "k_cc_link") if name in k_}
         res["roofline"]["moved_by_pmc"]["source"] = os.path.relpath(pmc, ROOT)
     # the same count from PINNED HOST memory (1.95 GB of `.bin` -> filtered table): the stream is cut where the device-resident count cuts
     # its batches, the first chunk's upload overlaps its own L1 scatter piece by piece, every later chunk's upload runs beside the

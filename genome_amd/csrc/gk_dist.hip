@@ -616,7 +616,6 @@ static int dist_gather(gk_dist *d, gk_map *local, gk_map **full, bool classify) 
     unsigned long long *d_cur = nullptr;
     uint8_t *d_send_m = nullptr, *d_recv_m = nullptr;                  // classified form: the masks beside the keys
     unsigned long long *d_dc = nullptr;                                // [5][64]: counts to send | counts received | remote counts | region offsets | cursors
-    u32 *d_err = nullptr;
     u64 *d_qk = nullptr, *d_qref = nullptr, *d_rk = nullptr;           // queries out (keys, who asked), queries in
     uint8_t *d_ans_in = nullptr, *d_ans_out = nullptr;                 // answers to my queries, my answers to the others'
     u64 q_out_cap = 0, q_in_cap = 0;
@@ -624,7 +623,7 @@ static int dist_gather(gk_dist *d, gk_map *local, gk_map **full, bool classify) 
     // hence no local failure, between a chunk's size exchange and its sends and receives
     const u64 recv_cap = std::max<u64>(std::min<u64>(total, (u64)P * CHS), 1);
     auto done = [&](int code) {
-        for (void *p : {(void *)d_send_k, (void *)d_send_c, (void *)d_recv_k, (void *)d_recv_c, (void *)d_cur, (void *)d_send_m, (void *)d_recv_m, (void *)d_dc, (void *)d_err,
+        for (void *p : {(void *)d_send_k, (void *)d_send_c, (void *)d_recv_k, (void *)d_recv_c, (void *)d_cur, (void *)d_send_m, (void *)d_recv_m, (void *)d_dc,
                         (void *)d_qk, (void *)d_qref, (void *)d_rk, (void *)d_ans_in, (void *)d_ans_out}) if (p) (void)hipFree(p);
         if (code != GK_OK && m) { gk_map_destroy(m); m = nullptr; }
         return code;
@@ -643,8 +642,6 @@ static int dist_gather(gk_dist *d, gk_map *local, gk_map **full, bool classify) 
         if (e == hipSuccess && classify) e = hipMalloc((void **)&d_send_m, std::max<u64>(send_cap, 1));
         if (e == hipSuccess && classify) e = hipMalloc((void **)&d_recv_m, recv_cap);
         if (e == hipSuccess && classify) e = hipMalloc((void **)&d_dc, 5 * 64 * 8);
-        if (e == hipSuccess && classify) e = hipMalloc((void **)&d_err, 4);
-        if (e == hipSuccess && classify) e = hipMemsetAsync(d_err, 0, 4, ctx->stream);
         if (e != hipSuccess) { my_rc = hip_fail(ctx, e, "gk_dist_gather_map: staging"); my_err = ctx->err; }
     }
 #define HIPD(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return done(hip_fail(ctx, e__, #call)); } while (0)
@@ -794,15 +791,9 @@ static int dist_gather(gk_dist *d, gk_map *local, gk_map **full, bool classify) 
             if (grc != ncclSuccess) return done(fail(ctx, GK_E_COMM, std::string("gk_dist_gather_map: ") + comm_error_text(grc)));
         }
         // one table holding every partition's keys (each key has exactly one owner: nothing merges)
-        my_rc = map_add_counted_keys_dev(m, d_recv_k, d_recv_c, tot_c);
-        if (!my_rc && classify) my_rc = map_set_masks_dev(m, d_recv_k, d_recv_m, tot_c, d_err);
+        // (each key has exactly one owner and the table was created for all of them: one CAS per key, count and mask beside it)
+        my_rc = map_add_unique_keys_dev(m, d_recv_k, d_recv_c, classify ? d_recv_m : nullptr, tot_c);
         if (my_rc) my_err = ctx->err;
-    }
-    if (classify && !my_rc) {           // a mask whose key the replica does not hold: cannot happen after the inserts above succeeded
-        u32 h_err = 0;
-        HIPD(hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPD(hipStreamSynchronize(ctx->stream));
-        if (h_err) { my_rc = GK_E_STATE; my_err = "gk_dist_gather_map: a gathered key is missing from the replica"; }
     }
     // the last chunk's insert may have failed after its word went out: agree on the outcome once more
     {

@@ -322,19 +322,7 @@ __global__ __launch_bounds__(BLOCK) void k_dc_apply(Table<W> t, const u64 *__res
         atomicOr(&t.slots[ref >> 3].aux, (j & 1) ? 16u << (j >> 1) : 1u << (j >> 1));
     }
 }
-// the replica: every gathered key's annotation word := the mask its owner computed
-template <int W>
-__global__ __launch_bounds__(BLOCK) void k_set_masks(Table<W> t, int k, const u64 *__restrict__ keys, const uint8_t *__restrict__ masks, u64 n, u32 *err) {
-    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
-        Kmer<W> x;
-        if constexpr (W == 1) x = Kmer<1>{keys[i]};
-        else x = Kmer<2>{keys[2 * i], keys[2 * i + 1]};
-        const i64 s = table_find(t, x, k);
-        if (s < 0) { *err = 1; continue; }
-        t.slots[s].aux = masks[i];
-    }
-}
-// ... and what k_classify derives from the masks (terminal, the SECONDARY mark of a hash-rule tie, the count of terminal k-mers)
+// what k_classify derives from the masks that came with a gathered table (terminal, the SECONDARY mark of a hash-rule tie, the count of terminal k-mers)
 template <int W>
 __global__ __launch_bounds__(BLOCK) void k_finish_masks(Table<W> t, int k, unsigned long long *n_term) {
     __shared__ u32 s_cnt;
@@ -2153,16 +2141,6 @@ int dclass_apply(gk_map *m, const u64 *d_qref, const uint8_t *d_ans, u64 n) {
     if (!n) return GK_OK;
     if (m->W == 1) hipLaunchKernelGGL((k_dc_apply<1>), dim3(ggrid(ctx, n)), dim3(BLOCK), 0, ctx->stream, graph_table_of<1>(m), d_qref, d_ans, n);
     else hipLaunchKernelGGL((k_dc_apply<2>), dim3(ggrid(ctx, n)), dim3(BLOCK), 0, ctx->stream, graph_table_of<2>(m), d_qref, d_ans, n);
-    GK_HIP(ctx, hipGetLastError());
-    return GK_OK;
-}
-// the replica's side: annotation word of every key in d_keys := its mask.  d_err: 4 bytes of device scratch, zeroed by the caller, set
-// when a key is not in the table (cannot happen after a successful insert of the same keys)
-int map_set_masks_dev(gk_map *m, const u64 *d_keys, const uint8_t *d_masks, u64 n, u32 *d_err) {
-    gk_ctx *ctx = m->ctx;
-    if (!n) return GK_OK;
-    if (m->W == 1) hipLaunchKernelGGL((k_set_masks<1>), dim3(ggrid(ctx, n)), dim3(BLOCK), 0, ctx->stream, graph_table_of<1>(m), m->k, d_keys, d_masks, n, d_err);
-    else hipLaunchKernelGGL((k_set_masks<2>), dim3(ggrid(ctx, n)), dim3(BLOCK), 0, ctx->stream, graph_table_of<2>(m), m->k, d_keys, d_masks, n, d_err);
     GK_HIP(ctx, hipGetLastError());
     return GK_OK;
 }

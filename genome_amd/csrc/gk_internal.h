@@ -234,10 +234,10 @@ int dclass_count(gk_map *m, int rank, int P, uint64_t s0, uint64_t s1, unsigned 
 int dclass_fill(gk_map *m, int rank, int P, uint64_t s0, uint64_t s1, const unsigned long long *d_off, unsigned long long *d_cur, uint64_t *d_qkeys, uint64_t *d_qref);
 int dclass_answer(gk_map *m, const uint64_t *d_keys, uint64_t n, uint8_t *d_ans);
 int dclass_apply(gk_map *m, const uint64_t *d_qref, const uint8_t *d_ans, uint64_t n);
-int map_set_masks_dev(gk_map *m, const uint64_t *d_keys, const uint8_t *d_masks, uint64_t n, uint32_t *d_err);
 int map_materialize(gk_map *m);                      // run a deferred clear so that the slots are valid
 int map_add_keys_direct(gk_map *m, const uint64_t *d_keys, uint64_t n);   // k_add_keys on device keys (W words each)
 int map_insert_keys_dev(gk_map *m, const uint64_t *d_keys, uint64_t n, bool verbatim);
+int map_add_unique_keys_dev(gk_map *m, const uint64_t *d_keys, const int32_t *d_counts, const uint8_t *d_masks, uint64_t n);   // absent, distinct keys into a graph-layout table
 int map_add_counted_keys_dev(gk_map *m, const uint64_t *d_keys, const int32_t *d_counts, uint64_t n);   // update(key, c, _ + c), canonical device keys   // update(key, 1, _+1) for device keys, either path
 int map_export_range_dev(gk_map *m, uint64_t s0, uint64_t s1, uint64_t *d_keys, int32_t *d_cnt, unsigned long long *d_cursor, uint64_t *n_out, uint8_t *d_masks = nullptr);
 int map_to_graph_layout(gk_map *m);                  // 8-byte keys in 12-byte count slots -> 16-byte graph slots (streaming rebuild); no-op otherwise

@@ -114,6 +114,28 @@ __global__ __launch_bounds__(BLOCK) void k_add_keys(const u64 *__restrict__ keys
     if (threadIdx.x == 0 && s_claimed) atomicAdd(&ctr->size, (unsigned long long)s_claimed);
 }
 
+// putNew-like insert of keys that are KNOWN to be absent and distinct (the gather of a PartitionedDNAMap: every key has exactly
+// one owner), graph layout: one CAS claims the slot, count and — when the owners classified their keys — the degree mask go in
+// with plain stores.  No second lookup for the mask, no count atomic.
+template <int W>
+__global__ __launch_bounds__(BLOCK) void k_add_unique(const u64 *__restrict__ keys, const i32 *__restrict__ counts, const uint8_t *__restrict__ masks, u64 n,
+                                                      Table<W> t, Counters *ctr) {
+    u32 err = 0;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        Kmer<W> key;
+        if constexpr (W == 1) key = Kmer<1>{keys[i]};
+        else key = Kmer<2>{keys[2 * i], keys[2 * i + 1]};
+        const u64 h = slot_hash(key);
+        Slot<W> *seg = t.slots + ((u64)seg_of(t, h) << SegBits<W>::value);
+        const i64 at = seg_claim_unique(seg, home_pos(t, h), key, t.tagged);
+        if (at < 0) { err = 1; continue; }
+        seg[at].extra = (u32)counts[i] - 1u;
+        seg[at].aux = masks ? (u32)masks[i] : 0u;
+    }
+    if (err) ctr->error = 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->size, (unsigned long long)n);
+}
+
 // ArrayDNAMap.rescale (ArrayDNAMap.scala:217-230): move every live (key, count) into a new table.
 template <int W, class SO, class SN>
 __global__ __launch_bounds__(BLOCK) void k_rehash(const SO *__restrict__ old, u64 ncap, Table<W, SN> t, Counters *ctr) {   // old and new share t.tagged
@@ -1540,6 +1562,20 @@ int map_add_keys_direct(gk_map *m, const uint64_t *d_keys, uint64_t n) { return 
 int map_add_counted_keys_dev(gk_map *m, const uint64_t *d_keys, const int32_t *d_counts, uint64_t n) {
     if (int rc = map_materialize(m)) return rc;
     return n ? add_keys_dev(m, d_keys, d_counts, n) : GK_OK;
+}
+// the same for keys known to be absent and distinct, into a GRAPH-layout table that was sized for them (gk_map_create_for_graph):
+// counts and optional degree masks stored beside the claim (k_add_unique)
+int map_add_unique_keys_dev(gk_map *m, const uint64_t *d_keys, const int32_t *d_counts, const uint8_t *d_masks, uint64_t n) {
+    gk_ctx *ctx = m->ctx;
+    if (int rc = map_materialize(m)) return rc;
+    if (!n) return GK_OK;
+    if (m->W == 1 && m->layout != LAYOUT_GRAPH) return fail(ctx, GK_E_STATE, "map_add_unique_keys_dev: count-layout table");
+    if (int rc = map_reserve(m, n)) return rc;
+    const int grid = grid_for(ctx, n, BLOCK);
+    if (m->W == 1) hipLaunchKernelGGL((k_add_unique<1>), dim3(grid), dim3(BLOCK), 0, ctx->stream, d_keys, d_counts, d_masks, n, table_of<1, Slot<1>>(m), m->d_ctr);
+    else hipLaunchKernelGGL((k_add_unique<2>), dim3(grid), dim3(BLOCK), 0, ctx->stream, d_keys, d_counts, d_masks, n, table_of<2, Slot<2>>(m), m->d_ctr);
+    GK_HIP(ctx, hipGetLastError());
+    return map_sync_counters(m);
 }
 // the live (key, count) of slots [s0, s1) of m, packed into d_keys (W words per key) / d_cnt; d_cursor: 8 bytes of device scratch
 int map_export_range_dev(gk_map *m, uint64_t s0, uint64_t s1, uint64_t *d_keys, int32_t *d_cnt, unsigned long long *d_cursor, uint64_t *n_out, uint8_t *d_masks) {

@@ -4,22 +4,35 @@ profiles/r02/pmc_c3_<tag>.json.  FETCH_SIZE x2 (gfx950 correction, see summarize
 kernel NAME over the whole flow (three count batches, one graph build)."""
 import collections, csv, glob, json, os, sys
 tag = sys.argv[1]
-out_dir = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02"
+out_dir = sys.argv[2] if len(sys.argv) > 2 else "profiles/r03"
 res = json.load(open(f"gpurun_out/{tag}_c3prof.json"))
+
+
+def short(name):
+    """k_classify<1, gk::Table<1, gk::Slot<1> > > -> k_classify<1>: the kernel and its key width (round 3 templated the kernels on the
+    table / slot type as well; the C3 flow runs one instantiation of each)"""
+    name = name.replace("void ", "").split("(")[0]
+    if "<" not in name:
+        return name
+    base, args = name.split("<", 1)
+    return f"{base}<{args.split(',')[0].split('>')[0].strip()}>"
+
 
 
 def counters(kind):
     f = max(glob.glob(f"gpurun_out/{tag}_c3pmc_{kind}/*/*counter_collection.csv"), key=os.path.getmtime)
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(f)):
-        agg[r["Kernel_Name"].replace("void ", "").split("(")[0]][r["Counter_Name"]] += float(r["Counter_Value"])
+        agg[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
     return agg
 
 
 stats = {}
 f = max(glob.glob(f"gpurun_out/{tag}_c3prof/*/*kernel_stats.csv"), key=os.path.getmtime)
 for r in csv.DictReader(open(f)):
-    stats[r["Name"].replace("void ", "").split("(")[0]] = (int(r["Calls"]), float(r["TotalDurationNs"]) / 1e6)
+    nm = short(r["Name"])
+    c0, m0 = stats.get(nm, (0, 0.0))
+    stats[nm] = (c0 + int(r["Calls"]), m0 + float(r["TotalDurationNs"]) / 1e6)
 fetch, write, req = counters("fetch"), counters("write"), counters("req")
 try:
     rdsz = counters("rdsz")          # optional fourth pass: TCC_EA0_RDREQ_{32B,64B,128B}_sum (scripts/runs/gpu_run33.sh)
@@ -31,7 +44,8 @@ walked = res["build_stats"]["walked_bases"]
 # SURVEY.md §8(d) algorithmic bytes of the graph-phase kernels; the count pipeline's are in bench.py's c3 object
 algo = {"k_classify<1>": ("80 B per live key", 80.0 * good), "k_walk_q<1>": ("9.25 B per walked base", 9.25 * walked),
         "k_filter_lt<1>": ("20 B per slot (12 scan + 8 tombstone)", 20.0 * slots_count),
-        "k_rehash<1>": ("16 B read per old slot + 16 B written per survivor", 16.0 * slots_count + 16.0 * good)}
+        "k_rehash<1>": ("16 B read per old slot + 16 B written per survivor", 16.0 * slots_count + 16.0 * good),
+        "k_compact_seg<1>": ("20 B per slot (SURVEY's figure for scan + tombstone; this pass reads 12 B per old slot and writes 16 B per new slot)", 20.0 * slots_count)}
 doc = {"command": f"scripts/prof_c3_pmc.sh {tag}: rocprofv3 --kernel-trace --stats, then three separate --pmc passes, over scripts/run_c3.py (C3, resident reads)",
        "corrections": "FETCH_SIZE x2 (gfx950), FETCH/WRITE_SIZE in units of 1024 B; sums over all launches of a kernel in the flow",
        "reading": "every read request of every kernel here is a 128-byte line (rd_request_sizes), also for the random probes of k_classify / k_walk_q: "
