@@ -1132,7 +1132,7 @@ template <int V> __device__ __forceinline__ u32 cc_find(u32 *parent, u32 v) {
     while (p != v) {
         const u32 gp = parent[p];
         if (gp == p) { v = p; break; }
-        if (V == 0) parent[v] = gp;     // (v is not a root and never becomes one again: no CAS targets this word)
+        if (V == 0 || V == 3) parent[v] = gp;     // (v is not a root and never becomes one again: no CAS targets this word)
         v = gp; p = parent[v];
     }
     if (V == 2 && v != v0 && parent[v0] != v) parent[v0] = v;
@@ -1144,6 +1144,12 @@ template <int V> __global__ __launch_bounds__(BLOCK) void k_cc_link(GraphView g,
         u32 ru = cc_find<V>(parent, g.e_start[e]), rv = cc_find<V>(parent, g.e_end[e]);
         while (ru != rv) {
             if (ru < rv) { const u32 x = ru; ru = rv; rv = x; }
+            if (V == 3) {
+                // look before the CAS (a device-scope load: another XCD's hook is visible): when two large trees meet, thousands of
+                // edges want the same root's word, and a failed same-address CAS costs what a successful one does
+                const u32 cur = __hip_atomic_load(&parent[ru], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur != ru) { ru = cc_find<V>(parent, cur); rv = cc_find<V>(parent, rv); continue; }
+            }
             const u32 old = atomicCAS(&parent[ru], ru, rv);
             if (old == ru) break;
             ru = cc_find<V>(parent, old);
@@ -2164,6 +2170,7 @@ static int graph_components(gk_graph *g, u32 **parent_out, u32 **size_out, u64 *
     const int gn = ggrid(ctx, std::max<u64>(v.n_nodes, 1)), ge = ggrid(ctx, std::max<u64>(v.n_edges, 1));
     hipLaunchKernelGGL(k_cc_init, dim3(gn), dim3(BLOCK), 0, ctx->stream, v, parent);
     if (ctx->hook_cc_find == 1) hipLaunchKernelGGL(k_cc_link<1>, dim3(ge), dim3(BLOCK), 0, ctx->stream, v, parent);
+    else if (ctx->hook_cc_find == 3) hipLaunchKernelGGL(k_cc_link<3>, dim3(ge), dim3(BLOCK), 0, ctx->stream, v, parent);
     else if (ctx->hook_cc_find == 2) hipLaunchKernelGGL(k_cc_link<2>, dim3(ge), dim3(BLOCK), 0, ctx->stream, v, parent);
     else hipLaunchKernelGGL(k_cc_link<0>, dim3(ge), dim3(BLOCK), 0, ctx->stream, v, parent);
     e = hipGetLastError();

@@ -1,6 +1,7 @@
 """Rehearsal of an 8-GPU configuration's REPLICA at full size on one MI355X: >= 1.5e9 solid 55-mers (C4's whole k-mer set;
 BASELINE.json configs[3]) counted from error-free synthetic reads, gathered through the real collective (a communicator of
-one rank: chunked export -> insert into a table sized by graph_table_load), then Graph.buildGraph -> removeBubbles ->
+one rank: chunked export -> insert into a table sized by graph_table_load; in its classified form, so the first buildGraph takes the
+degree masks that came with the keys and the second one classifies by itself), then Graph.buildGraph -> removeBubbles ->
 simplifyGraph -> retainLargest, with the context's device-memory high-water mark per stage.
 
     python scripts/rehearse_replica.py [--k 55] [--genome 1500000000] [--coverage 6] [--out gpurun_out/replica_c4.json]
@@ -31,6 +32,8 @@ def main():
     ap.add_argument("--coverage", type=float, default=6.0)
     ap.add_argument("--chunk", type=int, default=10_000_000)
     ap.add_argument("--both", type=int, default=1, help="1: build the graph in both unitig constructions and compare")
+    ap.add_argument("--classified", type=int, default=1, help="1: the gather in its classified form — the FIRST build then takes the owners' masks, "
+                    "the second classifies by itself, and the two graphs must be the same")
     ap.add_argument("--out", default="gpurun_out/replica.json")
     a = ap.parse_args()
     k, G, L_ = a.k, a.genome, 150
@@ -58,8 +61,9 @@ def main():
     ctx.trim()
     base = ctx.mem_stats(reset_peak=True)["live"] - local_bytes
     t0 = time.perf_counter()
-    full = dm.gathered()
+    full = dm.gathered(classified=bool(a.classified))      # (one rank: every neighbour is local; the masks travel into the replica)
     rep["gather_s"] = time.perf_counter() - t0
+    rep["gather_classified"] = bool(a.classified)
     rep["gather_peak_bytes"] = ctx.mem_stats()["peak"] - base          # local partition + replica + staging
     rep["local_table_bytes"] = local_bytes
     assert full.verify_checksum() == dm.local.verify_checksum()
@@ -76,6 +80,8 @@ def main():
         g = buildGraph(k, full)
         rep[name + "_build_s"] = time.perf_counter() - t0
         rep[name + "_build"] = g.buildStats()
+        if a.both and a.classified:
+            assert rep[name + "_build"]["classified_by_owners"] == (mode == 1)      # the masks serve the first build only
         out[name] = (g.counts(), g.checksum())
         rep[name + "_build_peak_bytes"] = ctx.mem_stats(reset_peak=True)["peak"] - base
         print(name, out[name], rep[name + "_build_s"], flush=True)
