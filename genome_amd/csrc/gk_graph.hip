@@ -1124,8 +1124,13 @@ __global__ __launch_bounds__(BLOCK) void k_cc_init(GraphView g, u32 *parent) {
 // only ever go to smaller ids, so there are no cycles, a stale read is an older ancestor (a longer walk, never a wrong one),
 // and the root a component ends with is its smallest node id — the label the round-2 form (min-label hooking + full
 // compression, repeated until nothing moved: 5-7 rounds of two kernels and a host round trip each, 7 ms at C3) converged to.
-// V = how a find shortens the paths it walks (A/B, "cc_find": 0 = path halving, every hop writes; 1 = nothing is written;
-// 2 = only the node the find started from is pointed at the root it found)
+// What bounds the pass is not its reads (12.8e9 requests/s by PMC, a quarter of the random-read ceiling) but same-address
+// atomics: when two large trees meet, thousands of edges want the same root's word at once, and a CAS that fails costs what one
+// that succeeds does (~88 per microsecond on one address, chip-wide).  So a device-scope LOAD looks first and the CAS is only
+// sent when the word still names a root: k_cc_link 5.6 -> ~2 ms, retainLargest at C3 8.4 -> 4.7 ms
+// (profiles/r03/ab_components_find_variants.txt).
+// V (A/B, "cc_find"): 3 = path halving, every hop writes, and the link looks before its CAS (the default); 0 = the same without
+// the look; 1 = nothing is written on the way; 2 = only the node the find started from is pointed at the root it found
 template <int V> __device__ __forceinline__ u32 cc_find(u32 *parent, u32 v) {
     const u32 v0 = v;
     u32 p = parent[v];

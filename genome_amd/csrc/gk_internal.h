@@ -36,7 +36,8 @@ struct gk_ctx {
                                      // a batch that outgrows the fan-out between its levels can be staged with a small table
     int hook_min_lnb1 = 0;           // test hook: tables of enough segments get at least 2^this L1 buckets (9, 10: the fan-out of tables beyond 34 GB)
     int hook_dist_small_send = 0;    // test hook: the next gk_dist_route_begin on this context gets a send buffer of so many records (forces the in-place re-route)
-    int hook_cc_find = 0;            // A/B: how the components' find shortens paths (gk_graph.hip: cc_find)
+    int hook_cc_find = 3;            // A/B: the components' link pass (gk_graph.hip: cc_find / k_cc_link): 3 = path halving + look before the CAS (default);
+                                     // 0 = halving only, 1 = no path writes, 2 = only the start node is re-pointed
     int hook_dist_fail_classify = 0; // test hook: this context's next classified gather cannot stage its queries (GK_E_CAPACITY after the sizes round)
     int hook_dist_fail = 0;          // test hook: this context's next exchange fails locally with this code before anything is posted (the peers must drop the batch too)
     int hook_dist_ahead = -1;        // gk_dist_count_routed with three batches begun: 0 = do not post the next batch's exchange ahead (every rank alike)
