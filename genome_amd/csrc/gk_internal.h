@@ -36,6 +36,7 @@ struct gk_ctx {
                                      // a batch that outgrows the fan-out between its levels can be staged with a small table
     int hook_min_lnb1 = 0;           // test hook: tables of enough segments get at least 2^this L1 buckets (9, 10: the fan-out of tables beyond 34 GB)
     int hook_dist_small_send = 0;    // test hook: the next gk_dist_route_begin on this context gets a send buffer of so many records (forces the in-place re-route)
+    int hook_target_load_pct = 0;    // A/B: load factor new tables are sized for, in percent (0: 65)
     int hook_cc_find = 3;            // A/B: the components' link pass (gk_graph.hip: cc_find / k_cc_link): 3 = path halving + look before the CAS (default);
                                      // 0 = halving only, 1 = no path writes, 2 = only the start node is re-pointed
     int hook_dist_fail_classify = 0; // test hook: this context's next classified gather cannot stage its queries (GK_E_CAPACITY after the sizes round)

@@ -581,7 +581,11 @@ int ctx_check_format(gk_ctx *ctx) {
 // Load limits: grow before a batch could exceed max_load; size for target_load.  A tagged table
 // (k = 64) is four interleaved sub-tables of a quarter segment each, so it runs emptier.
 static inline double max_load(const gk_map *m) { return m->k == 64 ? 0.6 : 0.8; }
-static inline double target_load(const gk_map *m) { return m->k == 64 ? 0.45 : 0.65; }
+static inline double target_load(const gk_map *m) {
+    if (m->k == 64) return 0.45;
+    if (m->ctx && m->ctx->hook_target_load_pct > 0) return m->ctx->hook_target_load_pct / 100.0;        // A/B ("target_load_pct")
+    return 0.65;
+}
 
 // Replace the table by one of (at least) want_slots slots.  rehash = false: the old contents are void (a deferred
 // clear is pending and the caller is about to rebuild every segment from EMPTY): nothing is moved and nothing is cleared.
@@ -1600,7 +1604,7 @@ int map_export_range_dev(gk_map *m, uint64_t s0, uint64_t s1, uint64_t *d_keys, 
 int map_create_for_graph(gk_ctx *ctx, int k, uint64_t keys, gk_map **out) {
     const double load = graph_table_load(ctx, k, keys);
     // gk_map_create sizes for its own target load: hand it the key count that gives the wanted number of slots
-    gk_map probe; probe.k = k;
+    gk_map probe; probe.k = k; probe.ctx = ctx;
     const uint64_t hint = (uint64_t)((double)std::max<uint64_t>(keys, 1) / load * target_load(&probe)) + 1;
     if (int rc = gk_map_create(ctx, k, hint, out)) return rc;
     gk_map *m = *out;

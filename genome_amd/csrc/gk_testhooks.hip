@@ -50,6 +50,7 @@ int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value) {
     else if (n == "p24_pieces") ctx->hook_p24_pieces = (int)value;
     else if (n == "dist_exchange_ahead") ctx->hook_dist_ahead = (int)value;
     else if (n == "test_dist_small_send") ctx->hook_dist_small_send = (int)std::max<int64_t>(0, value);
+    else if (n == "target_load_pct") ctx->hook_target_load_pct = (int)value;
     else if (n == "cc_find") ctx->hook_cc_find = (int)value;
     else if (n == "test_dist_fail_classify") ctx->hook_dist_fail_classify = (int)value;
     else if (n == "test_dist_fail_exchange") ctx->hook_dist_fail = value > 0 ? -(int)value : (int)value;
