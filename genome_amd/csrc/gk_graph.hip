@@ -247,7 +247,10 @@ __global__ __launch_bounds__(BLOCK) void k_dc_scan(Table<W> t, int k, int rank, 
         __syncthreads();
         if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
         __syncthreads();
-        const bool live = i < s1 && slot_live(&t.slots[i]);
+        bool live = i < s1 && slot_live(&t.slots[i]);
+        // (the counting pass leaves "which neighbours are remote" in bits 8..15 of the annotation word: the filling pass skips the
+        //  keys that have none — most of them — without going over their m-mers again)
+        if (FILL && live && ((t.slots[i].aux >> 8) & 0xffu) == 0u) live = false;
         u32 remote = 0;                 // bit j: neighbour j lives on another rank
         u64 owners = 0;                 // 6 bits per neighbour
         Kmer<W> y{};
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(BLOCK) void k_dc_scan(Table<W> t, int k, int rank, 
             if (FILL) s_base[threadIdx.x] = b;
         }
         if constexpr (!FILL) {
-            if (live) t.slots[i].aux = neighbour_masks<W>(t, k, y, remote);
+            if (live) t.slots[i].aux = neighbour_masks<W>(t, k, y, remote) | (remote << 8);
         } else {
             __syncthreads();
             if (live) {
