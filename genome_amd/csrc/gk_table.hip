@@ -497,6 +497,9 @@ hipError_t pool_free(gk_ctx *ctx, void *p) {
     // The copy stream only when it carries work on pooled blocks (a route of gk_dist, a striped P5): the uploads of a host-fed
     // count go to STAGING areas, which stage_reserve / gk_map_destroy wait for themselves — a table replaced between a batch's two
     // levels must not wait here for the next chunk's 0.7 GB to arrive over PCIe (12 ms of C3's host-fed count, measured).
+    // (A gk_dist handle's communication stream is not waited for either, by protocol: a send or receive buffer is only replaced
+    //  — by dist_grow, or through the handle's garbage list — after the exchange that used it has been consumed by its owner
+    //  count, whose own stream IS waited for here; waiting for the wire in every free would stall the count beside it.)
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess && ctx->copy_stream && ctx->copy_other_pending) { e = hipStreamSynchronize(ctx->copy_stream); ctx->copy_other_pending = false; }
     if (e == hipSuccess && ctx->aux_stream) e = hipStreamSynchronize(ctx->aux_stream);
