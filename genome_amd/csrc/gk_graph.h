@@ -58,6 +58,7 @@ struct gk_graph {
     float build_ms[6] = {0, 0, 0, 0, 0, 0};
     u64 walked_bases = 0;        // bases emitted by the unitig construction (= total edge length at build time)
     int used_pj = 0;
+    bool index_ready = false;    // the k-mer -> node id index (nidx) exists: it is built on the first point query / by-k-mer edit, not by the build
     int used_masks = 0;          // the classify came with the table (masks computed by the keys' owners, gk_dist_gather_map): no k_classify ran
     float mbt_ms = 0;            // building the minimizer-bucketed copy of the table, when the build used one ("graph_mbt")
     u64 mbt_slots = 0;
@@ -87,4 +88,5 @@ int check_graph(const gk_graph *g);
 int ggrid(const gk_ctx *ctx, u64 items);                  // grid of BLOCK-thread workgroups for `items` work items
 int graph_refresh_counts(gk_graph *g);                    // live nodes / edges / bases; bumps the graph's epoch
 int graph_build_index(gk_graph *g);                       // k-mer -> node id index
+inline int graph_ensure_index(gk_graph *g) { return g->index_ready ? 0 : graph_build_index(g); }   // before any kernel that calls node_find / reads nidx
 int graph_grow_nodes(gk_graph *g, u64 new_cap);

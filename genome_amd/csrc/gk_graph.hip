@@ -1674,6 +1674,7 @@ int graph_build_index(gk_graph *g) {
         GK_HIP(ctx, hipGetLastError());
     }
     GK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    g->index_ready = true;
     return GK_OK;
 }
 
@@ -1855,7 +1856,9 @@ template <int W, class TT> static int graph_build_impl(gk_map *m, gk_graph *g, T
         if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: pool"));
         g->pool_cap = 1;
     }
-    if ((rc = graph_build_index(g)) != GK_OK) return done(rc);
+    // (the k-mer -> node index serves point queries and by-k-mer edits only — GraphBuilder's own flow, components, the export and
+    //  the paired-end stage go by ids: it is built by the first call that needs it, graph_ensure_index; 1.5 ms of C3's buildGraph)
+    g->index_ready = false;
     rc = graph_refresh_counts(g);
     g->walked_bases = g->live_len;
     lap(5);
@@ -2085,6 +2088,7 @@ int gk_graph_remove_edges(gk_graph *g, const uint64_t *start_lo, const uint64_t 
     gk_ctx *ctx = g->ctx;
     if (removed) *removed = 0;
     if (n == 0) return GK_OK;
+    if (int rc = graph_ensure_index(g)) return rc;             // (edges are named by their start k-mer here)
     if (!start_lo || !base || (g->W == 2 && !start_hi)) return fail(ctx, GK_E_INVALID, "null argument");
     u64 *d_lo = nullptr, *d_hi = nullptr;
     uint8_t *d_b = nullptr;
@@ -2394,6 +2398,7 @@ int gk_graph_out_order(gk_graph *g, uint64_t lo, uint64_t hi, int *bases4, int *
     if (int rc = check_graph(g)) return rc;
     gk_ctx *ctx = g->ctx;
     if (!bases4 || !count) return fail(ctx, GK_E_INVALID, "null argument");
+    if (int rc = graph_ensure_index(g)) return rc;
     int *d = nullptr, h[5] = {-1, 0, 0, 0, 0};
     GK_HIP(ctx, hipMalloc((void **)&d, 20));
     if (g->W == 1) hipLaunchKernelGGL(k_out_order<1>, dim3(1), dim3(1), 0, ctx->stream, g->v, lo, hi, d);
@@ -2492,6 +2497,7 @@ int gk_graph_position_map(gk_graph *g, gk_vmap *vm, uint64_t *entries) {
 int gk_graph_node_lookup(gk_graph *g, uint64_t lo, uint64_t hi, int base, uint32_t *node_id, uint32_t *edge_id) {
     if (int rc = check_graph(g)) return rc;
     gk_ctx *ctx = g->ctx;
+    if (int rc = graph_ensure_index(g)) return rc;
     u32 *d = nullptr, h[2] = {NONE, NONE};
     GK_HIP(ctx, hipMalloc((void **)&d, 8));
     if (g->W == 1) hipLaunchKernelGGL(k_node_lookup<1>, dim3(1), dim3(1), 0, ctx->stream, g->v, lo, hi, base, d);
@@ -2520,7 +2526,9 @@ int gk_graph_add_node(gk_graph *g, uint64_t lo, uint64_t hi, uint32_t *node_id) 
     hipLaunchKernelGGL(k_add_node, dim3(1), dim3(1), 0, ctx->stream, v, n, lo, hi);
     v.n_nodes++;
     g->live_nodes++;
-    if (2 * v.n_nodes > v.nidx_mask) {
+    if (!g->index_ready) {
+        // (no index yet: the first query builds it, this node included)
+    } else if (2 * v.n_nodes > v.nidx_mask) {
         if (int rc = graph_build_index(g)) return rc;          // the index outgrew its table: rebuild (power of two >= 2 n)
     } else {
         const u64 h = g->W == 1 ? slot_hash(Kmer<1>{lo}) : slot_hash(Kmer<2>{lo, hi});

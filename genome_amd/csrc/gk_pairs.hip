@@ -1067,7 +1067,7 @@ int gk_graph_split_by_support(gk_graph *g, const gk_support *sup, int cutoff, ui
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         (void)hipFree(d_src); (void)hipFree(d_a); (void)hipFree(d_b);
         if (e != hipSuccess) return hip_fail(ctx, e, "gk_graph_split_by_support");
-        if (int rc = graph_build_index(g)) return rc;         // several nodes share a sequence now: the index lists them all
+        g->index_ready = false;                                // several nodes share a sequence now: the next point query rebuilds the index with all of them
     }
     uint64_t removed = 0;
     if (!to_remove.empty()) { if (int rc = gk_graph_remove_edges_by_id(g, to_remove.data(), to_remove.size(), &removed)) return rc; }   // :316
