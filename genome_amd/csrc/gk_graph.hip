@@ -1,7 +1,7 @@
 // gk_graph.hip — de Bruijn graph build and structural simplification as HIP kernels (gfx950).
 //
 // Reference path replaced (S/ = /root/reference/src/main/scala/ru/ifmo/genome/):
-//   Graph.buildGraph      S/data/graph/Graph.scala:269-382   k_classify, k_collect_terminals,
+//   Graph.buildGraph      S/data/graph/Graph.scala:269-382   k_classify, k_collect_bits,
 //                                                            k_make_nodes, k_walk
 //   contains/incoming/outcoming          :270-282            gk::table_find_either (gk_device.h)
 //   MapGraph.addNode/addEdge/removeEdge  :172-195            node/edge arrays below
@@ -165,21 +165,26 @@ __device__ __forceinline__ u32 neighbour_masks(const TT &t, int k, Kmer<W> y, u3
 // op1 of Graph.buildGraph (Graph.scala:320-329) for every live stored key: incoming/outcoming
 // through `contains` on both strands (:270-282), 8 lookups per key; result kept in the slot.
 template <int W, class TT>
-__global__ __launch_bounds__(BLOCK) void k_classify(TT t, int k, unsigned long long *n_term) {
+__global__ __launch_bounds__(BLOCK) void k_classify(TT t, int k, unsigned long long *n_term /* [0] terminal k-mers, [2] their out-edges */,
+                                                    unsigned long long *termbits /* bit i of word i / 64: slot i is a terminal k-mer (and not SECONDARY) */) {
     // The table this runs on is 40 % full (map_compact): walking the slots directly leaves 60 % of every wave idle through
     // the eight lookups.  A workgroup therefore takes CLASSIFY_SPT slots per thread at a time, compacts the live ones'
     // indices into LDS (ballot + one LDS atomic per wave) and classifies from that dense list: every lane has work, and a
     // wave keeps 64 x 8 independent sectors in flight instead of ~26 x 8.
     constexpr int SPT = 8;
-    __shared__ u32 s_cnt, s_n;
+    __shared__ u32 s_cnt, s_n, s_edges;
     __shared__ uint16_t s_idx[BLOCK * SPT];
-    if (threadIdx.x == 0) s_cnt = 0;
-    u32 cnt = 0;
+    // The terminal slots of this round's window as a bitmap, written out once per round: what k_collect_bits turns into the
+    // terminal list WITHOUT reading the table again (the separate pass over all slots was 2.5 ms of C3's buildGraph).
+    __shared__ u32 s_tb[BLOCK * SPT / 32];
+    if (threadIdx.x == 0) { s_cnt = 0; s_edges = 0; }
+    u32 cnt = 0, edges = 0;
     const u64 ncap = t.capacity();
     const int lane = threadIdx.x & 63;
     for (u64 base = (u64)blockIdx.x * (BLOCK * SPT); base < ncap; base += (u64)gridDim.x * (BLOCK * SPT)) {
-        __syncthreads();                                    // the previous round's list has been consumed
+        __syncthreads();                                    // the previous round's list has been consumed (and its bitmap written)
         if (threadIdx.x == 0) s_n = 0;
+        if (threadIdx.x < BLOCK * SPT / 32) s_tb[threadIdx.x] = 0;
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < SPT; q++) {
@@ -210,13 +215,25 @@ __global__ __launch_bounds__(BLOCK) void k_classify(TT t, int k, unsigned long l
         if ((t.both || ref_hash(y) == ref_hash(rc)) && !(y == rc) && kmer_less(rc, y) && table_find(t, rc, k) >= 0) secondary = true;
         if (secondary) aux |= AUX_SECONDARY;
         s->aux = aux;
-        if (term && !secondary) cnt++;
+        if (term && !secondary) {
+            cnt++;
+            // out(y) + out(rc y) = popc(out) + popc(in); a palindrome (y == rc y, even k) is ONE node
+            edges += (y == rc) ? (u32)no : (u32)(ni + no);
+            const u32 w = s_idx[li];
+            atomicOr(&s_tb[w >> 5], 1u << (w & 31u));
+        }
     }
+        __syncthreads();
+        if (threadIdx.x < BLOCK * SPT / 64) {
+            const u64 word = (base >> 6) + threadIdx.x;
+            if (word * 64 < ncap) termbits[word] = (unsigned long long)s_tb[2 * threadIdx.x] | ((unsigned long long)s_tb[2 * threadIdx.x + 1] << 32);
+        }
     }
     __syncthreads();
     if (cnt) atomicAdd(&s_cnt, cnt);
+    if (edges) atomicAdd(&s_edges, edges);
     __syncthreads();
-    if (threadIdx.x == 0 && s_cnt) atomicAdd(n_term, (unsigned long long)s_cnt);
+    if (threadIdx.x == 0 && s_cnt) { atomicAdd(&n_term[0], (unsigned long long)s_cnt); atomicAdd(&n_term[2], (unsigned long long)s_edges); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -327,14 +344,17 @@ __global__ __launch_bounds__(BLOCK) void k_dc_apply(Table<W> t, const u64 *__res
 }
 // what k_classify derives from the masks that came with a gathered table (terminal, the SECONDARY mark of a hash-rule tie, the count of terminal k-mers)
 template <int W>
-__global__ __launch_bounds__(BLOCK) void k_finish_masks(Table<W> t, int k, unsigned long long *n_term) {
-    __shared__ u32 s_cnt;
-    if (threadIdx.x == 0) s_cnt = 0;
+__global__ __launch_bounds__(BLOCK) void k_finish_masks(Table<W> t, int k, unsigned long long *n_term, unsigned long long *termbits) {
+    __shared__ u32 s_cnt, s_edges;
+    if (threadIdx.x == 0) { s_cnt = 0; s_edges = 0; }
     __syncthreads();
-    u32 cnt = 0;
+    u32 cnt = 0, edges = 0;
     const u64 ncap = t.capacity();
-    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < ncap; i += (u64)gridDim.x * BLOCK) {
-        if (!slot_live(&t.slots[i])) continue;
+    // (wave-uniform trip count: a wave's 64 lanes hold 64 consecutive slots = one word of the terminal bitmap)
+    for (u64 i0 = (u64)blockIdx.x * BLOCK + (threadIdx.x & ~63u); i0 < ncap; i0 += (u64)gridDim.x * BLOCK) {
+        const u64 i = i0 + (threadIdx.x & 63u);
+        bool is_term = false;
+        if (i < ncap && slot_live(&t.slots[i])) {
         u32 aux = t.slots[i].aux & 0xffu;
         const int ni = __popc(aux & 15u), no = __popc(aux >> 4);
         const bool term = (ni != 1 || no != 1) && (ni != 0 || no != 0);     // Graph.scala:323
@@ -345,52 +365,34 @@ __global__ __launch_bounds__(BLOCK) void k_finish_masks(Table<W> t, int k, unsig
         if ((t.both || ref_hash(y) == ref_hash(rc)) && !(y == rc) && kmer_less(rc, y) && table_find(t, rc, k) >= 0) secondary = true;
         if (secondary) aux |= AUX_SECONDARY;
         t.slots[i].aux = aux;
-        if (term && !secondary) cnt++;
+        if (term && !secondary) { cnt++; edges += (y == rc) ? (u32)no : (u32)(ni + no); is_term = true; }
+        }
+        const unsigned long long word = __ballot(is_term);
+        if ((threadIdx.x & 63u) == 0) termbits[i0 >> 6] = word;
     }
     if (cnt) atomicAdd(&s_cnt, cnt);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_cnt) atomicAdd(n_term, (unsigned long long)s_cnt);
-}
-
-// The terminal slots, compacted.  One workgroup takes 16 slots per thread at a time and reserves its output with ONE atomic:
-// the cursor is a single address, and same-address atomics retire at ~88 per microsecond chip-wide — one per 256 slots
-// (1.25e6 of them over C3's 3.2e8-slot table) was 15 of this kernel's 16 ms.
-template <int W, class TT>
-__global__ __launch_bounds__(BLOCK) void k_collect_terminals(TT t, int k, u64 *tslots, unsigned long long *cursor,
-                                                             unsigned long long *n_edges) {
-    constexpr int PER = 16;
-    __shared__ u32 lds4[BLOCK / 64];
-    __shared__ unsigned long long s_base;
-    __shared__ u32 s_edges;
-    if (threadIdx.x == 0) s_edges = 0;
-    const u64 ncap = t.capacity();
-    const u64 ngroups = (ncap + (u64)BLOCK * PER - 1) / ((u64)BLOCK * PER);
-    u32 edges = 0;
-    for (u64 g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        // thread j takes slots j, j + BLOCK, ... of the group: coalesced loads
-        const u64 i0 = g * BLOCK * PER + threadIdx.x;
-        u32 selmask = 0;
-#pragma unroll
-        for (int q = 0; q < PER; q++) {
-            const u64 i = i0 + (u64)q * BLOCK;
-            if (i < ncap && slot_live(&t.slots[i])) {
-                const u32 aux = t.slots[i].aux;
-                if ((aux & AUX_TERMINAL) && !(aux & AUX_SECONDARY)) {
-                    selmask |= 1u << q;
-                    // out(y) + out(rc y) = popc(out) + popc(in); a palindrome (y == rc y, even k) is ONE node
-                    const Kmer<W> y = slot_key(t, i);
-                    edges += (y == revcomp(y, k)) ? __popc((aux >> 4) & 15u) : __popc(aux & 0xffu);
-                }
-            }
-        }
-        u64 o = block_reserve((u32)__popc(selmask), cursor, lds4, &s_base);
-#pragma unroll
-        for (int q = 0; q < PER; q++)
-            if (selmask & (1u << q)) tslots[o++] = i0 + (u64)q * BLOCK;
-    }
     if (edges) atomicAdd(&s_edges, edges);
     __syncthreads();
-    if (threadIdx.x == 0 && s_edges) atomicAdd(n_edges, (unsigned long long)s_edges);
+    if (threadIdx.x == 0 && s_cnt) { atomicAdd(&n_term[0], (unsigned long long)s_cnt); atomicAdd(&n_term[2], (unsigned long long)s_edges); }
+}
+
+// The terminal slots, compacted — from the bitmap the classify left (one word per 64 slots), not from the table: a thread takes one
+// word, a workgroup reserves its output with ONE atomic per 256 words (the cursor is a single address: same-address atomics retire
+// at ~88 per microsecond chip-wide).  Slots come out in ascending order inside a workgroup's share.
+__global__ __launch_bounds__(BLOCK) void k_collect_bits(const unsigned long long *__restrict__ termbits, u64 nwords, u64 *tslots, unsigned long long *cursor) {
+    __shared__ u32 lds4[BLOCK / 64];
+    __shared__ unsigned long long s_base;
+    const u64 ngroups = (nwords + BLOCK - 1) / BLOCK;
+    for (u64 g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const u64 w = g * BLOCK + threadIdx.x;
+        unsigned long long bits = w < nwords ? termbits[w] : 0ull;
+        u64 o = block_reserve((u32)__popcll(bits), cursor, lds4, &s_base);
+        while (bits) {
+            const int b = __ffsll((long long)bits) - 1;
+            tslots[o++] = w * 64 + (u64)b;
+            bits &= bits - 1;
+        }
+    }
 }
 
 // nodeMap (Graph.scala:343-347): node 2j = the stored terminal k-mer, node 2j+1 = its reverse
@@ -1686,9 +1688,11 @@ template <int W, class TT> static int graph_build_impl(gk_map *m, gk_graph *g, T
     unsigned long long *d_cnt = nullptr;     // [0] terminals [1] cursor [2] edges [3] ecursor [4] pool cursor
     u32 *d_err = nullptr;
     u64 *tslots = nullptr;
+    unsigned long long *termbits = nullptr;  // one bit per slot of the table the build reads: a terminal k-mer lives there (k_classify / k_finish_masks -> k_collect_bits)
     int rc = GK_OK;
     hipError_t e = hipMalloc((void **)&d_cnt, 8 * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&d_err, 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&termbits, std::max<u64>(tcap / 64, 1) * 8);
     if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, 64, ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_err, 0, 16, ctx->stream);
     unsigned long long h_cnt[8] = {0};
@@ -1697,6 +1701,7 @@ template <int W, class TT> static int graph_build_impl(gk_map *m, gk_graph *g, T
         if (d_cnt) (void)hipFree(d_cnt);
         if (d_err) (void)hipFree(d_err);
         if (tslots) (void)hipFree(tslots);
+        if (termbits) (void)hipFree(termbits);
         return code;
     };
     if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: alloc"));
@@ -1711,9 +1716,9 @@ template <int W, class TT> static int graph_build_impl(gk_map *m, gk_graph *g, T
     bool from_masks = false;
     if constexpr (!is_mb<TT>::value) from_masks = masks_valid;
     if constexpr (!is_mb<TT>::value) {
-        if (from_masks) hipLaunchKernelGGL((k_finish_masks<W>), dim3(ggrid(ctx, tcap)), dim3(BLOCK), 0, ctx->stream, t, k, &d_cnt[0]);
+        if (from_masks) hipLaunchKernelGGL((k_finish_masks<W>), dim3(ggrid(ctx, tcap)), dim3(BLOCK), 0, ctx->stream, t, k, &d_cnt[0], termbits);
     }
-    if (!from_masks) hipLaunchKernelGGL((k_classify<W, TT>), dim3(ggrid(ctx, tcap)), dim3(BLOCK), 0, ctx->stream, t, k, &d_cnt[0]);
+    if (!from_masks) hipLaunchKernelGGL((k_classify<W, TT>), dim3(ggrid(ctx, tcap)), dim3(BLOCK), 0, ctx->stream, t, k, &d_cnt[0], termbits);
     g->used_masks = from_masks ? 1 : 0;
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, ctx->stream);
@@ -1725,12 +1730,13 @@ template <int W, class TT> static int graph_build_impl(gk_map *m, gk_graph *g, T
     // 2. terminal slots -> nodes (both strands) and edge stubs
     e = hipMalloc((void **)&tslots, std::max<u64>(nT, 1) * 8);
     if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: alloc nodes"));
-    hipLaunchKernelGGL((k_collect_terminals<W, TT>), dim3(ggrid(ctx, tcap / 16 + 1)), dim3(BLOCK), 0, ctx->stream, t, k, tslots, &d_cnt[1], &d_cnt[2]);
+    hipLaunchKernelGGL(k_collect_bits, dim3(ggrid(ctx, tcap / 64 + 1)), dim3(BLOCK), 0, ctx->stream, termbits, tcap / 64, tslots, &d_cnt[1]);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(h_cnt, d_cnt, 24, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return done(hip_fail(ctx, e, "gk_graph_build: collect"));
     if (h_cnt[1] != nT) return done(fail(ctx, GK_E_STATE, "terminal count mismatch"));
+    (void)hipFree(termbits); termbits = nullptr;                 // (an eighth of a byte per slot: gone before the graph arrays exist)
     const u64 nE = h_cnt[2];
     if (nE >= (u64)NONE) return done(fail(ctx, GK_E_CAPACITY, "more than 2^32 graph edges"));
     if ((rc = graph_alloc_nodes(g, 2 * nT)) != GK_OK) return done(rc);
