@@ -1215,6 +1215,13 @@ __global__ __launch_bounds__(SBLOCK, GK_P5_MIN_WAVES) void k_seg_insert(Table<W,
 #if GK_ABL_P5 == 3                      // timing-only: the write-out without the conversion (the LDS image's first 24 KiB as they are)
 #pragma unroll
                     for (u32 i = threadIdx.x; i < GVEC; i += SBLOCK) gseg[i] = lds_raw[i];
+#elif GK_ABL_P5 == 4                    // A/B: every thread packs ITS four slots (no selects) and stores three vectors at a 48-byte stride
+                    for (u32 g4 = threadIdx.x; g4 < S / 4; g4 += SBLOCK) {
+                        const Slot<1> a0 = seg[4 * g4], a1 = seg[4 * g4 + 1], a2 = seg[4 * g4 + 2], a3 = seg[4 * g4 + 3];
+                        gseg[3 * g4] = make_uint4(cfield(a0, 0), cfield(a0, 1), a0.extra, cfield(a1, 0));
+                        gseg[3 * g4 + 1] = make_uint4(cfield(a1, 1), a1.extra, cfield(a2, 0), cfield(a2, 1));
+                        gseg[3 * g4 + 2] = make_uint4(a2.extra, cfield(a3, 0), cfield(a3, 1), a3.extra);
+                    }
 #else
 #pragma unroll 1
                     for (u32 i = threadIdx.x; i < GVEC; i += SBLOCK) gseg[i] = cslot_vec_from_lds(seg, i);
