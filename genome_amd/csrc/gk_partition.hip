@@ -929,6 +929,26 @@ __device__ __forceinline__ u32 lds_add_unbounded(Slot<1> *seg, u32 pos, Kmer<1> 
     atomicAdd(&seg[i].extra, 1u);
     return 0u;
 }
+// The unbounded insert WITHOUT divergent control flow (GK_P5_FLAT, A/B): every lane issues its compare-and-swap in every trip —
+// a lane that is through swaps its own key for its own key (or fails), which changes nothing — so the
+// loop needs no exec-mask bookkeeping (the scalar instructions of the divergent form), at the price of predicated vector
+// instructions and LDS atomics for lanes that are done.
+__device__ __forceinline__ u32 lds_add_unbounded_flat(Slot<1> *seg, u32 pos, Kmer<1> key, bool valid) {
+    constexpr u32 smask = (1u << SegBits<1>::value) - 1u;
+    u32 i = pos;
+    bool done = !valid, claimed = false, found = false;
+    do {
+        const u64 expect = done ? key.lo : KEY_EMPTY;              // (done: key -> key where the key sits, a failure anywhere else)
+        const u64 old = atomicCAS(reinterpret_cast<unsigned long long *>(&seg[i].w0), (unsigned long long)expect, (unsigned long long)key.lo);
+        const bool e = old == KEY_EMPTY, k = old == key.lo;
+        claimed = claimed || (!done && e);
+        found = found || (!done && k);
+        done = done || e || k;
+        i = done ? i : ((i + 1) & smask);
+    } while (__any(!done));
+    if (found) atomicAdd(&seg[i].extra, 1u);
+    return claimed ? 1u : 0u;
+}
 // TWO keys of a lane in flight (GK_P5_ILP, A/B): an insert is a chain of dependent LDS round trips, a wave repeats it until its
 // slowest lane is through, and the kernel's issue ports are not what it waits for (a cheaper hash changes nothing, eight waves
 // per SIMD are all the LDS allows) — so a lane walks two independent chains per trip instead of one.  Same slot protocol: the
@@ -1059,6 +1079,12 @@ static constexpr int SBLOCK = GK_SBLOCK;               // threads per segment wo
 #endif
 #ifndef GK_P5_MIN_WAVES
 #define GK_P5_MIN_WAVES 8
+#endif
+#ifndef GK_P5_FORCE_LOOK
+#define GK_P5_FORCE_LOOK 0
+#endif
+#ifndef GK_P5_FLAT
+#define GK_P5_FLAT 0                    // 1: the unbounded insert without divergent control flow (lds_add_unbounded_flat)
 #endif
 #ifndef GK_P5_ILP
 #define GK_P5_ILP 0                     // 1: two keys of a lane in flight in the unbounded insert (lds_add_unbounded2)
@@ -1193,8 +1219,25 @@ __global__ __launch_bounds__(SBLOCK, GK_P5_MIN_WAVES) void k_seg_insert(Table<W,
             bool overflow = false;
             // fewer keys than free slots: cannot fill up -> unbounded one-CAS probe; more keys than that are repeats
             // (or the table is too small): bounded look-first probe; k = 64 keeps the general tagged form
+#if GK_P5_FORCE_LOOK                    // A/B: the look-first probe (a plain LDS read per step, a CAS only on an empty slot) for every segment
+            const int mode = t.tagged ? 2 : 1;
+#else
             const int mode = t.tagged ? 2 : (cnt < (from_empty ? S : flags[2]) ? 0 : 1);
+#endif
             auto insert_block = [&](Kmer<W> (&kk)[KPT], u32 nk) {
+#if GK_P5_FLAT
+                if constexpr (W == 1) {
+                    if (mode == 0) {
+#pragma unroll
+                        for (int j = 0; j < KPT; j++) {
+                            if ((u32)j * SBLOCK >= nk) continue;             // (workgroup-uniform: nobody has a key in this round)
+                            const bool va = threadIdx.x + j * SBLOCK < nk;
+                            claims += lds_add_unbounded_flat(seg, home_pos(t, slot_hash(kk[j])), kk[j], va);
+                        }
+                        return;
+                    }
+                }
+#endif
 #if GK_P5_ILP
                 if constexpr (W == 1 && KPT % 2 == 0) {
                     if (mode == 0) {
