@@ -929,45 +929,6 @@ __device__ __forceinline__ u32 lds_add_unbounded(Slot<1> *seg, u32 pos, Kmer<1> 
     atomicAdd(&seg[i].extra, 1u);
     return 0u;
 }
-// The unbounded insert WITHOUT divergent control flow (GK_P5_FLAT, A/B): every lane issues its compare-and-swap in every trip —
-// a lane that is through swaps its own key for its own key (or fails), which changes nothing — so the
-// loop needs no exec-mask bookkeeping (the scalar instructions of the divergent form), at the price of predicated vector
-// instructions and LDS atomics for lanes that are done.
-__device__ __forceinline__ u32 lds_add_unbounded_flat(Slot<1> *seg, u32 pos, Kmer<1> key, bool valid) {
-    constexpr u32 smask = (1u << SegBits<1>::value) - 1u;
-    u32 i = pos;
-    bool done = !valid, claimed = false, found = false;
-    do {
-        const u64 expect = done ? key.lo : KEY_EMPTY;              // (done: key -> key where the key sits, a failure anywhere else)
-        const u64 old = atomicCAS(reinterpret_cast<unsigned long long *>(&seg[i].w0), (unsigned long long)expect, (unsigned long long)key.lo);
-        const bool e = old == KEY_EMPTY, k = old == key.lo;
-        claimed = claimed || (!done && e);
-        found = found || (!done && k);
-        done = done || e || k;
-        i = done ? i : ((i + 1) & smask);
-    } while (__any(!done));
-    if (found) atomicAdd(&seg[i].extra, 1u);
-    return claimed ? 1u : 0u;
-}
-// TWO keys of a lane in flight (GK_P5_ILP, A/B): an insert is a chain of dependent LDS round trips, a wave repeats it until its
-// slowest lane is through, and the kernel's issue ports are not what it waits for (a cheaper hash changes nothing, eight waves
-// per SIMD are all the LDS allows) — so a lane walks two independent chains per trip instead of one.  Same slot protocol: the
-// two compare-and-swaps of a lane are ordered like any two lanes' (the second sees what the first wrote).
-__device__ __forceinline__ u32 lds_add_unbounded2(Slot<1> *seg, u32 pa, Kmer<1> ka, bool va, u32 pb, Kmer<1> kb, bool vb) {
-    constexpr u32 smask = (1u << SegBits<1>::value) - 1u;
-    bool da = !va, db = !vb;
-    u64 oa = KEY_EMPTY, ob = KEY_EMPTY;
-    while (!(da && db)) {
-        if (!da) oa = atomicCAS(reinterpret_cast<unsigned long long *>(&seg[pa].w0), (unsigned long long)KEY_EMPTY, (unsigned long long)ka.lo);
-        if (!db) ob = atomicCAS(reinterpret_cast<unsigned long long *>(&seg[pb].w0), (unsigned long long)KEY_EMPTY, (unsigned long long)kb.lo);
-        if (!da) { if (oa == KEY_EMPTY || oa == ka.lo) da = true; else pa = (pa + 1) & smask; }
-        if (!db) { if (ob == KEY_EMPTY || ob == kb.lo) db = true; else pb = (pb + 1) & smask; }
-    }
-    u32 claimed = 0;
-    if (va) { if (oa == KEY_EMPTY) claimed++; else atomicAdd(&seg[pa].extra, 1u); }
-    if (vb) { if (ob == KEY_EMPTY) claimed++; else atomicAdd(&seg[pb].extra, 1u); }
-    return claimed;
-}
 __device__ __forceinline__ u32 lds_add_unbounded(Slot<2> *seg, u32 pos, Kmer<2> key) {
     constexpr u32 smask = (1u << SegBits<2>::value) - 1u;
     const Stored<2> k = to_stored(key);
@@ -1079,15 +1040,6 @@ static constexpr int SBLOCK = GK_SBLOCK;               // threads per segment wo
 #endif
 #ifndef GK_P5_MIN_WAVES
 #define GK_P5_MIN_WAVES 8
-#endif
-#ifndef GK_P5_FORCE_LOOK
-#define GK_P5_FORCE_LOOK 0
-#endif
-#ifndef GK_P5_FLAT
-#define GK_P5_FLAT 0                    // 1: the unbounded insert without divergent control flow (lds_add_unbounded_flat)
-#endif
-#ifndef GK_P5_ILP
-#define GK_P5_ILP 0                     // 1: two keys of a lane in flight in the unbounded insert (lds_add_unbounded2)
 #endif
 template <class ST> struct LdsSlotOf { typedef ST type; };
 template <> struct LdsSlotOf<CSlot> { typedef Slot<1> type; };
@@ -1219,38 +1171,8 @@ __global__ __launch_bounds__(SBLOCK, GK_P5_MIN_WAVES) void k_seg_insert(Table<W,
             bool overflow = false;
             // fewer keys than free slots: cannot fill up -> unbounded one-CAS probe; more keys than that are repeats
             // (or the table is too small): bounded look-first probe; k = 64 keeps the general tagged form
-#if GK_P5_FORCE_LOOK                    // A/B: the look-first probe (a plain LDS read per step, a CAS only on an empty slot) for every segment
-            const int mode = t.tagged ? 2 : 1;
-#else
             const int mode = t.tagged ? 2 : (cnt < (from_empty ? S : flags[2]) ? 0 : 1);
-#endif
             auto insert_block = [&](Kmer<W> (&kk)[KPT], u32 nk) {
-#if GK_P5_FLAT
-                if constexpr (W == 1) {
-                    if (mode == 0) {
-#pragma unroll
-                        for (int j = 0; j < KPT; j++) {
-                            if ((u32)j * SBLOCK >= nk) continue;             // (workgroup-uniform: nobody has a key in this round)
-                            const bool va = threadIdx.x + j * SBLOCK < nk;
-                            claims += lds_add_unbounded_flat(seg, home_pos(t, slot_hash(kk[j])), kk[j], va);
-                        }
-                        return;
-                    }
-                }
-#endif
-#if GK_P5_ILP
-                if constexpr (W == 1 && KPT % 2 == 0) {
-                    if (mode == 0) {
-#pragma unroll
-                        for (int j = 0; j < KPT; j += 2) {
-                            const bool va = threadIdx.x + j * SBLOCK < nk, vb = threadIdx.x + (j + 1) * SBLOCK < nk;
-                            if (!va && !vb) continue;
-                            claims += lds_add_unbounded2(seg, home_pos(t, slot_hash(kk[j])), kk[j], va, home_pos(t, slot_hash(kk[j + 1])), kk[j + 1], vb);
-                        }
-                        return;
-                    }
-                }
-#endif
 #pragma unroll
                 for (int j = 0; j < KPT; j++) {
                     if (threadIdx.x + j * SBLOCK >= nk) continue;
