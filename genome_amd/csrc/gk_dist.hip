@@ -593,8 +593,8 @@ static int dist_gather(gk_dist *d, gk_map *local, gk_map **full, bool classify) 
     if (classify) { pre_rc = map_to_graph_layout(local); if (pre_rc) pre_err = ctx->err; }
     constexpr u64 CHS = 1ull << 25;
     // live keys of every rank, and the number of chunks of the rank with the largest table
-    // (one maximum over all ranks carries both: the number of chunks in its low 32 bits, "some partition holds verbatim
-    //  non-canonical keys" above them — the replica holds every partition's keys, so it is dirty if ANY of them is)
+    // (one maximum over all ranks carries both: the chunk count of SOME rank in its low 40 bits and, above them, "some partition holds verbatim
+    //  non-canonical keys" — the replica holds every partition's keys, so it is dirty if ANY of them is; the chunk count itself is a second maximum)
     unsigned long long mine[2] = {local->size, ((local->capacity + CHS - 1) / CHS) | (local->dirty ? 1ull << 40 : 0ull)};
     GK_HIP(ctx, hipMemcpyAsync(d->d_cnt + 2 * 64, mine, 16, hipMemcpyHostToDevice, ctx->stream));
     GK_NCCL(ctx, xAllGather(d, d->d_cnt + 2 * 64, d->d_cnt, 1, ncclUint64, ctx->stream));
