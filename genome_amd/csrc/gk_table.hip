@@ -1169,14 +1169,17 @@ static u64 reads_per_launch(gk_map *m, u64 nk) {
     return std::max<u64>(1, occ / nk);
 }
 // how many windows one partitioned batch may hold: bounded by the scratch it needs (two key buffers, the spill list)
-// next to what is free in HBM — half of it at most — and by 16 GiB of keys per buffer (gk_map_set_max_batch_keys changes
+// next to what is free in HBM — half of it at most — and by 64 GiB of keys per buffer (gk_map_set_max_batch_keys changes
 // that).  Big batches pay: every batch after the first streams the whole table in and out again
 static u64 part_batch_keys(gk_map *m) {
-    // (default: key buffers of 16 GiB — hipMalloc of much larger ones takes seconds the first time — OR scratch as large as
-    //  the table itself, whichever is more: behind a 74 GB table every further batch of a call streams those 74 GB in and out
-    //  again, 25 ms each; k = 55, 1.9e9 windows: 101 ms in two batches, 70 in one — profiles/r03/big_table_74GB_k55.json)
+    // (default: key buffers of up to 64 GiB, or scratch as large as the table itself, whichever is more — and never more than
+    //  half of what is free, below.  Every further batch of a call streams the whole table in and out again: C3's 6e9 windows
+    //  in three batches of 2^31 (16 GiB buffers, the default until the end of round 3) 103.3 ms, in one batch 98.5
+    //  (profiles/r03/c3_count_vs_batch_size.txt); k = 55 into a 74 GB table 101 -> 70 ms (big_table_74GB_k55.json).  The card
+    //  has 288 GB to be used; allocating is not what costs (alloc_cost_by_size.txt), and a caller that shares the card says so
+    //  with gk_ctx_set_mem_budget or gk_map_set_max_batch_keys.)
     const double per_key = 8.0 * m->W * (1.125 + 1.0 + 1.0 / 16) + 1.0;      // bufA + bufB + spill (+ range matrix, bounded above)
-    u64 cap = m->max_batch_keys ? m->max_batch_keys : (1ull << 31) / (u64)m->W;
+    u64 cap = m->max_batch_keys ? m->max_batch_keys : (1ull << 33) / (u64)m->W;         // 64 GiB of keys per buffer
     if (!m->max_batch_keys) cap = std::max<u64>(cap, (u64)((double)m->capacity * (double)map_slot_bytes(m) / per_key));
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {

@@ -121,7 +121,7 @@ int gk_map_slots(gk_map *m, uint64_t *slots);              /* current table capa
  * PartitionedDNAMap is the sum of its partitions' checksums mod 2^64).  Any may be NULL. */
 int gk_map_verify(gk_map *m, uint64_t *live, uint64_t *bad_slots, uint64_t *sum_counts, uint64_t *checksum);
 /* Upper bound on the k-mer windows one partitioned insert batch holds when a call brings more windows than the
- * table has room for (the batch's key scratch is ~17 x W bytes per window); 0 = default (16 GiB of keys, half of the free HBM at most). */
+ * table has room for (the batch's key scratch is ~17 x W bytes per window); 0 = default (64 GiB of keys per buffer or as much scratch as the table itself holds, half of the free HBM at most). */
 int gk_map_set_max_batch_keys(gk_map *m, uint64_t keys);
 /* Release the scratch the handle keeps between calls (key buffers of the partitioned insert, staging of host streams,
  * point-query scratch).  The table is untouched; the next call allocates what it needs again. */
