@@ -43,7 +43,7 @@ def run(label, f, reps=2, filter_first=False):
 
 run("device-resident", lambda: m.count_reads_dev(d, N, L), reps=3)
 variants = [("host default", {}), ("host_prefetch=0", {"host_prefetch": 0}), ("host default again", {}), ("max_stage=704MiB", {"test_max_stage": 704 << 20}),
-            ("max_stage=352MiB", {"test_max_stage": 352 << 20}), ("max_stage=1408MiB", {"test_max_stage": 1408 << 20}),
+            ("max_stage=352MiB", {"test_max_stage": 352 << 20}), ("max_stage=1408MiB", {"test_max_stage": 1408 << 20}), ("max_stage=2047MiB (one chunk)", {"test_max_stage": 2047 << 20}),
             ("max_stage=704MiB, host_prefetch=0", {"test_max_stage": 704 << 20, "host_prefetch": 0})]
 for label, opts in variants:
     for name, v in opts.items():
