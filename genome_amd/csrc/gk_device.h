@@ -131,21 +131,7 @@ GK_HD u64 mix64(u64 x) {
     x ^= x >> 33;
     return x;
 }
-// (A/B, variant builds only: GK_SLOT_MIX = 1 places slots with ONE 64-bit multiply between two xor-shifts instead of the
-//  finaliser's two — the multiplies are quarter-rate instructions and every pipeline kernel hashes every key)
-#ifndef GK_SLOT_MIX
-#define GK_SLOT_MIX 0
-#endif
-GK_HD u64 slot_mix(u64 x) {
-#if GK_SLOT_MIX == 1
-    x ^= x >> 32;
-    x *= 0xd6e8feb86659fd93ULL;
-    x ^= x >> 32;
-    return x;
-#else
-    return mix64(x);
-#endif
-}
+GK_HD u64 slot_mix(u64 x) { return mix64(x); }        // (a one-multiply mixer here changes nothing measurable: profiles/r03/ab_slot_mixer_one_multiply.txt)
 GK_HD u64 slot_hash(Kmer<1> x) { return slot_mix(x.lo); }
 GK_HD u64 slot_hash(Kmer<2> x) { return slot_mix(x.lo ^ (slot_mix(x.hi) + 0x9e3779b97f4a7c15ULL)); }
 
