@@ -24,7 +24,15 @@ extern "C" {
  * A/B switches of the kernels in gk_partition.hip / gk_graph.hip / gk_dist.hip; what each measured is in DESIGN.md and
  * profiles/r02.  "min_lnb1" (also GK_MIN_LNB1; 9 / 10: tables of enough segments get 512 / 1024 L1 buckets, the fan-out of
  * tables beyond 34 GB) and "test_max_nb2" (the pipeline refuses tables of more fine buckets per L1 bucket) stage the
- * large-table paths on small tables. */
+ * large-table paths on small tables.
+ * Round 3: "graph_mbt" / "graph_mbt_keys" (gk_graph_build on a minimizer-bucketed copy of the table; keys per bucket),
+ * "pairs_host" (1: the paired-end walks on host threads), "test_pairs_small_sets" (tiny LDS sets: walks overflow to the host
+ * walker), "host_prefetch" (0: a host-fed count does not upload the next chunk beside the current one), "test_max_stage" (bytes
+ * per staging area of a host-fed count), "cc_find" (the components' link pass: 3 = look before the CAS, the default; 0 / 1 / 2 =
+ * path halving only / no path writes / start node only), "target_load_pct" (load factor new tables are sized for, percent;
+ * 0 = 65), and the failure injections of the exchange: "test_dist_small_send" (a send region far too small: re-routed in
+ * place), "test_dist_fail_exchange" (this rank's next exchange fails locally with the given code), "test_dist_fail_classify"
+ * (this rank cannot stage the queries of its next classified gather). */
 int gk_ctx_set_option(gk_ctx *ctx, const char *name, int64_t value);
 
 /* TEST transport: the ranks are threads of ONE process on ONE device; sends, receives and reductions go through a hub in the
