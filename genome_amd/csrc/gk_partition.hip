@@ -66,10 +66,12 @@ static constexpr int TILE2 = PBLOCK * KEYS_PER_THREAD;   // keys per chunk in P3
 static constexpr u32 MAXB1 = 1u << MAX_LNB1;      // L1 buckets at most (256 for every table up to 34 GB, see plan_segments)
 static constexpr u32 MAX_NB2 = 4096;        // LDS bound in P3/P4 (16 B per fine bucket on top of the sorted chunk)
 #ifndef GK_MAX_RANGE_CHUNKS
-#define GK_MAX_RANGE_CHUNKS 24
+#define GK_MAX_RANGE_CHUNKS 96
 #endif
-// a range = up to 24 consecutive chunks of one L1 bucket (96 Ki keys = 8 sorts of 12288 keys, 12 of 8192: no partial sort at a
-// range's end; measured at C3, P4: 16 chunks 41.7-44.9 ms, 24: 38.5-40.0, 48: 38.9-41.9, 96: 38.5)
+// a range = up to 96 consecutive chunks of one L1 bucket (384 Ki keys = 32 sorts of 12288 keys, 48 of 8192: no partial sort at a
+// range's end; measured at C3, P4, three batches (round 2): 16 chunks 41.7-44.9 ms, 24: 38.5-40.0, 48: 38.9-41.9, 96: 38.5;
+// one batch (round 3, 23 M keys per L1 bucket): 24: 35.5-36.3, 48: 35.1-36.4, 96: 33.6-34.6.  Small batches keep enough
+// ranges to fill the chip: part_plan bounds the range by the batch's chunks per CU)
 static constexpr u32 MAX_RANGE_CHUNKS = GK_MAX_RANGE_CHUNKS;
 
 // The distinct-key SAMPLE: a key belongs to it iff bits 11..20 of its slot hash are zero (1 key in 1024, independent
